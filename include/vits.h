@@ -1,0 +1,196 @@
+/*
+ * vits.h — C ABI of the MI355X-native VITS inference library (libvits_hip.so).
+ *
+ * DROP-IN BOUNDARY. The first five entry points are byte-compatible with the reference's exported C API
+ * (/root/reference/src/include/vits.h:87-102, implemented at /root/reference/src/vits.cpp:1193-1232):
+ * same names, same argument meaning, same ownership rules. `vits_model` is opaque here (the reference exposes
+ * a C++ class with ggml-typed members, vits.h:17-85, which cannot survive without ggml; every reference
+ * caller — test/main.cpp:68-78, test/bench_e2e.cpp:68-91, test/bench.cpp:204-206 — only passes the pointer).
+ *
+ * Differences from the reference, all deliberate:
+ *   - no exception / exit(1) crosses the boundary (reference: std::runtime_error from
+ *     src/vits_model_data.cpp:102,144 and ASSERT->exit at src/include/debug.h:29-36). Failures return
+ *     NULL / {NULL,0}; the message is available from vits_last_error().
+ *   - nothing is printed to stdout (reference prints at src/vits.cpp:27,1200 and in the loaders).
+ *   - everything below "extensions" is new: id-level and batched entry points (the reference is batch-1,
+ *     text-only), synthetic model generation, taps, profiling, operator-level entry points for parity tests.
+ *
+ * Plain C types only: pointers, sizes, PODs. No torch / HIP types appear in any signature; device buffers are
+ * passed as `void*` device addresses.
+ */
+#ifndef VITS_HIP_H
+#define VITS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#define VITS_API extern "C" __attribute__((visibility("default")))
+#else
+#define VITS_API __attribute__((visibility("default")))
+#endif
+
+typedef struct vits_model vits_model; /* opaque */
+
+/* reference: src/include/vits.h:89-92 */
+typedef struct vits_result {
+    float* data; /* mono fp32 PCM in [-1,1]; owned by the library until vits_free_result */
+    size_t size; /* samples */
+} vits_result;
+
+/* ---- the reference's five symbols ------------------------------------------------------------------- */
+
+/* reference: vits.h:94, vits.cpp:1205-1215. Copies what it needs; caller may free `bytes` on return. */
+VITS_API vits_model* vits_model_load_from_bytes(const char* bytes, size_t size);
+/* reference: vits.h:96, vits.cpp:1193-1203 */
+VITS_API vits_model* vits_model_load_from_file(const char* path);
+/* reference: vits.h:98, vits.cpp:1217-1219 */
+VITS_API void vits_free_model(vits_model* model);
+/* reference: vits.h:100, vits.cpp:1221-1223 */
+VITS_API void vits_free_result(vits_result result);
+/* reference: vits.h:102, vits.cpp:1225-1232 -> vits_model::process vits.cpp:1101-1191.
+ * Text is lower-cased, greedily matched against the model vocabulary and interspersed with blanks
+ * (src/vits_tokenizer.cpp:182-208). Noise comes from the reference's process-global libstdc++ stream
+ * (VITS_NOISE_REFERENCE), mode is the model default (VITS_MODE_REFERENCE unless changed). */
+VITS_API vits_result vits_model_process(vits_model* model, const char* phonemes);
+
+/* ---- extensions ------------------------------------------------------------------------------------- */
+
+/* Thread-local message of the last failure in this thread ("" if none). */
+VITS_API const char* vits_last_error(void);
+
+/* Semantics mode:
+ *   VITS_MODE_REFERENCE: what /root/reference/src/vits.cpp literally computes: ConvTranspose1d without
+ *     crop (Q1, vits.cpp:187), final LeakyReLU slope 0.1 (Q2, :638), spline width affine (Q3, :720),
+ *     index -1 wrap on the last token (Q4, ggml-util.h:235), exp(+log_scale) (Q5, :913-918).
+ *   VITS_MODE_HF: what transformers.VitsModel (the model the reference ports, vits.cpp:113) computes. */
+#define VITS_MODE_DEFAULT (-1)
+#define VITS_MODE_REFERENCE 0
+#define VITS_MODE_HF 1
+VITS_API int vits_model_set_mode(vits_model* model, int mode);
+VITS_API int vits_model_get_mode(const vits_model* model);
+
+/* Noise source for the two N(0,1) draws (vits.cpp:948 [T,2] and :1059 [L,192]). */
+#define VITS_NOISE_REFERENCE 0 /* libstdc++ minstd_rand0 + normal_distribution<float>, global, host-serial */
+#define VITS_NOISE_COUNTER 1   /* include/vits_synth_noise.h, evaluated on the device                       */
+#define VITS_NOISE_EXPLICIT 2  /* caller-provided host buffers                                             */
+/* Re-seed the reference noise stream (the reference never does: default seed 1, vits.cpp:31). */
+VITS_API void vits_reference_noise_seed(uint32_t seed);
+
+typedef struct vits_process_opts {
+    uint32_t struct_size;        /* = sizeof(vits_process_opts) */
+    int32_t mode;                /* VITS_MODE_*; VITS_MODE_DEFAULT = model default */
+    int32_t noise_kind;          /* VITS_NOISE_* */
+    uint64_t noise_seed;         /* VITS_NOISE_COUNTER: utterance u uses seed noise_seed + u */
+    const float* noise_dur;      /* VITS_NOISE_EXPLICIT: host [B][2][id_stride] */
+    const float* noise_prior;    /* VITS_NOISE_EXPLICIT: host [B][192][noise_prior_stride] */
+    int64_t noise_prior_stride;  /* frames between channels in noise_prior */
+    int32_t fixed_duration;      /* >0: every id lasts this many frames (pinned-length benchmark run) */
+    int32_t collect_taps;        /* 1: keep stage outputs for vits_model_get_tap */
+    void* out_device;            /* optional device buffer [B][out_device_stride] fp32 to receive the PCM */
+    int64_t out_device_stride;   /* samples; must be >= the longest utterance */
+    int32_t skip_host_copy;      /* 1: leave PCM on the device only (requires out_device or tap access) */
+    int32_t async;               /* 1: return without synchronising the stream (requires skip_host_copy and
+                                    fixed_duration>0, the only case with no data-dependent host read);
+                                    call vits_model_sync() before touching out_device */
+} vits_process_opts;
+
+typedef struct vits_batch_result {
+    float* data;      /* host [batch][stride] PCM (NULL when skip_host_copy) */
+    size_t stride;    /* samples between utterances */
+    int64_t* lengths; /* [batch] samples per utterance */
+    int64_t* frames;  /* [batch] spectrogram frames per utterance (L) */
+    size_t batch;
+} vits_batch_result;
+
+/* One utterance from ids (already blank-interspersed, i.e. what input_ids_tensor holds at vits.cpp:1109-1111);
+ * same noise/mode behaviour as vits_model_process. */
+VITS_API vits_result vits_model_process_ids(vits_model* model, const int32_t* ids, size_t n_ids);
+
+/* B independent utterances; ids is host [B][id_stride], id_lengths[b] <= id_stride valid ids in row b.
+ * Utterances never interact: results equal B separate batch-1 calls. Returns 0 on success. */
+VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch,
+                                      int32_t id_stride, const vits_process_opts* opts, vits_batch_result* out);
+VITS_API void vits_free_batch_result(vits_batch_result* r);
+/* Block until everything queued by this model has finished. */
+VITS_API int vits_model_sync(vits_model* model);
+
+/* Tokenizer only (src/vits_tokenizer.cpp:182-208). Writes up to cap ids, returns the count (or -1). */
+VITS_API int64_t vits_model_tokenize(vits_model* model, const char* text, int32_t* ids, size_t cap);
+
+/* Model facts. */
+VITS_API int32_t vits_model_sampling_rate(const vits_model* model);
+VITS_API int32_t vits_model_vocab_size(const vits_model* model);
+VITS_API int64_t vits_model_weight_bytes(const vits_model* model);
+
+/* Stage outputs of the LAST call with collect_taps=1, for utterance `utt`, copied to host as a dense
+ * [channels][len] fp32 array. Names: "enc_out" [192][T], "prior_mean" [192][T], "prior_logvar" [192][T],
+ * "log_duration" [1][T], "durations" [1][T] (integer-valued), "z_p" [192][L], "z_flow" [192][L],
+ * "pre_tanh" [1][S], "waveform" [1][S], plus "noise_dur" [2][T] and "noise_prior" [192][L].
+ * Returns the element count (0 = unknown tap), copies min(count, cap) floats. */
+VITS_API int64_t vits_model_get_tap(vits_model* model, const char* name, int32_t utt, float* dst, size_t cap);
+
+/* ---- synthetic model files (no real checkpoint is available) --------------------------
+ * Builds a complete model file in the reference's on-disk format (writer
+ * scripts/export_vits.py:5-70) with the default MMS-TTS architecture (or the tiny test architecture) and
+ * deterministic weights derived from `seed`. Conv weights are stored as fp16 like export_vits.py:87. */
+#define VITS_SYNTH_FULL 0 /* VitsConfig defaults == facebook/mms-tts-* architecture */
+#define VITS_SYNTH_TINY 1 /* hidden 16 / small vocoder: small enough to commit as a fixture */
+VITS_API int vits_synth_model_bytes(uint64_t seed, int32_t arch, char** bytes, size_t* size);
+VITS_API void vits_free_bytes(char* bytes);
+
+/* ---- profiling (HIP events on the library's own stream) ------------------------------------------------
+ * While enabled every kernel launch is bracketed by hipEventRecord on the launch stream. The report is a
+ * JSON object {"kernels":[{"name":..,"calls":..,"ms":..,"flop":..,"bytes":..},...]} written into buf. */
+VITS_API int vits_prof_enable(vits_model* model, int32_t on);
+VITS_API int vits_prof_reset(vits_model* model);
+VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap);
+
+/* ---- operator-level entry points (host buffers in, host buffers out; for parity tests) ---------------
+ * Each mirrors one reference operator so a test can compare the HIP kernel with the oracle's restatement
+ * of the same reference lines. All tensors are dense fp32, layout [batch][channels][time], time fastest
+ * (== the reference's ggml ne order [time, channels, batch]). lens may be NULL (all = T). */
+
+/* conv1d_with_bias (vits.cpp:171-176 -> custom-ops.h:680-694) with the fusions the engine uses.
+ * y = post( conv(pre(x)) + bias ), pre: 0 none, 1 leaky_relu(slope); post: 0 none, 1 relu,
+ * 2 gated tanh*sigmoid over channel halves (vits.cpp:442-450; Cout must be even, output has Cout/2 channels);
+ * then y = (y + residual) if residual, y = (y + accum) * out_scale if accum.
+ * w is [Cout][Cin][K] (torch layout). pad_left/pad_right zero padding; output length T (same-length conv
+ * requires pad_left + pad_right == (K-1)*dilation). */
+typedef struct vits_conv1d_desc {
+    int32_t batch, cin, cout, t, t_stride;
+    int32_t k, dilation, pad_left;
+    int32_t pre_act; /* 0 none, 1 leaky_relu */
+    float pre_slope;
+    int32_t post_act; /* 0 none, 1 relu, 2 gate */
+    float out_scale;  /* applied when accum != NULL */
+} vits_conv1d_desc;
+VITS_API int vits_op_conv1d(const vits_conv1d_desc* d, const float* x, const float* w, const float* bias,
+                            const float* residual, const float* accum, const int32_t* lens, float* y);
+
+/* conv_transpose_1d_with_bias (vits.cpp:178-193). w is [Cin][Cout][K] (torch layout), K == 2*stride.
+ * crop = (K-stride)/2 in HF mode (HF modeling_vits.py:483-490), 0 in reference mode (vits.cpp:187, Q1).
+ * Output length = stride*T + K - stride - 2*crop. pre-activation leaky_relu(slope) is fused (vits.cpp:613). */
+typedef struct vits_convt1d_desc {
+    int32_t batch, cin, cout, t, t_stride, t_out_stride;
+    int32_t k, stride, crop;
+    float pre_slope; /* leaky_relu slope applied to x first; 1.0 = none */
+} vits_convt1d_desc;
+VITS_API int vits_op_conv_transpose1d(const vits_convt1d_desc* d, const float* x, const float* w, const float* bias,
+                                      const int32_t* lens, float* y);
+
+/* Relative-position multi-head self-attention core (vits.cpp:296-356):
+ * q,k,v [B][H*hd][T] (q already scaled), rel_k/rel_v [2w+1][hd] shared by heads; out [B][H*hd][T]. */
+VITS_API int vits_op_rel_attention(int32_t batch, int32_t heads, int32_t head_dim, int32_t t, int32_t t_stride,
+                                   int32_t window, const float* q, const float* k, const float* v,
+                                   const float* rel_k, const float* rel_v, const int32_t* lens, float* out);
+
+/* layer_norm over channels of (x + residual) (vits.cpp:115-120,365-372). */
+VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, int32_t t_stride, float eps,
+                                    const float* x, const float* residual, const float* gamma, const float* beta,
+                                    float* y);
+
+/* Device facts (for the bench's roofline block). */
+VITS_API int vits_device_info(char* name, size_t cap, int32_t* cu_count, int32_t* clock_mhz, int64_t* hbm_bytes);
+
+#endif /* VITS_HIP_H */
