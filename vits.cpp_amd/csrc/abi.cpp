@@ -1,0 +1,420 @@
+// abi.cpp — the C ABI of include/vits.h. Nothing below throws across the boundary (the reference lets
+// std::runtime_error escape and calls exit(1) from ASSERT: /root/reference/src/vits_model_data.cpp:102,144,
+// src/include/debug.h:29-36); failures return NULL / {NULL,0} / -1 and set vits_last_error().
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vits.h"
+#include "engine.h"
+
+namespace vits {
+void reference_noise_seed(uint32_t seed);
+}
+
+static thread_local std::string g_last_error;
+static void set_err(const std::string& e) { g_last_error = e; }
+
+#define VITS_TRY try {
+#define VITS_CATCH(ret)                           \
+    }                                             \
+    catch (const std::exception& e) {             \
+        set_err(e.what());                        \
+        return ret;                               \
+    }                                             \
+    catch (...) {                                 \
+        set_err("unknown exception");             \
+        return ret;                               \
+    }
+
+VITS_API const char* vits_last_error(void) { return g_last_error.c_str(); }
+
+// reference: src/vits.cpp:1205-1215
+VITS_API vits_model* vits_model_load_from_bytes(const char* bytes, size_t size) {
+    VITS_TRY
+    if (!bytes) {
+        set_err("null model bytes");
+        return nullptr;
+    }
+    vits_model* m = new vits_model();
+    std::string err;
+    if (!m->eng.load(reinterpret_cast<const uint8_t*>(bytes), size, err)) {
+        set_err(err);
+        delete m;
+        return nullptr;
+    }
+    return m;
+    VITS_CATCH(nullptr)
+}
+
+// reference: src/vits.cpp:1193-1203 -> vits_model_data::from_file src/vits_model_data.cpp:99-109
+VITS_API vits_model* vits_model_load_from_file(const char* path) {
+    VITS_TRY
+    if (!path) {
+        set_err("null path");
+        return nullptr;
+    }
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) {
+        set_err(std::string("[ERROR] failed to open file: ") + path);  // message of vits_model_data.cpp:102
+        return nullptr;
+    }
+    std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return vits_model_load_from_bytes(buf.data(), buf.size());
+    VITS_CATCH(nullptr)
+}
+
+// reference: src/vits.cpp:1217-1219
+VITS_API void vits_free_model(vits_model* model) {
+    try {
+        delete model;
+    } catch (...) {
+    }
+}
+
+// reference: src/vits.cpp:1221-1223 (scalar delete on new[] there, Q12; both sides are ours here)
+VITS_API void vits_free_result(vits_result result) { delete[] result.data; }
+
+static vits_result process_ids_impl(vits_model* model, const int32_t* ids, size_t n) {
+    vits_result r{nullptr, 0};
+    if (!model || !ids || n == 0) {
+        set_err(n == 0 ? "empty input (no known symbols in the text)" : "null argument");
+        return r;
+    }
+    vits_process_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.struct_size = sizeof(o);
+    o.mode = VITS_MODE_DEFAULT;
+    o.noise_kind = VITS_NOISE_REFERENCE;
+    vits_batch_result br;
+    std::memset(&br, 0, sizeof(br));
+    std::string err;
+    const int32_t len = (int32_t)n;
+    if (model->eng.process_batch(ids, &len, 1, (int)n, o, &br, err) != 0) {
+        set_err(err);
+        vits_free_batch_result(&br);
+        return r;
+    }
+    // vits.cpp:1226-1231: a fresh buffer of exactly `size` samples owned by the library
+    r.size = (size_t)br.lengths[0];
+    r.data = new float[r.size];
+    std::memcpy(r.data, br.data, sizeof(float) * r.size);
+    vits_free_batch_result(&br);
+    return r;
+}
+
+// reference: src/vits.cpp:1225-1232 -> vits_model::process :1101-1191
+VITS_API vits_result vits_model_process(vits_model* model, const char* phonemes) {
+    vits_result none{nullptr, 0};
+    VITS_TRY
+    if (!model || !phonemes) {
+        set_err("null argument");
+        return none;
+    }
+    std::vector<int32_t> ids = model->eng.tok.tokenize(phonemes);  // vits.cpp:1109
+    return process_ids_impl(model, ids.data(), ids.size());
+    VITS_CATCH(none)
+}
+
+VITS_API vits_result vits_model_process_ids(vits_model* model, const int32_t* ids, size_t n_ids) {
+    vits_result none{nullptr, 0};
+    VITS_TRY
+    return process_ids_impl(model, ids, n_ids);
+    VITS_CATCH(none)
+}
+
+VITS_API int vits_model_set_mode(vits_model* model, int mode) {
+    if (!model || (mode != VITS_MODE_REFERENCE && mode != VITS_MODE_HF)) {
+        set_err("bad mode");
+        return -1;
+    }
+    model->eng.mode = mode;
+    return 0;
+}
+VITS_API int vits_model_get_mode(const vits_model* model) { return model ? model->eng.mode : -1; }
+VITS_API void vits_reference_noise_seed(uint32_t seed) { vits::reference_noise_seed(seed); }
+
+VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
+                                      const vits_process_opts* opts, vits_batch_result* out) {
+    VITS_TRY
+    if (out) std::memset(out, 0, sizeof(*out));
+    if (!model || !ids) {
+        set_err("null argument");
+        return -1;
+    }
+    vits_process_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.mode = VITS_MODE_DEFAULT;
+    o.noise_kind = VITS_NOISE_COUNTER;
+    if (opts) std::memcpy(&o, opts, std::min<size_t>(sizeof(o), opts->struct_size ? opts->struct_size : sizeof(o)));
+    std::string err;
+    const int rc = model->eng.process_batch(ids, id_lengths, batch, id_stride, o, out, err);
+    if (rc != 0) {
+        set_err(err);
+        if (out) vits_free_batch_result(out);
+    }
+    return rc;
+    VITS_CATCH(-1)
+}
+
+VITS_API void vits_free_batch_result(vits_batch_result* r) {
+    if (!r) return;
+    delete[] r->data;
+    delete[] r->lengths;
+    delete[] r->frames;
+    std::memset(r, 0, sizeof(*r));
+}
+
+VITS_API int vits_model_sync(vits_model* model) {
+    VITS_TRY
+    if (!model) return -1;
+    std::string err;
+    const int rc = model->eng.sync(err);
+    if (rc) set_err(err);
+    return rc;
+    VITS_CATCH(-1)
+}
+
+VITS_API int64_t vits_model_tokenize(vits_model* model, const char* text, int32_t* ids, size_t cap) {
+    VITS_TRY
+    if (!model || !text) return -1;
+    std::vector<int32_t> v = model->eng.tok.tokenize(text);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) ids[i] = v[i];
+    return (int64_t)v.size();
+    VITS_CATCH(-1)
+}
+
+VITS_API int32_t vits_model_sampling_rate(const vits_model* model) { return model ? model->eng.hp.sampling_rate : 0; }
+VITS_API int32_t vits_model_vocab_size(const vits_model* model) { return model ? model->eng.hp.vocab_size : 0; }
+VITS_API int64_t vits_model_weight_bytes(const vits_model* model) { return model ? model->eng.weight_bytes : 0; }
+
+VITS_API int64_t vits_model_get_tap(vits_model* model, const char* name, int32_t utt, float* dst, size_t cap) {
+    VITS_TRY
+    if (!model || !name) return 0;
+    return model->eng.get_tap(name, utt, dst, cap);
+    VITS_CATCH(0)
+}
+
+VITS_API int vits_synth_model_bytes(uint64_t seed, int32_t arch, char** bytes, size_t* size) {
+    VITS_TRY
+    if (!bytes || !size) return -1;
+    vits::ModelFile f = vits::make_synthetic_model(seed, arch);
+    std::vector<uint8_t> v = f.serialize();
+    *bytes = new char[v.size()];
+    std::memcpy(*bytes, v.data(), v.size());
+    *size = v.size();
+    return 0;
+    VITS_CATCH(-1)
+}
+VITS_API void vits_free_bytes(char* bytes) { delete[] bytes; }
+
+VITS_API int vits_prof_enable(vits_model* model, int32_t on) {
+    if (!model) return -1;
+    model->eng.prof.on = on != 0;
+    return 0;
+}
+VITS_API int vits_prof_reset(vits_model* model) {
+    if (!model) return -1;
+    hipStreamSynchronize(model->eng.stream);
+    model->eng.prof.reset();
+    return 0;
+}
+VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap) {
+    VITS_TRY
+    if (!model || !buf || !cap) return -1;
+    hipStreamSynchronize(model->eng.stream);
+    std::string s = model->eng.prof.report();
+    const size_t n = std::min(cap - 1, s.size());
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    return (int64_t)s.size();
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_device_info(char* name, size_t cap, int32_t* cu_count, int32_t* clock_mhz, int64_t* hbm_bytes) {
+    VITS_TRY
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_err("no HIP device");
+        return -1;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        set_err("hipGetDeviceProperties failed");
+        return -1;
+    }
+    if (name && cap) {
+        std::snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = p.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return 0;
+    VITS_CATCH(-1)
+}
+
+// ---- operator-level entry points: host in, host out ---------------------------------------------------------
+namespace {
+struct DevBuf {
+    float* p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    bool put(const float* h, size_t n) {
+        if (hipMalloc((void**)&p, std::max<size_t>(n, 1) * 4) != hipSuccess) return false;
+        if (h) return hipMemcpy(p, h, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+        return hipMemset(p, 0, n * 4) == hipSuccess;
+    }
+};
+struct DevInts {
+    int* p = nullptr;
+    ~DevInts() {
+        if (p) hipFree(p);
+    }
+    bool put(const int32_t* h, size_t n) {
+        if (!h) return true;
+        if (hipMalloc((void**)&p, n * 4) != hipSuccess) return false;
+        return hipMemcpy(p, h, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+};
+vits::TensorRef tref(float* p, int channels, int stride) {
+    vits::TensorRef t;
+    t.p = p;
+    t.cs = stride;
+    t.bs = (int64_t)channels * stride;
+    return t;
+}
+int fail(const char* what) {
+    set_err(what);
+    return -1;
+}
+}  // namespace
+
+VITS_API int vits_op_conv1d(const vits_conv1d_desc* d, const float* x, const float* w, const float* bias, const float* residual, const float* accum,
+                            const int32_t* lens, float* y) {
+    VITS_TRY
+    using namespace vits;
+    if (!d || !x || !w || !y) return fail("null argument");
+    const int gate = d->post_act == 2;
+    const int cy = gate ? d->cout / 2 : d->cout;
+    PackedConv pc;
+    pc.cin = d->cin;
+    pc.cout = d->cout;
+    pc.kt = d->k;
+    pc.epi = gate ? EPI_GATE : EPI_STD;
+    std::vector<float> packed = pack_conv_weights(w, d->cout, d->cin, d->k, pc.epi, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
+    DevBuf dw, db, dx, dy, dr, da;
+    DevInts dl;
+    const size_t nx = (size_t)d->batch * d->cin * d->t_stride, ny = (size_t)d->batch * cy * d->t_stride;
+    if (!dw.put(packed.data(), packed.size()) || !dx.put(x, nx) || !dy.put(nullptr, ny) || !dl.put(lens, d->batch)) return fail("device allocation failed");
+    if (bias && !db.put(bias, d->cout)) return fail("device allocation failed");
+    if (residual && !dr.put(residual, ny)) return fail("device allocation failed");
+    if (accum && !da.put(accum, ny)) return fail("device allocation failed");
+    pc.wp = dw.p;
+    pc.bias = db.p;
+    ConvCall c;
+    c.x = tref(dx.p, d->cin, d->t_stride);
+    c.y = tref(dy.p, cy, d->t_stride);
+    if (residual) c.res = tref(dr.p, cy, d->t_stride);
+    if (accum) c.acc = tref(da.p, cy, d->t_stride);
+    c.len_in = dl.p;
+    c.len_out = dl.p;
+    c.batch = d->batch;
+    c.t_in = c.t_out = d->t;
+    c.dil = d->dilation;
+    c.pad_l = d->pad_left;
+    c.pre_act = d->pre_act;
+    c.slope = d->pre_slope;
+    c.post_act = d->post_act == 1 ? 1 : 0;
+    c.scale = d->out_scale;
+    hipError_t e = launch_conv(pc, c, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_op_conv_transpose1d(const vits_convt1d_desc* d, const float* x, const float* w, const float* bias, const int32_t* lens, float* y) {
+    VITS_TRY
+    using namespace vits;
+    if (!d || !x || !w || !y) return fail("null argument");
+    if (d->k != 2 * d->stride) return fail("kernel must be 2*stride");
+    PackedConv pc;
+    pc.cin = d->cin;
+    pc.cout = d->cout;
+    pc.kt = 2;
+    pc.epi = EPI_CONVT;
+    pc.ct_stride = d->stride;
+    std::vector<float> packed = pack_conv_weights(w, d->cout, d->cin, d->k, EPI_CONVT, d->stride, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
+    DevBuf dw, db, dx, dy;
+    DevInts dl, dlo;
+    const size_t nx = (size_t)d->batch * d->cin * d->t_stride, ny = (size_t)d->batch * d->cout * d->t_out_stride;
+    std::vector<int32_t> lo;
+    if (lens) {
+        lo.resize(d->batch);
+        for (int b = 0; b < d->batch; ++b) lo[b] = d->stride * lens[b] + d->k - d->stride - 2 * d->crop;
+    }
+    if (!dw.put(packed.data(), packed.size()) || !dx.put(x, nx) || !dy.put(nullptr, ny) || !dl.put(lens, d->batch) || !dlo.put(lens ? lo.data() : nullptr, d->batch))
+        return fail("device allocation failed");
+    if (bias && !db.put(bias, d->cout)) return fail("device allocation failed");
+    pc.wp = dw.p;
+    pc.bias = db.p;
+    ConvCall c;
+    c.x = tref(dx.p, d->cin, d->t_stride);
+    c.y = tref(dy.p, d->cout, d->t_out_stride);
+    c.len_in = dl.p;
+    c.len_out = dlo.p;
+    c.batch = d->batch;
+    c.t_in = d->t;
+    c.t_out = d->stride * d->t + d->k - d->stride - 2 * d->crop;
+    c.pre_act = d->pre_slope != 1.0f;
+    c.slope = d->pre_slope;
+    c.ct_crop = d->crop;
+    hipError_t e = launch_conv(pc, c, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_op_rel_attention(int32_t batch, int32_t heads, int32_t head_dim, int32_t t, int32_t t_stride, int32_t window, const float* q, const float* k,
+                                   const float* v, const float* rel_k, const float* rel_v, const int32_t* lens, float* out) {
+    VITS_TRY
+    using namespace vits;
+    const int C = heads * head_dim;
+    const size_t n = (size_t)batch * C * t_stride, nr = (size_t)(2 * window + 1) * head_dim;
+    DevBuf dq, dk, dv, drk, drv, dout;
+    DevInts dl;
+    if (!dq.put(q, n) || !dk.put(k, n) || !dv.put(v, n) || !drk.put(rel_k, nr) || !drv.put(rel_v, nr) || !dout.put(nullptr, n) || !dl.put(lens, batch))
+        return fail("device allocation failed");
+    hipError_t e = launch_rel_attention(tref(dq.p, C, t_stride), tref(dk.p, C, t_stride), tref(dv.p, C, t_stride), drk.p, drv.p, tref(dout.p, C, t_stride), dl.p, batch,
+                                        heads, head_dim, t, window, 1.0f, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, int32_t t_stride, float eps, const float* x, const float* residual,
+                                    const float* gamma, const float* beta, float* y) {
+    VITS_TRY
+    using namespace vits;
+    const size_t n = (size_t)batch * channels * t_stride;
+    DevBuf dx, dr, dg, db, dy;
+    if (!dx.put(x, n) || !dg.put(gamma, channels) || !db.put(beta, channels) || !dy.put(nullptr, n)) return fail("device allocation failed");
+    if (residual && !dr.put(residual, n)) return fail("device allocation failed");
+    TensorRef none;
+    hipError_t e = launch_add_layer_norm(tref(dx.p, channels, t_stride), residual ? tref(dr.p, channels, t_stride) : none, dg.p, db.p, tref(dy.p, channels, t_stride),
+                                         nullptr, batch, channels, t, eps, 0, none, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (hipMemcpy(y, dy.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
+    return 0;
+    VITS_CATCH(-1)
+}

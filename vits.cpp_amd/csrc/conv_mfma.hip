@@ -1,0 +1,394 @@
+// conv_mfma.hip — the hot kernel: Conv1d / ConvTranspose1d as an implicit GEMM on the gfx950 matrix cores,
+// exact fp32 (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, at the 157 TFLOP/s fp32 rate).
+//
+// Replaces the reference's conv1d = ggml_im2col_1d + ggml_mul_mat (+ separate bias / leaky_relu / add nodes):
+//   /root/reference/src/include/custom-ops.h:680-694 (conv1d_impl), :397-431 (bias), :894-896 (leaky_relu),
+//   :696-727 (add), called from src/vits.cpp:137-142,171-176 (conv1d[_with_bias]), :545-581 (HiFiGAN ResBlock),
+//   :452-498 (WaveNet), :384-403 (encoder FFN), :287-289,358 (Linear), :178-193 (conv_transpose_1d_with_bias).
+// Nothing is unfolded in memory: the input tile (with its (K-1)*dilation halo) is staged ONCE in LDS and every
+// tap reads it at a shifted column, so each activation is fetched from HBM once per conv instead of K times.
+//
+// GEMM view:  Y[M = out channel][N = time] = sum_{kappa = (ci, tap)} A[M][kappa] * B[kappa][N]
+//   A = weights, pre-packed at model load in exact MFMA A-fragment order -> one coalesced 16 B/lane load feeds
+//       4 consecutive MFMAs, straight from L2 (weights of one conv are <= 2.9 MB, shared by every block);
+//   B = x[ci][t + tap*dil - pad] read from the LDS tile with ds_read_b32 (lanes 0-31 / 32-63 each read 32
+//       consecutive floats: conflict-free for any dilation).
+// v_mfma_f32_32x32x2_f32 operand map (cdna guide §3): A lane l -> A[row l&31][k l>>5]; B lane l -> B[k l>>5][col l&31];
+// C/D reg r of lane l -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+//
+// Fused around the GEMM (all separate graph nodes = full DRAM passes in the reference):
+//   load side : ragged-length masking (zero padding), leaky_relu(slope)               (vits.cpp:554,567,613)
+//   store side: + bias, relu (FFN, :397) | tanh*sigmoid gate (:442-450) | residual add (:578) |
+//               resblock accumulation and the 1/num_kernels scale (:630,635) | transposed-conv phase scatter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace vits {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 32;  // input channels per LDS chunk
+
+struct ConvParams {
+    const float* x;
+    int64_t x_bs;
+    int x_cs;
+    float* y;
+    int64_t y_bs;
+    int y_cs;
+    const float* res;
+    int64_t r_bs;
+    int r_cs;
+    const float* acc;
+    int64_t a_bs;
+    int a_cs;
+    const float* wp;
+    const float* bias;
+    const int* len_in;
+    const int* len_out;
+    int t_in, t_out;
+    int cin, cout, rows, nchunks;
+    int dil, pad_l, xw, lds_off;
+    int pre_act;
+    float slope;
+    int post_act;
+    float scale;
+    int scale_div;
+    int ct_stride, ct_crop;
+};
+
+template <int KT, int WM, int WN, int MR, int NR, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+    constexpr int BN = WN * NR * 32;
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][xw]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * BN;
+    const int len_in = p.len_in ? p.len_in[b] : p.t_in;
+    // number of valid GEMM columns for this utterance
+    int ncols;
+    if (EPI == EPI_CONVT) ncols = len_in + 1;  // q in [0, L_in]: the last phase group only sees the m=1 tap
+    else ncols = p.len_out ? p.len_out[b] : p.t_out;
+    if (t0 >= ncols) return;
+
+    const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
+    const int xw = p.xw;
+    const int tile_start = t0 - p.pad_l - p.lds_off;  // global time of LDS column 0
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+
+    floatx16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int krow = lane >> 5;
+    const int col0 = wn * (NR * 32) + (lane & 31) + p.lds_off;
+    const size_t tile_floats = (size_t)p.nchunks * KT * (CK / 2) * 64;  // packed floats per 32-row tile
+    const float4* __restrict__ wbase = reinterpret_cast<const float4*>(p.wp + (size_t)mt0 * tile_floats) + lane;
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        __syncthreads();  // everyone finished reading the previous chunk
+        // ---- stage CK x xw input tile: masked, pre-activated; one wave per row, lanes along time (coalesced)
+        for (int r = wid; r < CK; r += 4) {
+            const int ch = c * CK + r;
+            const float* __restrict__ src = xb + (int64_t)ch * p.x_cs;
+            float* dst = xs + r * xw;
+            const bool chok = ch < p.cin;
+            for (int i = lane; i < xw; i += 64) {
+                const int t = tile_start + i;
+                float v = 0.f;
+                if (chok && t >= 0 && t < len_in) {
+                    v = src[t];
+                    if (p.pre_act) v = v > 0.f ? v : v * p.slope;
+                }
+                dst[i] = v;
+            }
+        }
+        __syncthreads();
+        const float4* __restrict__ wq = wbase + (size_t)c * (KT * (CK / 8) * 64);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+#pragma unroll
+            for (int p4 = 0; p4 < CK / 8; ++p4) {
+                float4 a4[MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a4[mr] = wq[(size_t)mr * (tile_floats / 4) + (j * (CK / 8) + p4) * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* xr = xs + (2 * (4 * p4 + q) + krow) * xw + col0 + j * p.dil;
+                    float bv[NR];
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) bv[nr] = xr[nr * 32];
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) {
+                        const float av = q == 0 ? a4[mr].x : q == 1 ? a4[mr].y : q == 2 ? a4[mr].z : a4[mr].w;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nr], acc[mr][nr], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    const int colbase = t0 + wn * (NR * 32) + (lane & 31);
+    const int rowoff = 4 * (lane >> 5);
+    if (EPI == EPI_STD) {
+        float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+        const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+        const float* __restrict__ ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (mt0 + mr) * 32 + (r & 3) + 8 * (r >> 2) + rowoff;
+                if (co >= p.cout) continue;
+                const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int t = colbase + nr * 32;
+                    if (t >= ncols) continue;
+                    float v = acc[mr][nr][r] + bias;
+                    if (p.post_act == 1) v = v > 0.f ? v : 0.f;
+                    if (rb) v = rb[(int64_t)co * p.r_cs + t] + v;
+                    if (ab) {
+                        v = ab[(int64_t)co * p.a_cs + t] + v;
+                        v = p.scale_div ? v / p.scale : v * p.scale;
+                    }
+                    yb[(int64_t)co * p.y_cs + t] = v;
+                }
+            }
+        }
+    } else if (EPI == EPI_GATE) {
+        // packed tile 2i = tanh rows (channels 32i..), tile 2i+1 = sigmoid rows (half + 32i..): MR == 2
+        float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+        const int half = p.cout / 2;
+        const int chbase = (mt0 / 2) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = chbase + (r & 3) + 8 * (r >> 2) + rowoff;
+            if (ch >= half) continue;
+            const float b0 = p.bias ? p.bias[ch] : 0.f, b1 = p.bias ? p.bias[ch + half] : 0.f;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = colbase + nr * 32;
+                if (t >= ncols) continue;
+                const float ta = tanhf(acc[0][nr][r] + b0);
+                const float sg = 1.0f / (1.0f + expf(-(acc[MR - 1][nr][r] + b1)));
+                yb[(int64_t)ch * p.y_cs + t] = ta * sg;
+            }
+        }
+    } else {  // EPI_CONVT: GEMM row rho = co*s + phase, column q; output sample n = s*q + phase - crop
+        float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+        const int s = p.ct_stride;
+        const int out_len = p.len_out ? p.len_out[b] : p.t_out;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = (mt0 + mr) * 32 + (r & 3) + 8 * (r >> 2) + rowoff;
+                if (rho >= p.rows) continue;
+                const int co = rho / s, ph = rho - co * s;
+                const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int q = colbase + nr * 32;
+                    const int n = s * q + ph - p.ct_crop;
+                    if (q >= ncols || n < 0 || n >= out_len) continue;
+                    yb[(int64_t)co * p.y_cs + n] = acc[mr][nr][r] + bias;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+struct TileShape {
+    int wm, wn, mr, nr;
+};
+static TileShape tile_shape(int tile) {
+    switch (tile) {
+        case TILE_128x128: return {2, 2, 2, 2};
+        case TILE_64x256: return {1, 4, 2, 2};
+        case TILE_32x256: return {1, 4, 1, 2};
+        case TILE_64x64: return {1, 4, 2, 1};  // 64 x 128
+        default: return {1, 4, 1, 1};          // TILE_32x64: 32 x 128
+    }
+}
+
+int choose_conv_tile(int rows, int epi, int t_hint) {
+    const bool small_t = t_hint <= 128;
+    if (epi == EPI_GATE) return small_t ? TILE_64x64 : TILE_64x256;
+    if (rows % 128 == 0) return TILE_128x128;
+    if (rows % 64 == 0) return small_t ? TILE_64x64 : TILE_64x256;
+    return small_t ? TILE_32x64 : TILE_32x256;
+}
+
+// Packed layout: [mtile][chunk][tap][p4 = pair/4][lane][q = pair%4]; the value for (mtile, chunk c, tap j, pair p,
+// lane l) is A[row = mtile*32 + (l&31)][ci = c*32 + 2p + (l>>5)][tap j] — lane l's A operand of the MFMA
+// that consumes input channels (2p, 2p+1) of chunk c at tap j.
+std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, int epi, int ct_stride, int* rows_out, int* mtiles_used_out,
+                                     int* mtiles_out, int* nchunks_out) {
+    const int bm_tiles = 4;  // padded so that every tile shape (1, 2 or 4 row tiles per block) divides it
+    const int half = cout / 2;
+    int rows, kt;
+    if (epi == EPI_CONVT) {
+        rows = cout * ct_stride;
+        kt = k / ct_stride;  // == 2 taps per phase
+    } else {
+        rows = cout;
+        kt = k;
+    }
+    int mtiles = (rows + 31) / 32;
+    if (epi == EPI_GATE) mtiles = 2 * ((half + 31) / 32);
+    *mtiles_used_out = mtiles;
+    mtiles = (mtiles + bm_tiles - 1) / bm_tiles * bm_tiles;
+    const int nchunks = (cin + CK - 1) / CK;
+    std::vector<float> out((size_t)mtiles * nchunks * kt * (CK / 2) * 64, 0.f);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nchunks; ++c)
+            for (int j = 0; j < kt; ++j)
+                for (int pr = 0; pr < CK / 2; ++pr)
+                    for (int l = 0; l < 64; ++l) {
+                        const int ci = c * CK + 2 * pr + (l >> 5);
+                        const int r = l & 31;
+                        float v = 0.f;
+                        if (ci < cin) {
+                            if (epi == EPI_STD) {
+                                const int co = mt * 32 + r;
+                                if (co < cout) v = w[((size_t)co * cin + ci) * k + j];
+                            } else if (epi == EPI_GATE) {
+                                const int ch = (mt / 2) * 32 + r;
+                                const int co = (mt & 1) ? half + ch : ch;
+                                if (ch < half) v = w[((size_t)co * cin + ci) * k + j];
+                            } else {
+                                // y[co][s*q + ph - crop] = sum_ci sum_m x[ci][q - m] * W[ci][co][ph + s*m]  
+                                const int rho = mt * 32 + r;
+                                const int co = rho / ct_stride, ph = rho % ct_stride;
+                                if (co < cout) v = w[((size_t)ci * cout + co) * k + ph + ct_stride * j];
+                            }
+                        }
+                        const size_t idx = (((((size_t)mt * nchunks + c) * kt + j) * (CK / 8) + pr / 4) * 64 + l) * 4 + (pr & 3);
+                        out[idx] = v;
+                    }
+    *rows_out = rows;
+    *mtiles_out = mtiles;
+    *nchunks_out = nchunks;
+    return out;
+}
+
+template <int KT, int EPI>
+static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
+    const TileShape ts = tile_shape(tile);
+    const int bn = ts.wn * ts.nr * 32;
+    const int bm_tiles = ts.wm * ts.mr;
+    dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
+    const size_t lds = (size_t)CK * p.xw * sizeof(float);
+#define VITS_LAUNCH(WM, WN, MR, NR) hipLaunchKernelGGL((conv_mfma_kernel<KT, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p)
+    switch (tile) {
+        case TILE_128x128:
+            if (EPI == EPI_GATE) return hipErrorInvalidValue;
+            VITS_LAUNCH(2, 2, 2, 2);
+            break;
+        case TILE_64x256: VITS_LAUNCH(1, 4, 2, 2); break;
+        case TILE_64x64: VITS_LAUNCH(1, 4, 2, 1); break;
+        case TILE_32x256:
+            if (EPI == EPI_GATE) return hipErrorInvalidValue;
+            VITS_LAUNCH(1, 4, 1, 2);
+            break;
+        default:
+            if (EPI == EPI_GATE) return hipErrorInvalidValue;
+            VITS_LAUNCH(1, 4, 1, 1);
+            break;
+    }
+#undef VITS_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
+    ConvParams p;
+    p.x = c.x.p;
+    p.x_bs = c.x.bs;
+    p.x_cs = c.x.cs;
+    p.y = c.y.p;
+    p.y_bs = c.y.bs;
+    p.y_cs = c.y.cs;
+    p.res = c.res.p;
+    p.r_bs = c.res.bs;
+    p.r_cs = c.res.cs;
+    p.acc = c.acc.p;
+    p.a_bs = c.acc.bs;
+    p.a_cs = c.acc.cs;
+    p.wp = w.wp;
+    p.bias = w.bias;
+    p.len_in = c.len_in;
+    p.len_out = c.len_out;
+    p.t_in = c.t_in;
+    p.t_out = c.t_out;
+    p.cin = w.cin;
+    p.cout = w.cout;
+    p.rows = w.rows;
+    p.nchunks = w.nchunks;
+    p.pre_act = c.pre_act;
+    p.slope = c.slope;
+    p.post_act = c.post_act;
+    p.scale = c.scale;
+    p.scale_div = c.scale_div;
+    p.ct_stride = w.ct_stride;
+    p.ct_crop = c.ct_crop;
+    int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
+    const int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
+    const TileShape ts = tile_shape(tile);
+    const int bn = ts.wn * ts.nr * 32;
+    if (w.epi == EPI_CONVT) {
+        p.dil = -1;  // tap m reads x[q - m]
+        p.pad_l = 0;
+        ncols_max = c.t_in + 1;
+    } else {
+        p.dil = c.dil;
+        p.pad_l = c.pad_l;
+        ncols_max = c.t_out;
+    }
+    const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
+    p.lds_off = span < 0 ? -span : 0;
+    p.xw = bn + (span < 0 ? -span : span);
+    if ((size_t)CK * p.xw * 4 > 64 * 1024) return hipErrorInvalidValue;
+    const int batch = c.batch;
+#define VITS_KT(K)                                                                                  \
+    case K:                                                                                         \
+        if (w.epi == EPI_STD) return launch_tile<K, EPI_STD>(w, tile, p, ncols_max, batch, s);            \
+        break;
+    switch (w.kt) {
+        VITS_KT(1)
+        VITS_KT(3)
+        VITS_KT(7)
+        VITS_KT(11)
+        case 5:
+            if (w.epi == EPI_STD) return launch_tile<5, EPI_STD>(w, tile, p, ncols_max, batch, s);
+            if (w.epi == EPI_GATE) return launch_tile<5, EPI_GATE>(w, tile, p, ncols_max, batch, s);
+            break;
+        case 2:
+            if (w.epi == EPI_CONVT) return launch_tile<2, EPI_CONVT>(w, tile, p, ncols_max, batch, s);
+            break;
+        default: break;
+    }
+#undef VITS_KT
+    return hipErrorInvalidValue;
+}
+
+double conv_flops(const PackedConv& w, const ConvCall&, int64_t total_cols) {
+    // algorithmic MACs: every (row, col) output sums cin*kt products
+    return 2.0 * (double)w.rows * (double)w.cin * (double)w.kt * (double)total_cols;
+}
+
+}  // namespace vits

@@ -1,0 +1,995 @@
+// engine.cpp — host orchestrator (see engine.h). Compiled with hipcc as host C++.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <sstream>
+
+namespace vits {
+
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----
+static std::default_random_engine g_ref_rng;
+static std::mutex g_ref_mu;
+void reference_noise_seed(uint32_t seed) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    g_ref_rng.seed(seed);
+}
+static void reference_noise_fill(float* dst, size_t n) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    std::normal_distribution<float> dist(0.0f, 1.0f);
+    for (size_t i = 0; i < n; ++i) dst[i] = dist(g_ref_rng);
+}
+
+// ---- tokenizer (src/vits_tokenizer.cpp:57-78,182-208; deterministic longest match instead of unordered_map order, Q11) ----
+void Tokenizer::init(const ModelFile& f) {
+    vocab.clear();
+    for (auto& kv : f.vocab) vocab.emplace_back(kv.first, (int32_t)kv.second);
+    std::stable_sort(vocab.begin(), vocab.end(), [](auto& a, auto& b) { return a.first.size() > b.first.size(); });
+    add_blank = f.add_blank != 0;
+    blank_id = 0;
+    for (auto& kv : f.vocab)
+        if (kv.first == f.pad_token) blank_id = (int32_t)kv.second;  // vocab[pad_token], vits_tokenizer.cpp:201
+}
+
+std::vector<int32_t> Tokenizer::tokenize(const std::string& text) const {
+    std::string s = text;
+    for (auto& c : s) c = (char)std::tolower((unsigned char)c);  // :195-197
+    std::vector<int32_t> toks;
+    size_t i = 0;
+    while (i < s.size()) {
+        bool found = false;
+        for (auto& kv : vocab) {
+            if (!kv.first.empty() && s.compare(i, kv.first.size(), kv.first) == 0) {
+                toks.push_back(kv.second);
+                i += kv.first.size();
+                found = true;
+                break;
+            }
+        }
+        if (!found) i++;  // unknown bytes are skipped (:72-75)
+    }
+    std::vector<int32_t> fin;
+    if (add_blank) {  // :200-206 ; without add_blank the reference returns an empty vector
+        fin.assign(toks.size() * 2 + 1, blank_id);
+        for (size_t k = 0; k < toks.size(); ++k) fin[k * 2 + 1] = toks[k];
+    }
+    return fin;
+}
+
+// ---- profiler -----------------------------------------------------------------------------------------
+hipEvent_t Profiler::get() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s) {
+    if (!on) return;
+    auto it = ids.find(name);
+    int id;
+    if (it == ids.end()) {
+        id = (int)names.size();
+        names.push_back(name);
+        ids[name] = id;
+        agg.emplace_back();
+    } else
+        id = it->second;
+    Rec r{id, get(), get(), flop, bytes};
+    hipEventRecord(r.a, s);
+    recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+    if (!on || recs.empty()) return;
+    hipEventRecord(recs.back().b, s);
+}
+void Profiler::collect() {
+    for (auto& r : recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.name_id];
+            a.calls++;
+            a.ms += ms;
+            a.flop += r.flop;
+            a.bytes += r.bytes;
+        }
+        pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    recs.clear();
+}
+void Profiler::reset() {
+    collect();
+    for (auto& a : agg) a = Agg();
+}
+std::string Profiler::report() {
+    collect();
+    std::ostringstream o;
+    o.precision(9);
+    o << "{\"kernels\":[";
+    bool first = true;
+    for (size_t i = 0; i < names.size(); ++i) {
+        if (!agg[i].calls) continue;
+        o << (first ? "" : ",") << "{\"name\":\"" << names[i] << "\",\"calls\":" << agg[i].calls << ",\"ms\":" << agg[i].ms << ",\"flop\":" << agg[i].flop
+          << ",\"bytes\":" << agg[i].bytes << "}";
+        first = false;
+    }
+    o << "]}";
+    return o.str();
+}
+Profiler::~Profiler() {
+    collect();
+    for (auto e : pool) hipEventDestroy(e);
+}
+
+// ---- arena ----------------------------------------------------------------------------------------------
+hipError_t Arena::reserve(size_t bytes) {
+    off = 0;
+    if (bytes <= cap) return hipSuccess;
+    if (base) hipFree(base);
+    base = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    hipError_t e = hipMalloc((void**)&base, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+}
+Arena::~Arena() {
+    if (base) hipFree(base);
+}
+
+// ---- load -------------------------------------------------------------------------------------------------
+Engine::~Engine() {
+    if (stream) hipStreamSynchronize(stream);
+    clear_taps();
+    for (void* p : owned_) hipFree(p);
+    if (stream) hipStreamDestroy(stream);
+}
+
+float* Engine::upload(const std::vector<float>& v) {
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * sizeof(float)) != hipSuccess) return nullptr;
+    hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+    owned_.push_back(d);
+    weight_bytes += (int64_t)v.size() * 4;
+    return d;
+}
+
+float* Engine::upload_tensor(const ModelFile& f, const std::string& name, std::string& err) {
+    const TensorEntry* t = f.find(name);
+    if (!t) {
+        err = "[ERROR] tensor not found: " + name;  // message of the reference, vits_model_data.cpp:144
+        return nullptr;
+    }
+    float* d = upload(t->to_f32());
+    if (!d) err = "hipMalloc failed for " + name;
+    return d;
+}
+
+static bool get_conv(const ModelFile& f, const std::string& wname, std::vector<float>& w, int& cout, int& cin, int& k, std::string& err) {
+    const TensorEntry* t = f.find(wname);
+    if (!t) {
+        err = "[ERROR] tensor not found: " + wname;
+        return false;
+    }
+    w = t->to_f32();
+    if (t->rank == 3) {  // file ne = [k, cin, cout] (reversed torch [cout][cin][k])
+        k = (int)t->ne[0];
+        cin = (int)t->ne[1];
+        cout = (int)t->ne[2];
+    } else if (t->rank == 2) {  // Linear [out][in]
+        k = 1;
+        cin = (int)t->ne[0];
+        cout = (int)t->ne[1];
+    } else {
+        err = "unexpected rank for " + wname;
+        return false;
+    }
+    return true;
+}
+
+// transform: 0 none | 1 reverse input channels | 2 negate | 3 negate + reverse output channels
+bool Engine::pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, int, PackedConv& out, std::string& err, int ct_stride,
+                  int transform) {
+    std::vector<float> w;
+    int d0, d1, k;
+    if (!get_conv(f, wname, w, d0, d1, k, err)) return false;
+    int cout = d0, cin = d1;
+    if (epi == EPI_CONVT) {  // torch ConvTranspose1d weight [cin][cout][k]
+        cin = d0;
+        cout = d1;
+    }
+    std::vector<float> bias;
+    if (!bname.empty()) {
+        const TensorEntry* b = f.find(bname);
+        if (!b) {
+            err = "[ERROR] tensor not found: " + bname;
+            return false;
+        }
+        bias = b->to_f32();
+    }
+    if (transform == 1) {
+        std::vector<float> w2(w.size());
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int j = 0; j < k; ++j) w2[((size_t)co * cin + ci) * k + j] = w[((size_t)co * cin + (cin - 1 - ci)) * k + j];
+        w.swap(w2);
+    } else if (transform == 2 || transform == 3) {
+        std::vector<float> w2(w.size()), b2(bias.size());
+        for (int co = 0; co < cout; ++co) {
+            const int src = transform == 3 ? cout - 1 - co : co;
+            for (int e = 0; e < cin * k; ++e) w2[(size_t)co * cin * k + e] = -w[(size_t)src * cin * k + e];
+            if (!bias.empty()) b2[co] = -bias[src];
+        }
+        w.swap(w2);
+        bias.swap(b2);
+    }
+    out.cin = cin;
+    out.cout = cout;
+    out.epi = epi;
+    out.ct_stride = ct_stride;
+    out.kt = epi == EPI_CONVT ? k / ct_stride : k;
+    std::vector<float> packed = pack_conv_weights(w.data(), cout, cin, k, epi, ct_stride, &out.rows, &out.mtiles_used, &out.mtiles, &out.nchunks);
+    out.wp = upload(packed);
+    out.bias = bias.empty() ? nullptr : upload(bias);
+    out.bytes = (int64_t)packed.size() * 4;
+    if (!out.wp) {
+        err = "hipMalloc failed for " + wname;
+        return false;
+    }
+    return true;
+}
+
+bool Engine::load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err) {
+    for (int i = 0; i < hp.dds_layers; ++i) {
+        const std::string si = std::to_string(i);
+        float* p;
+        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".weight", err))) return false;
+        d.dw_w.push_back(p);
+        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".bias", err))) return false;
+        d.dw_b.push_back(p);
+        PackedConv pc;
+        if (!pack(f, base + "convs_pointwise." + si + ".weight", base + "convs_pointwise." + si + ".bias", EPI_STD, 0, pc, err)) return false;
+        d.pw.push_back(pc);
+        if (!(p = upload_tensor(f, base + "norms_1." + si + ".weight", err))) return false;
+        d.n1_g.push_back(p);
+        if (!(p = upload_tensor(f, base + "norms_1." + si + ".bias", err))) return false;
+        d.n1_b.push_back(p);
+        if (!(p = upload_tensor(f, base + "norms_2." + si + ".weight", err))) return false;
+        d.n2_g.push_back(p);
+        if (!(p = upload_tensor(f, base + "norms_2." + si + ".bias", err))) return false;
+        d.n2_b.push_back(p);
+    }
+    return true;
+}
+
+bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
+    ModelFile f;
+    if (!f.parse(bytes, size, err)) return false;
+    if (!hp.load(f, err)) return false;
+    tok.init(f);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        err = "no HIP device available: this library has no CPU path";
+        return false;
+    }
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+        err = "hipStreamCreate failed";
+        return false;
+    }
+    const int H = hp.hidden;
+    if (!(emb_ = upload_tensor(f, "text_encoder.embed_tokens.weight", err))) return false;
+    {
+        const TensorEntry* e = f.find("text_encoder.embed_tokens.weight");
+        hp.vocab_size = (int)e->ne[1];
+    }
+    enc_.resize(hp.layers);
+    for (int l = 0; l < hp.layers; ++l) {
+        const std::string b = "text_encoder.encoder.layers." + std::to_string(l) + ".";
+        EncoderLayerW& L = enc_[l];
+        // fused Q|K|V projection: one GEMM with 3H output rows (vits.cpp:287-289 are three mul_mat + three adds)
+        {
+            std::vector<float> w((size_t)3 * H * H), bias((size_t)3 * H);
+            const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int i = 0; i < 3; ++i) {
+                const TensorEntry* tw = f.find(b + "attention." + names[i] + ".weight");
+                const TensorEntry* tb = f.find(b + "attention." + names[i] + ".bias");
+                if (!tw || !tb) {
+                    err = "[ERROR] tensor not found: " + b + "attention." + names[i];
+                    return false;
+                }
+                auto wv = tw->to_f32();
+                auto bv = tb->to_f32();
+                std::memcpy(w.data() + (size_t)i * H * H, wv.data(), sizeof(float) * H * H);
+                std::memcpy(bias.data() + (size_t)i * H, bv.data(), sizeof(float) * H);
+            }
+            PackedConv& pc = L.qkv;
+            pc.cin = H;
+            pc.cout = 3 * H;
+            pc.kt = 1;
+            pc.epi = EPI_STD;
+            auto packed = pack_conv_weights(w.data(), 3 * H, H, 1, EPI_STD, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
+            pc.wp = upload(packed);
+            pc.bias = upload(bias);
+            pc.bytes = (int64_t)packed.size() * 4;
+        }
+        if (!pack(f, b + "attention.out_proj.weight", b + "attention.out_proj.bias", EPI_STD, 0, L.out, err)) return false;
+        if (!pack(f, b + "feed_forward.conv_1.weight", b + "feed_forward.conv_1.bias", EPI_STD, 0, L.ffn1, err)) return false;
+        if (!pack(f, b + "feed_forward.conv_2.weight", b + "feed_forward.conv_2.bias", EPI_STD, 0, L.ffn2, err)) return false;
+        if (!(L.rel_k = upload_tensor(f, b + "attention.emb_rel_k", err))) return false;
+        if (!(L.rel_v = upload_tensor(f, b + "attention.emb_rel_v", err))) return false;
+        if (!(L.ln1_g = upload_tensor(f, b + "layer_norm.weight", err))) return false;
+        if (!(L.ln1_b = upload_tensor(f, b + "layer_norm.bias", err))) return false;
+        if (!(L.ln2_g = upload_tensor(f, b + "final_layer_norm.weight", err))) return false;
+        if (!(L.ln2_b = upload_tensor(f, b + "final_layer_norm.bias", err))) return false;
+    }
+    if (!pack(f, "text_encoder.project.weight", "text_encoder.project.bias", EPI_STD, 0, enc_proj_, err)) return false;
+    // duration predictor
+    {
+        const std::string dp = "duration_predictor.";
+        if (!pack(f, dp + "conv_pre.weight", dp + "conv_pre.bias", EPI_STD, 0, dp_pre_, err)) return false;
+        if (!pack(f, dp + "conv_proj.weight", dp + "conv_proj.bias", EPI_STD, 0, dp_proj_, err)) return false;
+        if (!load_dds(f, dp + "conv_dds.", dp_dds_, err)) return false;
+        if (!(dp_translate_ = upload_tensor(f, dp + "flows.0.translate", err))) return false;
+        if (!(dp_logscale_ = upload_tensor(f, dp + "flows.0.log_scale", err))) return false;
+        dp_flows_.resize(hp.dp_flows);
+        for (int fl = 1; fl <= hp.dp_flows; ++fl) {
+            if (fl == 1) continue;  // never evaluated (vits.cpp:954; HF "remove a useless vflow")
+            const std::string b = dp + "flows." + std::to_string(fl) + ".";
+            DpFlowW& W = dp_flows_[fl - 1];
+            if (!(W.pre_w = upload_tensor(f, b + "conv_pre.weight", err))) return false;
+            if (!(W.pre_b = upload_tensor(f, b + "conv_pre.bias", err))) return false;
+            if (!load_dds(f, b + "conv_dds.", W.dds, err)) return false;
+            if (!pack(f, b + "conv_proj.weight", b + "conv_proj.bias", EPI_STD, 0, W.proj, err)) return false;
+        }
+    }
+    // coupling flow: channel flips (vits.cpp:532) are folded into the weights. Layer i (processed i = n-1 .. 0) sees
+    // (n - i) flips; with an odd count the logical first half lives in physical channels [F/2, F) reversed.
+    flow_.resize(hp.n_flows);
+    for (int i = 0; i < hp.n_flows; ++i) {
+        const std::string b = "flow.flows." + std::to_string(i) + ".";
+        const bool flipped = ((hp.n_flows - i) % 2) == 1;
+        FlowLayerW& L = flow_[i];
+        if (!pack(f, b + "conv_pre.weight", b + "conv_pre.bias", EPI_STD, 0, L.pre, err, 0, flipped ? 1 : 0)) return false;
+        if (!pack(f, b + "conv_post.weight", b + "conv_post.bias", EPI_STD, 0, L.post, err, 0, flipped ? 3 : 2)) return false;  // x1 -= mean
+        L.in_layers.resize(hp.wn_layers);
+        L.res_skip.resize(hp.wn_layers);
+        for (int l = 0; l < hp.wn_layers; ++l) {
+            const std::string sl = std::to_string(l);
+            if (!pack(f, b + "wavenet.in_layers." + sl + ".weight", b + "wavenet.in_layers." + sl + ".bias", EPI_GATE, 0, L.in_layers[l], err)) return false;
+            if (!pack(f, b + "wavenet.res_skip_layers." + sl + ".weight", b + "wavenet.res_skip_layers." + sl + ".bias", EPI_STD, 0, L.res_skip[l], err))
+                return false;
+        }
+    }
+    // HiFiGAN
+    if (!pack(f, "decoder.conv_pre.weight", "decoder.conv_pre.bias", EPI_STD, 0, dec_pre_, err)) return false;
+    ups_.resize(hp.up_rates.size());
+    {
+        int c = hp.up_init;
+        for (size_t i = 0; i < hp.up_rates.size(); ++i) {
+            UpStageW& U = ups_[i];
+            U.stride = hp.up_rates[i];
+            U.k = hp.up_k[i];
+            c /= 2;
+            U.channels = c;
+            const std::string si = std::to_string(i);
+            if (!pack(f, "decoder.upsampler." + si + ".weight", "decoder.upsampler." + si + ".bias", EPI_CONVT, 0, U.up, err, U.stride)) return false;
+            if (U.up.cout != c) {
+                err = "upsampler channel mismatch";
+                return false;
+            }
+            U.rbs.resize(hp.rb_k.size());
+            for (size_t j = 0; j < hp.rb_k.size(); ++j) {
+                ResBlockW& R = U.rbs[j];
+                R.k = hp.rb_k[j];
+                R.dil = hp.rb_d[j];
+                const std::string rb = "decoder.resblocks." + std::to_string(i * hp.rb_k.size() + j) + ".";
+                R.c1.resize(R.dil.size());
+                R.c2.resize(R.dil.size());
+                for (size_t d = 0; d < R.dil.size(); ++d) {
+                    const std::string sd = std::to_string(d);
+                    if (!pack(f, rb + "convs1." + sd + ".weight", rb + "convs1." + sd + ".bias", EPI_STD, 0, R.c1[d], err)) return false;
+                    if (!pack(f, rb + "convs2." + sd + ".weight", rb + "convs2." + sd + ".bias", EPI_STD, 0, R.c2[d], err)) return false;
+                }
+            }
+        }
+        const TensorEntry* pw = f.find("decoder.conv_post.weight");
+        if (!pw) {
+            err = "[ERROR] tensor not found: decoder.conv_post.weight";
+            return false;
+        }
+        dec_post_k_ = (int)pw->ne[0];
+        dec_post_cin_ = (int)pw->ne[1];
+        if (!(dec_post_w_ = upload_tensor(f, "decoder.conv_post.weight", err))) return false;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        err = "device error while uploading weights";
+        return false;
+    }
+    return true;
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------
+hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c) {
+    if (prof.on) {
+        const int64_t cols = (int64_t)c.batch * (w.epi == EPI_CONVT ? c.t_in : c.t_out);
+        prof.begin(name, conv_flops(w, c, cols), 0.0, stream);
+    }
+    hipError_t e = launch_conv(w, c, stream);
+    prof.end(stream);
+    return e;
+}
+
+#define KPROF(name, call)              \
+    do {                               \
+        prof.begin(name, 0, 0, stream); \
+        hipError_t e__ = (call);       \
+        prof.end(stream);              \
+        if (e__ != hipSuccess) return e__; \
+    } while (0)
+
+// DDS block (vits.cpp:646-692): x is updated in place; y, p are scratch [B][H][ts]
+hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax) {
+    const int H = hp.hidden;
+    TensorRef none;
+    int dil = 1;
+    for (int i = 0; i < hp.dds_layers; ++i) {
+        KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream));
+        ConvCall c;
+        c.x = y;
+        c.y = p;
+        c.len_in = lens;
+        c.len_out = lens;
+        c.batch = batch;
+        c.t_in = c.t_out = tmax;
+        hipError_t e = conv("conv1x1_dp", d.pw[i], c);
+        if (e != hipSuccess) return e;
+        KPROF("ln_gelu_residual", launch_add_layer_norm(p, none, d.n2_g[i], d.n2_b[i], none, lens, batch, H, tmax, 1e-5f, 1, x, stream));
+        dil *= hp.dp_k;
+    }
+    return hipSuccess;
+}
+
+void Engine::clear_taps() {
+    for (auto& kv : taps_)
+        if (kv.second.dev) hipFree(kv.second.dev);
+    taps_.clear();
+}
+
+void Engine::snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens) {
+    Tap tp;
+    tp.channels = channels;
+    tp.stride = stride;
+    tp.lens = lens;
+    const size_t n = (size_t)batch * channels * stride;
+    if (hipMalloc((void**)&tp.dev, n * sizeof(float)) != hipSuccess) return;
+    // gather [b][c][0:stride] rows out of the (possibly wider) source tensor
+    hipMemcpy2DAsync(tp.dev, (size_t)stride * 4, t.p, (size_t)t.cs * 4, (size_t)stride * 4, (size_t)channels, hipMemcpyDeviceToDevice, stream);
+    for (int b = 1; b < batch; ++b)
+        hipMemcpy2DAsync(tp.dev + (size_t)b * channels * stride, (size_t)stride * 4, t.p + (size_t)b * t.bs, (size_t)t.cs * 4, (size_t)stride * 4, (size_t)channels,
+                         hipMemcpyDeviceToDevice, stream);
+    taps_[name] = tp;
+}
+
+int64_t Engine::get_tap(const char* name, int utt, float* dst, size_t cap) {
+    auto it = taps_.find(name);
+    if (it == taps_.end() || utt < 0 || utt >= tap_batch_) return 0;
+    const Tap& tp = it->second;
+    const int len = tp.lens[utt];
+    const int64_t n = (int64_t)tp.channels * len;
+    if (dst && cap) {
+        hipStreamSynchronize(stream);
+        std::vector<float> host((size_t)tp.channels * tp.stride);
+        hipMemcpy(host.data(), tp.dev + (size_t)utt * tp.channels * tp.stride, host.size() * 4, hipMemcpyDeviceToHost);
+        size_t w = 0;
+        for (int c = 0; c < tp.channels && w < cap; ++c)
+            for (int t = 0; t < len && w < cap; ++t) dst[w++] = host[(size_t)c * tp.stride + t];
+    }
+    return n;
+}
+
+int Engine::sync(std::string& err) {
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int id_stride, const vits_process_opts& o, vits_batch_result* out,
+                          std::string& err) {
+    if (B <= 0 || id_stride <= 0) {
+        err = "empty batch";
+        return -1;
+    }
+    const int md = o.mode == VITS_MODE_DEFAULT ? mode : o.mode;
+    const bool refmode = md == VITS_MODE_REFERENCE;
+    const int H = hp.hidden, F = hp.flow_size, heads = hp.heads, hd = H / heads;
+    std::vector<int> tlen(B);
+    int Tmax = 0;
+    for (int b = 0; b < B; ++b) {
+        tlen[b] = id_lens ? id_lens[b] : id_stride;
+        if (tlen[b] <= 0 || tlen[b] > id_stride) {
+            err = "bad id length";
+            return -1;
+        }
+        Tmax = std::max(Tmax, tlen[b]);
+        for (int t = 0; t < tlen[b]; ++t) {
+            const int id = ids[(size_t)b * id_stride + t];
+            if (id < 0 || id >= hp.vocab_size) {
+                err = "token id out of range";
+                return -1;
+            }
+        }
+    }
+    if (Tmax > 2048) {
+        err = "more than 2048 ids per utterance is not supported";
+        return -1;
+    }
+    const bool want_async = o.async && o.skip_host_copy && o.fixed_duration > 0 && !o.collect_taps;
+    const int ts = round_up(Tmax, 32);
+    const int n_up = (int)ups_.size();
+    clear_taps();
+    tap_batch_ = B;
+
+    // ---- stage one buffers ------------------------------------------------------------------------------
+    struct S1 {
+        int *ids, *lens, *cum, *frames, *stage_lens, *stage_mul, *stage_add;
+        float *x, *qkv, *att, *tmp, *ffn, *stats, *dpx, *dpy, *dpp, *cond, *z, *u, *dur;
+    } s1;
+    auto layout1 = [&](Arena& a) {
+        s1.ids = a.alloc<int>((size_t)B * id_stride);
+        s1.lens = a.alloc<int>(B);
+        s1.cum = a.alloc<int>((size_t)B * id_stride);
+        s1.frames = a.alloc<int>(B);
+        s1.stage_lens = a.alloc<int>((size_t)(n_up + 1) * B);
+        s1.stage_mul = a.alloc<int>(n_up + 1);
+        s1.stage_add = a.alloc<int>(n_up + 1);
+        s1.dur = a.alloc<float>((size_t)B * id_stride);
+        s1.x = a.alloc<float>((size_t)B * H * ts);
+        s1.qkv = a.alloc<float>((size_t)B * 3 * H * ts);
+        s1.att = a.alloc<float>((size_t)B * H * ts);
+        s1.tmp = a.alloc<float>((size_t)B * H * ts);
+        s1.ffn = a.alloc<float>((size_t)B * hp.ffn_dim * ts);
+        s1.stats = a.alloc<float>((size_t)B * 2 * F * ts);
+        s1.dpx = a.alloc<float>((size_t)B * H * ts);
+        s1.dpy = a.alloc<float>((size_t)B * H * ts);
+        s1.dpp = a.alloc<float>((size_t)B * H * ts);
+        s1.cond = a.alloc<float>((size_t)B * H * ts);
+        s1.z = a.alloc<float>((size_t)B * 2 * ts);
+        s1.u = a.alloc<float>((size_t)B * 32 * ts);
+    };
+    {
+        Arena measure;
+        measure.cap = (size_t)1 << 60;
+        layout1(measure);
+        const size_t need = measure.off + 4096;
+        measure.cap = 0;
+        if (need > a1_.cap) HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(a1_.reserve(need));
+        layout1(a1_);
+    }
+    auto TR = [](float* p, int channels, int stride) {
+        TensorRef t;
+        t.p = p;
+        t.cs = stride;
+        t.bs = (int64_t)channels * stride;
+        return t;
+    };
+    TensorRef none;
+    HIP_OK(hipMemcpyAsync(s1.ids, ids, sizeof(int) * (size_t)B * id_stride, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(s1.lens, tlen.data(), sizeof(int) * B, hipMemcpyHostToDevice, stream));
+    // vocoder stage lengths as affine functions of the frame count L: len_i = L*mul_i + add_i (Q1: the reference
+    // never crops the transposed conv, so every stage gains K - s samples; vits.cpp:187)
+    std::vector<int> smul(n_up + 1), sadd(n_up + 1);
+    smul[0] = 1;
+    sadd[0] = 0;
+    for (int i = 0; i < n_up; ++i) {
+        const int s = ups_[i].stride, K = ups_[i].k;
+        const int crop = refmode ? 0 : (K - s) / 2;
+        smul[i + 1] = smul[i] * s;
+        sadd[i + 1] = sadd[i] * s + (K - s - 2 * crop);
+    }
+    HIP_OK(hipMemcpyAsync(s1.stage_mul, smul.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(s1.stage_add, sadd.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
+
+    const int* dl = s1.lens;
+    TensorRef x = TR(s1.x, H, ts), qkv = TR(s1.qkv, 3 * H, ts), att = TR(s1.att, H, ts), tmp = TR(s1.tmp, H, ts), ffn = TR(s1.ffn, hp.ffn_dim, ts);
+    auto sub = [](TensorRef t, int c0) {
+        t.p += (int64_t)c0 * t.cs;
+        return t;
+    };
+    auto mk = [&](TensorRef xin, TensorRef yout, int tmax_) {
+        ConvCall c;
+        c.x = xin;
+        c.y = yout;
+        c.len_in = dl;
+        c.len_out = dl;
+        c.batch = B;
+        c.t_in = c.t_out = tmax_;
+        return c;
+    };
+
+    // ---- text encoder (vits.cpp:244-440) ---------------------------------------------------------------------
+    prof.begin("embed", 0, 0, stream);
+    HIP_OK(launch_embed(s1.ids, id_stride, dl, emb_, H, (float)std::sqrt((double)H), x, B, Tmax, stream));
+    prof.end(stream);
+    const float q_scale = (float)std::pow((double)hd, -0.5);
+    for (int l = 0; l < hp.layers; ++l) {
+        const EncoderLayerW& L = enc_[l];
+        HIP_OK(conv("enc_qkv_gemm", L.qkv, mk(x, qkv, Tmax)));
+        prof.begin("rel_attention", 0, 0, stream);
+        HIP_OK(launch_rel_attention(sub(qkv, 0), sub(qkv, H), sub(qkv, 2 * H), L.rel_k, L.rel_v, att, dl, B, heads, hd, Tmax, hp.window, q_scale, stream));
+        prof.end(stream);
+        {
+            ConvCall c = mk(att, tmp, Tmax);
+            c.res = x;  // residual + attention output (vits.cpp:367)
+            HIP_OK(conv("enc_out_gemm", L.out, c));
+        }
+        prof.begin("layer_norm", 0, 0, stream);
+        HIP_OK(launch_add_layer_norm(tmp, none, L.ln1_g, L.ln1_b, x, dl, B, H, Tmax, hp.ln_eps, 0, none, stream));
+        prof.end(stream);
+        {
+            ConvCall c = mk(x, ffn, Tmax);
+            c.pad_l = (hp.ffn_k - 1) / 2;  // vits.cpp:388
+            c.post_act = 1;                // relu :397
+            HIP_OK(conv("enc_ffn_conv", L.ffn1, c));
+        }
+        {
+            ConvCall c = mk(ffn, tmp, Tmax);
+            c.pad_l = (hp.ffn_k - 1) / 2;
+            c.res = x;  // :416
+            HIP_OK(conv("enc_ffn_conv", L.ffn2, c));
+        }
+        prof.begin("layer_norm", 0, 0, stream);
+        HIP_OK(launch_add_layer_norm(tmp, none, L.ln2_g, L.ln2_b, x, dl, B, H, Tmax, hp.ln_eps, 0, none, stream));
+        prof.end(stream);
+    }
+    TensorRef stats = TR(s1.stats, 2 * F, ts);
+    HIP_OK(conv("enc_project", enc_proj_, mk(x, stats, Tmax)));  // :429 ; split :436 = channel ranges [0,F) and [F,2F)
+    if (o.collect_taps) {
+        snapshot("enc_out", x, H, Tmax, B, tlen);
+        snapshot("prior_mean", sub(stats, 0), F, Tmax, B, tlen);
+        snapshot("prior_logvar", sub(stats, F), F, Tmax, B, tlen);
+    }
+
+    // ---- stochastic duration predictor, reverse (vits.cpp:927-972) ----------------------------------------
+    TensorRef dpx = TR(s1.dpx, H, ts), dpy = TR(s1.dpy, H, ts), dpp = TR(s1.dpp, H, ts), cond = TR(s1.cond, H, ts), z = TR(s1.z, 2, ts), u = TR(s1.u, 32, ts);
+    HIP_OK(conv("conv1x1_dp", dp_pre_, mk(x, dpx, Tmax)));
+    HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax));
+    HIP_OK(conv("conv1x1_dp", dp_proj_, mk(dpx, cond, Tmax)));
+    std::vector<float> host_noise;
+    if (o.noise_kind == VITS_NOISE_COUNTER) {
+        prof.begin("noise_dur", 0, 0, stream);
+        HIP_OK(launch_noise_dur(z, dl, B, Tmax, o.noise_seed, hp.noise_scale_dur, stream));
+        prof.end(stream);
+    } else {
+        host_noise.assign((size_t)B * 2 * ts, 0.f);
+        for (int b = 0; b < B; ++b) {
+            if (o.noise_kind == VITS_NOISE_EXPLICIT) {
+                if (!o.noise_dur) {
+                    err = "noise_dur missing";
+                    return -1;
+                }
+                for (int c = 0; c < 2; ++c) std::memcpy(&host_noise[((size_t)b * 2 + c) * ts], o.noise_dur + ((size_t)b * 2 + c) * id_stride, sizeof(float) * tlen[b]);
+            } else {
+                std::vector<float> tmpn((size_t)2 * tlen[b]);  // tensor_randn{T,2,1}: memory order [2][T] (vits.cpp:948)
+                reference_noise_fill(tmpn.data(), tmpn.size());
+                for (int c = 0; c < 2; ++c) std::memcpy(&host_noise[((size_t)b * 2 + c) * ts], &tmpn[(size_t)c * tlen[b]], sizeof(float) * tlen[b]);
+            }
+        }
+        HIP_OK(hipMemcpyAsync(s1.z, host_noise.data(), sizeof(float) * host_noise.size(), hipMemcpyHostToDevice, stream));
+        if (o.collect_taps) snapshot("noise_dur", z, 2, Tmax, B, tlen);
+        HIP_OK(launch_scale_rows(z, 2, hp.noise_scale_dur, B, Tmax, stream));
+    }
+    int c_first = 0;  // physical row holding logical latent channel 0
+    const float inv_sqrt = (float)(1.0 / std::sqrt((double)H));
+    for (int fl = hp.dp_flows; fl > -1; --fl) {
+        if (fl == 1) continue;
+        c_first ^= 1;  // flip (vits.cpp:956) is an index swap
+        if (fl == 0) {
+            prof.begin("dp_affine", 0, 0, stream);
+            HIP_OK(launch_affine(z, c_first, dp_translate_, dp_logscale_, refmode ? +1 : -1, dl, B, Tmax, stream));  // Q5
+            prof.end(stream);
+        } else {
+            const DpFlowW& W = dp_flows_[fl - 1];
+            // conv_pre (1 -> H, vits.cpp:864) fused with "inputs + global_conditioning" of the DDS block (:651-653)
+            prof.begin("dp_flow_pre", 0, 0, stream);
+            HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream));
+            prof.end(stream);
+            HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax));
+            HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
+            prof.begin("dp_spline", 0, 0, stream);
+            HIP_OK(launch_spline(u, z, 1 - c_first, dl, B, Tmax, hp.dp_bins, hp.dp_tail, inv_sqrt, md, stream));
+            prof.end(stream);
+        }
+    }
+    if (o.collect_taps) snapshot("log_duration", sub(z, c_first), 1, Tmax, B, tlen);
+    prof.begin("durations", 0, 0, stream);
+    HIP_OK(launch_durations(z, c_first, dl, B, id_stride, (float)(1.0 / hp.speaking_rate), o.fixed_duration, s1.dur, s1.cum, s1.frames, s1.stage_lens, n_up + 1,
+                            s1.stage_mul, s1.stage_add, stream));
+    prof.end(stream);
+
+    // ---- the one data-dependent shape (vits.cpp:1133): frames per utterance ---------------------------------
+    std::vector<int> frames(B);
+    if (o.fixed_duration > 0) {
+        for (int b = 0; b < B; ++b) frames[b] = std::max(1, o.fixed_duration * tlen[b]);
+    } else {
+        HIP_OK(hipMemcpyAsync(frames.data(), s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+    int Lmax = 0;
+    for (int b = 0; b < B; ++b) Lmax = std::max(Lmax, frames[b]);
+    std::vector<std::vector<int>> slen(n_up + 1, std::vector<int>(B));
+    std::vector<int> smax(n_up + 1, 0);
+    for (int i = 0; i <= n_up; ++i)
+        for (int b = 0; b < B; ++b) {
+            slen[i][b] = frames[b] * smul[i] + sadd[i];
+            smax[i] = std::max(smax[i], slen[i][b]);
+        }
+    if (o.collect_taps) {
+        TensorRef d;
+        d.p = s1.dur;
+        d.cs = id_stride;
+        d.bs = id_stride;
+        snapshot("durations", d, 1, Tmax, B, tlen);
+    }
+
+    // ---- stage two buffers -------------------------------------------------------------------------------------
+    const int ls = round_up(Lmax, 32);
+    size_t big = 0;  // floats of the largest vocoder activation
+    std::vector<int> sts(n_up + 1);
+    for (int i = 0; i <= n_up; ++i) sts[i] = round_up(smax[i], 32);
+    for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
+    struct S2 {
+        float *zp, *noise, *hout, *gate, *h0, *bu, *by, *bt, *bs, *pre, *wave;
+    } s2;
+    const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
+    const int S_stride = sts[n_up];
+    auto layout2 = [&](Arena& a) {
+        s2.zp = a.alloc<float>((size_t)B * F * ls);
+        s2.noise = need_noise_buf ? a.alloc<float>((size_t)B * F * ls) : nullptr;
+        s2.hout = a.alloc<float>((size_t)B * 2 * H * ls);
+        s2.gate = a.alloc<float>((size_t)B * H * ls);
+        s2.h0 = a.alloc<float>((size_t)B * hp.up_init * ls);
+        s2.bu = a.alloc<float>(big);
+        s2.by = a.alloc<float>(big);
+        s2.bt = a.alloc<float>(big);
+        s2.bs = a.alloc<float>(big);
+        s2.pre = o.collect_taps ? a.alloc<float>((size_t)B * S_stride) : nullptr;
+        s2.wave = a.alloc<float>((size_t)B * S_stride);
+    };
+    {
+        Arena measure;
+        measure.cap = (size_t)1 << 60;
+        layout2(measure);
+        const size_t need = measure.off + 4096;
+        measure.cap = 0;
+        if (need > a2_.cap) HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(a2_.reserve(need));
+        layout2(a2_);
+    }
+    const int* d_len[8];
+    for (int i = 0; i <= n_up && i < 8; ++i) d_len[i] = s1.stage_lens + (size_t)i * B;
+
+    // ---- prior sampling through the alignment (vits.cpp:1028-1064) -------------------------------------------
+    TensorRef zp = TR(s2.zp, F, ls), noise = TR(s2.noise, F, ls);
+    if (need_noise_buf) {
+        std::vector<float> hn((size_t)B * F * ls, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const int L = frames[b];
+            if (o.noise_kind == VITS_NOISE_EXPLICIT) {
+                if (!o.noise_prior) {
+                    err = "noise_prior missing";
+                    return -1;
+                }
+                for (int c = 0; c < F; ++c)
+                    std::memcpy(&hn[((size_t)b * F + c) * ls], o.noise_prior + ((size_t)b * F + c) * o.noise_prior_stride, sizeof(float) * std::min<int64_t>(L, o.noise_prior_stride));
+            } else {
+                std::vector<float> tmpn((size_t)F * L);  // tensor_randn_like(prior_means ne=[L,F]) (vits.cpp:1059)
+                reference_noise_fill(tmpn.data(), tmpn.size());
+                for (int c = 0; c < F; ++c) std::memcpy(&hn[((size_t)b * F + c) * ls], &tmpn[(size_t)c * L], sizeof(float) * L);
+            }
+        }
+        HIP_OK(hipMemcpyAsync(s2.noise, hn.data(), sizeof(float) * hn.size(), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // hn goes out of scope
+        if (o.collect_taps) snapshot("noise_prior", noise, F, Lmax, B, frames);
+    }
+    prof.begin("prior_sample_gather", 0, 0, stream);
+    HIP_OK(launch_zp(sub(stats, 0), sub(stats, F), s1.cum, id_stride, dl, s1.frames, noise, o.noise_kind == VITS_NOISE_COUNTER ? VITS_NOISE_COUNTER : VITS_NOISE_EXPLICIT,
+                     o.noise_seed, hp.noise_scale, zp, B, F, Lmax, stream));
+    prof.end(stream);
+    if (o.collect_taps) snapshot("z_p", zp, F, Lmax, B, frames);
+
+    // ---- residual coupling flow, reverse (vits.cpp:519-538,500-517,452-498) ------------------------------------
+    {
+        const int* ll = d_len[0];
+        TensorRef hout = TR(s2.hout, 2 * H, ls), gate = TR(s2.gate, H, ls);
+        TensorRef hh = hout;  // channels [0,H) = h, [H,2H) = skip accumulator "outputs" (vits.cpp:460)
+        auto mk2 = [&](TensorRef xin, TensorRef yout) {
+            ConvCall c;
+            c.x = xin;
+            c.y = yout;
+            c.len_in = ll;
+            c.len_out = ll;
+            c.batch = B;
+            c.t_in = c.t_out = Lmax;
+            return c;
+        };
+        for (int i = hp.n_flows - 1; i > -1; --i) {
+            const FlowLayerW& Lw = flow_[i];
+            const bool flipped = ((hp.n_flows - i) % 2) == 1;
+            TensorRef x0 = sub(zp, flipped ? F / 2 : 0), x1 = sub(zp, flipped ? 0 : F / 2);
+            HIP_OK(conv("flow_conv1x1", Lw.pre, mk2(x0, hh)));  // h -> hout[0,H)
+            prof.begin("fill_zero", 0, 0, stream);
+            HIP_OK(launch_fill_rows(sub(hout, H), H, 0.f, B, Lmax, stream));
+            prof.end(stream);
+            int dil = 1;
+            for (int l = 0; l < hp.wn_layers; ++l) {
+                ConvCall c = mk2(hh, gate);
+                c.dil = dil;
+                c.pad_l = (hp.wn_k * dil - dil) / 2;  // vits.cpp:470
+                HIP_OK(conv("flow_wavenet_gated_conv", Lw.in_layers[l], c));
+                if (l < hp.wn_layers - 1) {
+                    ConvCall r = mk2(gate, hout);  // rows [0,H): h += res ; rows [H,2H): outputs += skip (vits.cpp:484-489)
+                    r.res = hout;
+                    HIP_OK(conv("flow_conv1x1", Lw.res_skip[l], r));
+                } else {
+                    ConvCall r = mk2(gate, sub(hout, H));  // outputs += res_skip (vits.cpp:491)
+                    r.res = sub(hout, H);
+                    HIP_OK(conv("flow_conv1x1", Lw.res_skip[l], r));
+                }
+                dil *= hp.wn_rate;
+            }
+            ConvCall pc = mk2(sub(hout, H), x1);  // x1 <- x1 - (W out + b): weights negated at load (vits.cpp:506,513)
+            pc.res = x1;
+            HIP_OK(conv("flow_conv1x1", Lw.post, pc));
+        }
+        if (o.collect_taps) snapshot("z_flow", zp, F, Lmax, B, frames);
+    }
+
+    // ---- HiFiGAN (vits.cpp:583-644) -----------------------------------------------------------------------------
+    float* wave_dst = s2.wave;
+    int64_t wave_stride = S_stride;
+    if (o.out_device) {
+        if (o.out_device_stride < smax[n_up]) {
+            err = "out_device_stride is smaller than the longest utterance";
+            return -1;
+        }
+        wave_dst = (float*)o.out_device;
+        wave_stride = o.out_device_stride;
+    }
+    {
+        TensorRef h0 = TR(s2.h0, hp.up_init, ls);
+        {
+            ConvCall c;
+            c.x = zp;
+            c.y = h0;
+            c.len_in = d_len[0];
+            c.len_out = d_len[0];
+            c.batch = B;
+            c.t_in = c.t_out = Lmax;
+            c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
+            HIP_OK(conv("hifigan_conv_pre", dec_pre_, c));
+        }
+        TensorRef cur = h0;
+        const size_t nk = hp.rb_k.size();
+        for (int i = 0; i < n_up; ++i) {
+            const UpStageW& U = ups_[i];
+            const int C = U.channels, st_in = i, st_out = i + 1;
+            TensorRef bu = TR(s2.bu, C, sts[st_out]), by = TR(s2.by, C, sts[st_out]), bt = TR(s2.bt, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
+            {
+                ConvCall c;
+                c.x = cur;
+                c.y = bu;
+                c.len_in = d_len[st_in];
+                c.len_out = d_len[st_out];
+                c.batch = B;
+                c.t_in = smax[st_in];
+                c.t_out = smax[st_out];
+                c.pre_act = 1;  // leaky_relu before the upsampler (vits.cpp:613)
+                c.slope = hp.lrelu;
+                c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
+                HIP_OK(conv("hifigan_upsample_convT", U.up, c));
+            }
+            for (size_t j = 0; j < nk; ++j) {
+                const ResBlockW& R = U.rbs[j];
+                const size_t nd = R.dil.size();
+                for (size_t d = 0; d < nd; ++d) {
+                    TensorRef resid = d == 0 ? bu : by;
+                    ConvCall c1;
+                    c1.x = resid;
+                    c1.y = bt;
+                    c1.len_in = c1.len_out = d_len[st_out];
+                    c1.batch = B;
+                    c1.t_in = c1.t_out = smax[st_out];
+                    c1.dil = R.dil[d];
+                    c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
+                    c1.pre_act = 1;
+                    c1.slope = hp.lrelu;
+                    HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1));
+                    ConvCall c2 = c1;
+                    c2.x = bt;
+                    c2.dil = 1;
+                    c2.pad_l = (R.k - 1) / 2;
+                    c2.res = resid;  // residual add (vits.cpp:578)
+                    if (d + 1 < nd) c2.y = by;
+                    else {
+                        // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)
+                        c2.y = bsum;
+                        if (j > 0) c2.acc = bsum;
+                        if (j + 1 == nk) {
+                            if (refmode) {
+                                c2.scale = (float)(1.0 / (double)nk);  // ggml_scale by float(1/num_kernels) (vits.cpp:607)
+                                c2.scale_div = 0;
+                            } else {
+                                c2.scale = (float)nk;  // HF divides (modeling_vits.py:546)
+                                c2.scale_div = 1;
+                            }
+                        } else {
+                            c2.scale = 1.f;
+                        }
+                        if (j == 0 && nk == 1) {
+                            // single-kernel vocoder: nothing to accumulate, scale is 1
+                        }
+                    }
+                    HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2));
+                }
+            }
+            cur = bsum;
+        }
+        TensorRef pre;
+        pre.p = s2.pre;
+        pre.bs = S_stride;
+        pre.cs = S_stride;
+        TensorRef wv;
+        wv.p = wave_dst;
+        wv.bs = wave_stride;
+        wv.cs = (int)wave_stride;
+        prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)B * smax[n_up], 0, stream);
+        HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, refmode ? hp.lrelu : 0.01f, pre, wv, d_len[n_up], B, smax[n_up], stream));  // Q2
+        prof.end(stream);
+        if (o.collect_taps) {
+            snapshot("pre_tanh", pre, 1, smax[n_up], B, slen[n_up]);
+            snapshot("waveform", wv, 1, smax[n_up], B, slen[n_up]);
+        }
+    }
+
+    // ---- results ------------------------------------------------------------------------------------------------
+    if (out) {
+        out->batch = (size_t)B;
+        out->stride = (size_t)smax[n_up];
+        out->lengths = new int64_t[B];
+        out->frames = new int64_t[B];
+        for (int b = 0; b < B; ++b) {
+            out->lengths[b] = slen[n_up][b];
+            out->frames[b] = frames[b];
+        }
+        out->data = nullptr;
+        if (!o.skip_host_copy) {
+            out->data = new float[(size_t)B * out->stride];
+            HIP_OK(hipMemcpy2DAsync(out->data, out->stride * 4, wave_dst, (size_t)wave_stride * 4, out->stride * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    if (!want_async) {
+        HIP_OK(hipStreamSynchronize(stream));
+        if (prof.on) prof.collect();
+    }
+    return 0;
+}
+
+}  // namespace vits

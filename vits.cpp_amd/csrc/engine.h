@@ -1,0 +1,152 @@
+// engine.h — host orchestrator: owns the device-resident (pre-packed) weights, the activation arenas, the HIP
+// stream, and issues the kernel sequence that replaces the reference's two ggml graphs
+// (/root/reference/src/vits.cpp:975-1080 build_graph_part_one/two, :1082-1099 execute_graph, :1101-1191 process).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vits.h"
+#include "kernels.h"
+#include "model_file.h"
+
+namespace vits {
+
+struct Tokenizer {
+    std::vector<std::pair<std::string, int32_t>> vocab;  // sorted by descending key length
+    int32_t blank_id = 0;
+    bool add_blank = true;
+    void init(const ModelFile& f);
+    std::vector<int32_t> tokenize(const std::string& text) const;
+};
+
+struct Profiler {
+    struct Rec {
+        int name_id;
+        hipEvent_t a, b;
+        double flop, bytes;
+    };
+    bool on = false;
+    std::vector<std::string> names;
+    std::unordered_map<std::string, int> ids;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    struct Agg {
+        long calls = 0;
+        double ms = 0, flop = 0, bytes = 0;
+    };
+    std::vector<Agg> agg;
+    hipEvent_t get();
+    void begin(const char* name, double flop, double bytes, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();  // after a stream sync
+    void reset();
+    std::string report();
+    ~Profiler();
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    hipError_t reserve(size_t bytes);  // grow-only; invalidates previous contents
+    void reset() { off = 0; }
+    template <class T>
+    T* alloc(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return off <= cap ? p : nullptr;
+    }
+    ~Arena();
+};
+
+struct Tap {
+    float* dev = nullptr;  // snapshot [batch][channels][stride]
+    int channels = 0, stride = 0;
+    std::vector<int> lens;  // per utterance
+};
+
+struct EncoderLayerW {
+    PackedConv qkv, out, ffn1, ffn2;
+    float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+struct DdsW {
+    std::vector<float*> dw_w, dw_b, n1_g, n1_b, n2_g, n2_b;
+    std::vector<PackedConv> pw;
+};
+struct DpFlowW {
+    float *pre_w, *pre_b;
+    DdsW dds;
+    PackedConv proj;
+};
+struct FlowLayerW {
+    PackedConv pre, post;
+    std::vector<PackedConv> in_layers, res_skip;
+};
+struct ResBlockW {
+    std::vector<PackedConv> c1, c2;
+    std::vector<int> dil;
+    int k;
+};
+struct UpStageW {
+    PackedConv up;
+    std::vector<ResBlockW> rbs;
+    int channels, stride, k;
+};
+
+class Engine {
+  public:
+    ~Engine();
+    bool load(const uint8_t* bytes, size_t size, std::string& err);
+    int process_batch(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out,
+                      std::string& err);
+    int sync(std::string& err);
+    int64_t get_tap(const char* name, int utt, float* dst, size_t cap);
+
+    HParams hp;
+    Tokenizer tok;
+    int mode = VITS_MODE_REFERENCE;
+    int64_t weight_bytes = 0;
+    Profiler prof;
+    hipStream_t stream = nullptr;
+
+  private:
+    // weights
+    float* emb_ = nullptr;
+    std::vector<EncoderLayerW> enc_;
+    PackedConv enc_proj_;
+    PackedConv dp_pre_, dp_proj_;
+    DdsW dp_dds_;
+    float *dp_translate_ = nullptr, *dp_logscale_ = nullptr;
+    std::vector<DpFlowW> dp_flows_;  // index f-1 for flows.f, f = 1..dp_flows
+    std::vector<FlowLayerW> flow_;
+    PackedConv dec_pre_;
+    std::vector<UpStageW> ups_;
+    float* dec_post_w_ = nullptr;
+    int dec_post_cin_ = 0, dec_post_k_ = 0;
+    std::vector<void*> owned_;  // every device allocation made at load
+
+    Arena a1_, a2_;
+    std::map<std::string, Tap> taps_;
+    int tap_batch_ = 0;
+
+    float* upload(const std::vector<float>& v);
+    float* upload_tensor(const ModelFile& f, const std::string& name, std::string& err);
+    bool pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, int t_hint, PackedConv& out, std::string& err,
+              int ct_stride = 0, int transform = 0);
+    bool load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err);
+    hipError_t conv(const char* name, const PackedConv& w, ConvCall c);
+    hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax);
+    void snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens);
+    void clear_taps();
+};
+
+}  // namespace vits
+
+struct vits_model {
+    vits::Engine eng;
+};

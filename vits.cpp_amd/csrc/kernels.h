@@ -1,0 +1,89 @@
+// kernels.h — launch interface of the hand-written gfx950 kernels (host side sees only these functions).
+//
+// Data layout everywhere: activations are fp32 [batch][channel][time], TIME CONTIGUOUS (== the reference's ggml
+// ne order [time, channel, batch], so a wavefront's 64 lanes read 64 consecutive time steps = 256 B coalesced).
+// Every tensor argument carries its own batch stride (bs) and channel stride (cs), in floats. Ragged batches:
+// `len[b]` is the number of valid time steps of utterance b; loads beyond it read as ZERO (utterance boundaries
+// behave exactly like the zero padding a batch-1 run sees) and stores beyond it are suppressed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace vits {
+
+struct TensorRef {
+    float* p = nullptr;
+    int64_t bs = 0;  // batch stride (floats)
+    int32_t cs = 0;  // channel stride (floats)
+};
+
+// ---- MFMA convolution ---------------------------------------------------------------------------------
+enum ConvEpilogue : int { EPI_STD = 0, EPI_GATE = 1, EPI_CONVT = 2 };
+enum ConvTile : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x64 = 3, TILE_32x64 = 4 };
+
+// Weights pre-packed at load time in exact MFMA A-fragment order (see conv_mfma.hip), resident in HBM.
+struct PackedConv {
+    float* wp = nullptr;    // packed weights
+    float* bias = nullptr;  // [cout] (original channel order) or nullptr
+    int cin = 0, cout = 0, kt = 0;
+    int rows = 0;      // GEMM M (cout, or cout*stride for the transposed conv)
+    int mtiles = 0;       // number of 32-row tiles in the packed array (padded to a multiple of 4)
+    int mtiles_used = 0;  // tiles that hold real rows
+    int nchunks = 0;   // ceil(cin / 32)
+    int epi = EPI_STD;
+    int ct_stride = 0;  // EPI_CONVT: upsampling stride s
+    int64_t bytes = 0;
+};
+
+struct ConvCall {
+    TensorRef x, y, res, acc;  // res/acc optional (p == nullptr)
+    const int* len_in = nullptr;   // per-utterance valid input length (nullptr: t_in)
+    const int* len_out = nullptr;  // per-utterance valid output length (nullptr: t_out)
+    int batch = 1;
+    int t_in = 0, t_out = 0;  // maximum lengths (grid extent)
+    int dil = 1, pad_l = 0;
+    int pre_act = 0;  // 1: leaky_relu(slope) on load
+    float slope = 0.f;
+    int post_act = 0;  // 1: relu
+    float scale = 1.f;  // applied when acc.p: y = (acc + v) * scale, or / scale when scale_div
+    int scale_div = 0;
+    int ct_crop = 0;  // EPI_CONVT: output crop
+    int tile = -1;    // ConvTile override (-1: chosen from the shape)
+};
+
+// host-side packing: w is torch layout [cout][cin][k] (EPI_STD / EPI_GATE) or [cin][cout][k] (EPI_CONVT)
+std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, int epi, int ct_stride, int* rows, int* mtiles_used, int* mtiles,
+                                     int* nchunks);
+int choose_conv_tile(int rows, int epi, int t_hint);
+hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s);
+double conv_flops(const PackedConv& w, const ConvCall& c, int64_t total_cols);
+
+// ---- small kernels ------------------------------------------------------------------------------------
+hipError_t launch_embed(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, TensorRef x, int batch, int tmax,
+                        hipStream_t s);
+hipError_t launch_scale_rows(TensorRef x, int channels, float scale, int batch, int tmax, hipStream_t s);
+hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
+                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s);
+hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
+                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s);
+hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s);
+hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch,
+                                  int channels, int tmax, hipStream_t s);
+hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode,
+                         hipStream_t s);
+hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
+                         hipStream_t s);
+hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, float scale, hipStream_t s);
+hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
+                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s);
+hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
+                     uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s);
+hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch,
+                            int tmax, hipStream_t s);
+
+}  // namespace vits

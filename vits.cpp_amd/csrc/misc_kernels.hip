@@ -1,0 +1,643 @@
+// misc_kernels.hip — the non-GEMM kernels of the path (all HBM/latency-bound; coalesced along time).
+// Each kernel cites the reference lines it replaces (/root/reference/src/...).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/vits.h"
+#include "../../include/vits_synth_noise.h"
+#include "kernels.h"
+
+namespace vits {
+
+// ---------------------------------------------------------------------------------------------------------
+// embedding gather * sqrt(hidden)   (vits.cpp:262-264: ggml_get_rows + ggml_scale)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, float* x, int64_t bs, int cs,
+                             int tmax) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tmax) return;
+    const int len = lens ? lens[b] : tmax;
+    float v = 0.f;
+    if (t < len) v = table[(size_t)ids[(size_t)b * id_stride + t] * hidden + c] * scale;
+    x[(int64_t)b * bs + (int64_t)c * cs + t] = v;
+}
+
+hipError_t launch_embed(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, TensorRef x, int batch, int tmax,
+                        hipStream_t s) {
+    dim3 grid((tmax + 63) / 64, hidden, batch);
+    hipLaunchKernelGGL(embed_kernel, grid, dim3(64), 0, s, ids, id_stride, lens, table, hidden, scale, x.p, x.bs, x.cs, tmax);
+    return hipGetLastError();
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Relative-position self-attention core (vits.cpp:296-356; helpers :195-235).  SURVEY.md App. F1 closed form:
+//   s_ij = q_i.k_j + [|j-i|<=w] q_i.Ek[j-i+w];  p = softmax_j;  o_i = sum_j p_ij v_j + sum_{|j-i|<=w} p_ij Ev[j-i+w]
+// The reference materialises dense (2T-1)-row relative tables and pads/reshapes them (pure data movement);
+// here the 2w+1 relative logits are 9 extra dot products per query.
+// One block = (utterance, head, 16 queries); scores for the 16 queries x T keys live in LDS.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ATT_Q = 16;
+
+__global__ __launch_bounds__(256) void rel_attention_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+                                                            int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
+                                                            int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
+    const int len = lens ? lens[b] : tmax;
+    if (i0 >= len) return;
+    const int hd = head_dim, nrel = 2 * window + 1;
+    float* qs = sm;                      // [ATT_Q][hd]
+    float* qe = qs + ATT_Q * hd;         // [ATT_Q][nrel]   q_i . Ek[r]
+    float* sc = qe + ATT_Q * nrel;       // [ATT_Q][len_pad]
+    const int lp = (len + 3) & ~3;
+    const int tid = threadIdx.x;
+    const float* qb = q + (int64_t)b * q_bs + (int64_t)h * hd * q_cs;
+    const float* kb = k + (int64_t)b * k_bs + (int64_t)h * hd * k_cs;
+    const float* vb = v + (int64_t)b * v_bs + (int64_t)h * hd * v_cs;
+    for (int idx = tid; idx < ATT_Q * hd; idx += 256) {
+        const int d = idx / ATT_Q, qi = idx % ATT_Q;
+        const int i = i0 + qi;
+        qs[qi * hd + d] = i < len ? qb[(int64_t)d * q_cs + i] * q_scale : 0.f;  // scaling: vits.cpp:296-297
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ATT_Q * nrel; idx += 256) {
+        const int qi = idx / nrel, r = idx % nrel;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a += qs[qi * hd + d] * rel_k[r * hd + d];
+        qe[idx] = a;
+    }
+    __syncthreads();
+    // scores: thread -> key j (coalesced along time), loops over the 16 queries
+    for (int j = tid; j < len; j += 256) {
+        float a[ATT_Q];
+#pragma unroll
+        for (int qi = 0; qi < ATT_Q; ++qi) a[qi] = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            const float kv = kb[(int64_t)d * k_cs + j];
+#pragma unroll
+            for (int qi = 0; qi < ATT_Q; ++qi) a[qi] += qs[qi * hd + d] * kv;
+        }
+#pragma unroll
+        for (int qi = 0; qi < ATT_Q; ++qi) {
+            const int r = j - (i0 + qi) + window;
+            float s = a[qi];
+            if (r >= 0 && r < nrel) s += qe[qi * nrel + r];
+            sc[qi * lp + j] = s;
+        }
+    }
+    __syncthreads();
+    // softmax per query: 16 lanes per query
+    {
+        const int qi = tid >> 4, l16 = tid & 15;
+        float mx = -INFINITY;
+        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        for (int j = l16; j < len; j += 16) {
+            const float e = expf(sc[qi * lp + j] - mx);
+            sc[qi * lp + j] = e;
+            sum += e;
+        }
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
+    }
+    __syncthreads();
+    // o[qi][d] = sum_j p[qi][j] v[d][j] + windowed relative-value term; thread -> (d, 4-query group)
+    float* ob = out + (int64_t)b * o_bs + (int64_t)h * hd * o_cs;
+    for (int idx = tid; idx < hd * (ATT_Q / 4); idx += 256) {
+        const int d = idx % hd, qg = idx / hd;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* p0 = sc + (qg * 4 + 0) * lp;
+        const float* p1 = sc + (qg * 4 + 1) * lp;
+        const float* p2 = sc + (qg * 4 + 2) * lp;
+        const float* p3 = sc + (qg * 4 + 3) * lp;
+        const float* vr = vb + (int64_t)d * v_cs;
+        for (int j = 0; j < len; ++j) {
+            const float vv = vr[j];
+            a0 += p0[j] * vv;
+            a1 += p1[j] * vv;
+            a2 += p2[j] * vv;
+            a3 += p3[j] * vv;
+        }
+        float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int qi = qg * 4 + u, i = i0 + qi;
+            if (i >= len) continue;
+            float rsum = 0.f;
+            for (int r = 0; r < nrel; ++r) {
+                const int j = i + r - window;
+                if (j >= 0 && j < len) rsum += sc[qi * lp + j] * rel_v[r * hd + d];
+            }
+            ob[(int64_t)d * o_cs + i] = acc[u] + rsum;
+        }
+    }
+}
+
+hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
+                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s) {
+    const int lp = (tmax + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * lp);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rel_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
+    hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(256), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
+                       lens, head_dim, tmax, window, q_scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y = LayerNorm_channels(x + res) [optionally gelu, optionally add_to += y]
+//   encoder: vits.cpp:365-372, 412-418 (ggml_add + ggml_norm + mul + add = 4 nodes)
+//   DDS:     vits.cpp:679-688 (permute, cont, norm, permute, cont, gelu, add)
+// Block = 64 time steps x all channels; the tile is held in LDS so x is read from HBM once.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
+                                                             const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs, float* addto,
+                                                             int64_t a_bs, int a_cs, const int* lens, int channels, int tmax, float eps, int post_gelu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* tile = sm;                    // [channels][64]
+    float* red = sm + channels * 64;     // [4][64] x2
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int len = lens ? lens[b] : tmax;
+    if (t0 >= len) return;
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = t0 + tl;
+    const bool ok = t < len;
+    float s = 0.f;
+    for (int c = g; c < channels; c += 4) {
+        float v = 0.f;
+        if (ok) {
+            v = x[(int64_t)b * x_bs + (int64_t)c * x_cs + t];
+            if (res) v += res[(int64_t)b * r_bs + (int64_t)c * r_cs + t];
+        }
+        tile[c * 64 + tl] = v;
+        s += v;
+    }
+    red[g * 64 + tl] = s;
+    __syncthreads();
+    const float mean = (red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl]) / (float)channels;
+    float vs = 0.f;
+    for (int c = g; c < channels; c += 4) {
+        const float d = tile[c * 64 + tl] - mean;
+        vs += d * d;
+    }
+    red[256 + g * 64 + tl] = vs;
+    __syncthreads();
+    const float var = (red[256 + tl] + red[320 + tl] + red[384 + tl] + red[448 + tl]) / (float)channels;
+    const float inv = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    for (int c = g; c < channels; c += 4) {
+        float v = (tile[c * 64 + tl] - mean) * inv * gamma[c] + beta[c];
+        if (post_gelu) v = gelu_erf(v);
+        if (addto) {
+            float* a = addto + (int64_t)b * a_bs + (int64_t)c * a_cs + t;
+            *a = *a + v;
+        } else
+            y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = v;
+    }
+}
+
+hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
+                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)channels * 64 + 512);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(add_layer_norm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((tmax + 63) / 64, batch);
+    hipLaunchKernelGGL(add_layer_norm_kernel, grid, dim3(256), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
+                       add_to.cs, lens, channels, tmax, eps, post_gelu);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DDS first half: y = gelu(LN_channels(depthwise_conv_k(x [+ g], dilation) + bias))
+//   vits.cpp:651-673 with depthwise_conv_with_bias :144-169 (the reference runs `channels` separate 1-channel
+//   convolutions = ~2,300 graph nodes per predictor, Q16). If g != null, x <- x + g is also written back
+//   (vits.cpp:651-653 happens once before the layer loop; the engine passes g only for layer 0).
+// Block = 64 time steps x all channels, input tile with halo in LDS.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dds_depthwise_kernel(float* x, int64_t x_bs, int x_cs, const float* g, int64_t g_bs, int g_cs, const float* w,
+                                                            const float* bias, const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs,
+                                                            const int* lens, int channels, int tmax, int k, int dil, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int pad = (k * dil - dil) / 2;  // vits.cpp:660
+    const int xw = 64 + 2 * pad;
+    float* xt = sm;                       // [channels][xw]
+    float* ht = xt + channels * xw;       // [channels][64]
+    float* red = ht + channels * 64;      // [512]
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int len = lens ? lens[b] : tmax;
+    if (t0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int c = wid; c < channels; c += 4) {
+        for (int i = lane; i < xw; i += 64) {
+            const int t = t0 - pad + i;
+            float v = 0.f;
+            if (t >= 0 && t < len) {
+                v = x[(int64_t)b * x_bs + (int64_t)c * x_cs + t];
+                if (g) {
+                    v += g[(int64_t)b * g_bs + (int64_t)c * g_cs + t];
+                }
+            }
+            xt[c * xw + i] = v;
+        }
+    }
+    __syncthreads();
+    if (g) {  // write back x + g for the centre columns (this block owns them)
+        for (int c = wid; c < channels; c += 4) {
+            const int t = t0 + lane;
+            if (t < len) x[(int64_t)b * x_bs + (int64_t)c * x_cs + t] = xt[c * xw + pad + lane];
+        }
+    }
+    const int tl = lane, gq = wid;
+    float s = 0.f;
+    for (int c = gq; c < channels; c += 4) {
+        float a = bias[c];
+        for (int j = 0; j < k; ++j) a += w[c * k + j] * xt[c * xw + tl + j * dil];
+        ht[c * 64 + tl] = a;
+        s += a;
+    }
+    red[gq * 64 + tl] = s;
+    __syncthreads();
+    const float mean = (red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl]) / (float)channels;
+    float vs = 0.f;
+    for (int c = gq; c < channels; c += 4) {
+        const float d = ht[c * 64 + tl] - mean;
+        vs += d * d;
+    }
+    red[256 + gq * 64 + tl] = vs;
+    __syncthreads();
+    const float var = (red[256 + tl] + red[320 + tl] + red[384 + tl] + red[448 + tl]) / (float)channels;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const int t = t0 + tl;
+    if (t >= len) return;
+    for (int c = gq; c < channels; c += 4) y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = gelu_erf((ht[c * 64 + tl] - mean) * inv * gamma[c] + beta[c]);
+}
+
+hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s) {
+    const int pad = (k * dil - dil) / 2;
+    const size_t lds = sizeof(float) * ((size_t)channels * (64 + 2 * pad) + (size_t)channels * 64 + 512);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dds_depthwise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((tmax + 63) / 64, batch);
+    hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(256), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
+                       k, dil, eps);
+    return hipGetLastError();
+}
+
+// conv_pre of a conv flow: 1 -> channels pointwise conv of latent row zc (vits.cpp:864): y[c][t] = w[c]*z[zc][t] + b[c]
+//   optionally + cond[c][t]: the DDS block's "inputs + global_conditioning" (vits.cpp:651-653), same order of additions
+__global__ void pointwise_from1_kernel(const float* z, int64_t z_bs, int z_cs, int zc, const float* w, const float* bias, const float* cond, int64_t c_bs,
+                                       int c_cs, float* y, int64_t y_bs, int y_cs, const int* lens, int tmax) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    float v = w[c] * z[(int64_t)b * z_bs + (int64_t)zc * z_cs + t] + bias[c];
+    if (cond) v = v + cond[(int64_t)b * c_bs + (int64_t)c * c_cs + t];
+    y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = v;
+}
+hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch, int channels,
+                                  int tmax, hipStream_t s) {
+    dim3 grid((tmax + 63) / 64, channels, batch);
+    hipLaunchKernelGGL(pointwise_from1_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, zc, w, bias, cond.p, cond.bs, cond.cs, y.p, y.bs, y.cs, lens, tmax);
+    return hipGetLastError();
+}
+
+__global__ void fill_rows_kernel(float* x, int64_t bs, int cs, float v, int tmax) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tmax) return;
+    x[(int64_t)b * bs + (int64_t)c * cs + t] = v;
+}
+hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s) {
+    dim3 grid((tmax + 255) / 256, channels, batch);
+    hipLaunchKernelGGL(fill_rows_kernel, grid, dim3(256), 0, s, x.p, x.bs, x.cs, v, tmax);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Inverse rational-quadratic spline on latent row zc, one thread per token
+//   vits.cpp:695-802 (+ tails :804-852); HF modeling_vits.py:139-163,211-302. u = conv_proj output [3*bins-1][T].
+//   mode == VITS_MODE_REFERENCE applies Q3 (:720) and, on the LAST token, Q4 (ggml-util.h:235-236,252-253).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MAX_BINS = 16;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : (float)log(1.0 + exp((double)x)); }  // custom-ops.h:872-879
+
+__global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax, int nb, float B,
+                              float inv_sqrt, int mode) {
+    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    float* zp = z + (int64_t)b * z_bs + (int64_t)zc * z_cs + t;
+    const float x = *zp;
+    if (!(x >= -B && x <= B)) return;  // identity outside the interval (:819-832)
+    const float* ub = u + (int64_t)b * u_bs + t;
+    const bool q4 = (mode == VITS_MODE_REFERENCE) && (t == len - 1);
+    const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+    float W[MAX_BINS], H[MAX_BINS], cw[MAX_BINS + 1], ch[MAX_BINS + 1];
+    // widths
+    {
+        float mx = -INFINITY;
+        for (int i = 0; i < nb; ++i) {
+            W[i] = ub[(int64_t)i * u_cs] * inv_sqrt;
+            mx = fmaxf(mx, W[i]);
+        }
+        float sum = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            W[i] = expf(W[i] - mx);
+            sum += W[i];
+        }
+        for (int i = 0; i < nb; ++i) W[i] /= sum;
+        if (mode == VITS_MODE_REFERENCE) {
+            const float sc = min_w + (1 - min_w * nb);  // Q3
+            for (int i = 0; i < nb; ++i) W[i] = W[i] * sc;
+        } else {
+            for (int i = 0; i < nb; ++i) W[i] = min_w + (1 - min_w * nb) * W[i];
+        }
+        float cum = 0.f;
+        cw[0] = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            cum += W[i];
+            cw[i + 1] = cum;
+        }
+        for (int i = 0; i <= nb; ++i) cw[i] = (B - (-B)) * cw[i] + (-B);
+        cw[0] = -B;
+        if (!q4) cw[nb] = B;
+        for (int i = 0; i < nb; ++i) W[i] = cw[i + 1] - cw[i];
+    }
+    {
+        float mx = -INFINITY;
+        for (int i = 0; i < nb; ++i) {
+            H[i] = ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
+            mx = fmaxf(mx, H[i]);
+        }
+        float sum = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            H[i] = expf(H[i] - mx);
+            sum += H[i];
+        }
+        for (int i = 0; i < nb; ++i) H[i] /= sum;
+        for (int i = 0; i < nb; ++i) H[i] = min_h + (1 - min_h * nb) * H[i];
+        float cum = 0.f;
+        ch[0] = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            cum += H[i];
+            ch[i + 1] = cum;
+        }
+        for (int i = 0; i <= nb; ++i) ch[i] = (B - (-B)) * ch[i] + (-B);
+        ch[0] = -B;
+        if (!q4) ch[nb] = B;
+        for (int i = 0; i < nb; ++i) H[i] = ch[i + 1] - ch[i];
+    }
+    int bin = -1;
+    for (int i = 0; i <= nb; ++i) {
+        float loc = ch[i];
+        if (i == nb && !q4) loc += 1e-6f;
+        if (x >= loc) bin++;
+    }
+    bin = min(max(bin, 0), nb - 1);
+    const float constant = (float)log(exp(1.0 - (double)min_d) - 1.0);
+    auto deriv = [&](int i) -> float {
+        float ud;
+        if (i == 0) ud = constant;
+        else if (i == nb) ud = q4 ? 0.f : constant;
+        else ud = ub[(int64_t)(2 * nb + i - 1) * u_cs];
+        return min_d + softplus_f(ud);
+    };
+    float in_cw = 0.f, in_w = 1.f, in_ch = 0.f, in_h = 1.f;
+    for (int i = 0; i < nb; ++i)  // register arrays: select without dynamic indexing
+        if (i == bin) {
+            in_cw = cw[i];
+            in_w = W[i];
+            in_ch = ch[i];
+            in_h = H[i];
+        }
+    const float d0 = deriv(bin), d1 = deriv(bin + 1);
+    const float delta = in_h / in_w;
+    const float i1 = d0 + d1 - 2 * delta;
+    const float i2 = x - in_ch;
+    const float i3 = i2 * i1;
+    const float a = in_h * (delta - d0) + i3;
+    const float bq = in_h * d0 - i3;
+    const float cc = -delta * i2;
+    const float disc = bq * bq - 4 * a * cc;
+    const float root = (2 * cc) / (-bq - sqrtf(disc));
+    *zp = root * in_w + in_cw;
+}
+
+hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode, hipStream_t s) {
+    if (bins > MAX_BINS) return hipErrorInvalidValue;
+    dim3 grid((tmax + 63) / 64, batch);
+    hipLaunchKernelGGL(spline_kernel, grid, dim3(64), 0, s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt, mode);
+    return hipGetLastError();
+}
+
+// elementwise affine, reverse (vits.cpp:901-925; Q5 sign): logical channel ch lives in physical row (c_first ? 1-ch : ch)
+__global__ void affine_kernel(float* z, int64_t z_bs, int z_cs, int c_first, const float* translate, const float* log_scale, int sign, const int* lens,
+                              int tmax) {
+    const int b = blockIdx.z, ch = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    const int row = c_first ? 1 - ch : ch;
+    float* p = z + (int64_t)b * z_bs + (int64_t)row * z_cs + t;
+    *p = (*p - translate[ch]) * expf(sign > 0 ? log_scale[ch] : -log_scale[ch]);
+}
+hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
+                         hipStream_t s) {
+    dim3 grid((tmax + 63) / 64, 2, batch);
+    hipLaunchKernelGGL(affine_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, c_first, translate, log_scale, sign, lens, tmax);
+    return hipGetLastError();
+}
+
+// duration latents: z[c][t] = N(0,1) * noise_scale_duration (vits.cpp:948-949), counter-based stream
+__global__ void noise_dur_kernel(float* z, int64_t z_bs, int z_cs, const int* lens, int tmax, uint64_t seed, float scale) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    z[(int64_t)b * z_bs + (int64_t)c * z_cs + t] = vits_counter_normal(seed + (uint64_t)b, VITS_STREAM_NOISE_DUR, (uint64_t)c * len + t) * scale;
+}
+hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, float scale, hipStream_t s) {
+    dim3 grid((tmax + 63) / 64, 2, batch);
+    hipLaunchKernelGGL(noise_dur_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, lens, tmax, seed, scale);
+    return hipGetLastError();
+}
+
+__global__ void scale_rows_kernel(float* x, int64_t bs, int cs, float scale, int tmax) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tmax) return;
+    x[(int64_t)b * bs + (int64_t)c * cs + t] *= scale;
+}
+hipError_t launch_scale_rows(TensorRef x, int channels, float scale, int batch, int tmax, hipStream_t s) {
+    dim3 grid((tmax + 63) / 64, channels, batch);
+    hipLaunchKernelGGL(scale_rows_kernel, grid, dim3(64), 0, s, x.p, x.bs, x.cs, scale, tmax);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// durations: d = ceil(exp(logw) * length_scale) (vits.cpp:996), per-utterance inclusive cumsum (:1001),
+// frames L = max(1, sum) (:999-1000,1133) and the per-stage vocoder lengths. One block per utterance.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64_t l_bs, int l_cs, int c, const int* lens, int tmax, float length_scale,
+                                                        int fixed, float* dur, int* cum, int* frames, int* stage_lens, int n_stage, const int* stage_mul,
+                                                        const int* stage_add, int batch) {
+    __shared__ int part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    const int per = (tmax + 255) / 256;
+    const int beg = tid * per, end = min(beg + per, len);
+    int s = 0;
+    for (int t = beg; t < end; ++t) {
+        float d = ceilf(expf(logw[(int64_t)b * l_bs + (int64_t)c * l_cs + t]) * length_scale);
+        if (fixed > 0) d = (float)fixed;
+        dur[(int64_t)b * tmax + t] = d;
+        s += (int)d;
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        const int L = max(1, run);
+        frames[b] = L;
+        for (int st = 0; st < n_stage; ++st) stage_lens[st * batch + b] = L * stage_mul[st] + stage_add[st];
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int t = beg; t < end; ++t) {
+        run += (int)dur[(int64_t)b * tmax + t];
+        cum[(int64_t)b * tmax + t] = run;
+    }
+    for (int t = max(beg, len); t < min(beg + per, tmax); ++t) {
+        dur[(int64_t)b * tmax + t] = 0.f;
+        cum[(int64_t)b * tmax + t] = 0x7fffffff;
+    }
+}
+
+hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
+                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s) {
+    hipLaunchKernelGGL(durations_kernel, dim3(batch), dim3(256), 0, s, logw.p, logw.bs, logw.cs, c, lens, tmax, length_scale, fixed, dur, cum, frames, stage_lens,
+                       n_stage, stage_mul, stage_add, batch);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prior sampling through the monotonic alignment, as a GATHER:
+//   a(j) = min{ i : j < cum_i };  z_p[c][j] = mean[c][a(j)] + eps[c][j] * exp(logvar[c][a(j)]) * noise_scale
+// replaces the dense [L,T] one-hot matrix + two mul_mat (vits.cpp:1028-1057) and :1059-1063.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs, int m_cs, const float* logvar, int64_t v_bs, int v_cs, const int* cum,
+                                                 int cum_stride, const int* tok_lens, const int* frames, const float* noise, int64_t n_bs, int n_cs,
+                                                 int noise_kind, uint64_t seed, float noise_scale, float* zp, int64_t z_bs, int z_cs, int channels, int tmax_tok) {
+    __shared__ int tok[256];
+    const int b = blockIdx.y, j0 = blockIdx.x * 256, tid = threadIdx.x;
+    const int L = frames[b];
+    if (j0 >= L) return;
+    const int T = tok_lens ? tok_lens[b] : tmax_tok;
+    const int j = j0 + tid;
+    {
+        // binary search: first i with cum[i] > j
+        const int* cb = cum + (int64_t)b * cum_stride;
+        int lo = 0, hi = T;  // answer in [0, T]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cb[mid] > j) hi = mid;
+            else lo = mid + 1;
+        }
+        tok[tid] = lo < T ? lo : -1;
+    }
+    __syncthreads();
+    if (j >= L) return;
+    const int a = tok[tid];
+    for (int c = 0; c < channels; ++c) {
+        const float mu = a >= 0 ? mean[(int64_t)b * m_bs + (int64_t)c * m_cs + a] : 0.f;
+        const float lv = a >= 0 ? logvar[(int64_t)b * v_bs + (int64_t)c * v_cs + a] : 0.f;
+        float e;
+        if (noise_kind == VITS_NOISE_COUNTER) e = vits_counter_normal(seed + (uint64_t)b, VITS_STREAM_NOISE_PRIOR, (uint64_t)c * L + j);
+        else e = noise[(int64_t)b * n_bs + (int64_t)c * n_cs + j];
+        float n = e * expf(lv);  // vits.cpp:1060
+        n = n * noise_scale;     // :1061
+        zp[(int64_t)b * z_bs + (int64_t)c * z_cs + j] = mu + n;
+    }
+}
+
+hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
+                     uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s) {
+    dim3 grid((lmax + 255) / 256, batch);
+    hipLaunchKernelGGL(zp_kernel, grid, dim3(256), 0, s, mean.p, mean.bs, mean.cs, logvar.p, logvar.bs, logvar.cs, cum, cum_stride, tok_lens, frames, noise.p,
+                       noise.bs, noise.cs, noise_kind, seed, noise_scale, zp.p, zp.bs, zp.cs, channels, cum_stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_post: leaky_relu -> Conv1d(C -> 1, k, no bias) -> tanh   (vits.cpp:638-642). One output row: a matrix
+// tile would be 31/32 empty, so this is a VALU kernel; HBM-bound (reads C floats per output sample).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t x_bs, int x_cs, const float* w, int cin, int k, float slope, float* pre,
+                                                        int64_t p_bs, float* wave, int64_t w_bs, const int* lens, int tmax) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [cin][k]
+    const int b = blockIdx.y;
+    const int len = lens ? lens[b] : tmax;
+    const int t0 = blockIdx.x * 1024;
+    if (t0 >= len) return;
+    for (int i = threadIdx.x; i < cin * k; i += 256) sm[i] = w[i];
+    __syncthreads();
+    const int pad = (k - 1) / 2;
+    const float* xb = x + (int64_t)b * x_bs;
+    for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * 256 + threadIdx.x;
+        if (t >= len) continue;
+        float a = 0.f;
+        for (int c = 0; c < cin; ++c) {
+            const float* xr = xb + (int64_t)c * x_cs;
+            for (int j = 0; j < k; ++j) {
+                const int tt = t + j - pad;
+                float v = (tt >= 0 && tt < len) ? xr[tt] : 0.f;
+                v = v > 0.f ? v : v * slope;
+                a += sm[c * k + j] * v;
+            }
+        }
+        if (pre) pre[(int64_t)b * p_bs + t] = a;
+        wave[(int64_t)b * w_bs + t] = tanhf(a);
+    }
+}
+
+hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch, int tmax,
+                            hipStream_t s) {
+    dim3 grid((tmax + 1023) / 1024, batch);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * cin * k, s, x.p, x.bs, x.cs, w, cin, k, slope, pre_tanh.p, pre_tanh.bs, wave.p, wave.bs,
+                       lens, tmax);
+    return hipGetLastError();
+}
+
+}  // namespace vits
