@@ -190,6 +190,9 @@ VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, 
                                     const float* x, const float* residual, const float* gamma, const float* beta,
                                     float* y);
 
+/* Select the HIP device used by subsequent loads on this thread (one process per GPU: pass LOCAL_RANK). */
+VITS_API int vits_set_device(int32_t device);
+
 /* Device facts (for the bench's roofline block). */
 VITS_API int vits_device_info(char* name, size_t cap, int32_t* cu_count, int32_t* clock_mhz, int64_t* hbm_bytes);
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "vits_model_sync", "vits_model_tokenize", "vits_model_sampling_rate", "vits_model_vocab_size",
     "vits_model_weight_bytes", "vits_model_get_tap", "vits_synth_model_bytes", "vits_free_bytes",
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
-    "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info",
+    "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.vits_op_rel_attention.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.vits_op_add_layer_norm.restype = i32
     L.vits_op_add_layer_norm.argtypes = [i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, vp]
+    L.vits_set_device.restype = i32
+    L.vits_set_device.argtypes = [i32]
     L.vits_device_info.restype = i32
     L.vits_device_info.argtypes = [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
     _lib = L
@@ -365,6 +367,11 @@ def op_add_layer_norm(x, residual, gamma, beta, eps=1e-5):
     if lib().vits_op_add_layer_norm(B, Cc, T, T, eps, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y)) != 0:
         raise VitsError(last_error())
     return y
+
+
+def set_device(index):
+    if lib().vits_set_device(index) != 0:
+        raise VitsError(last_error())
 
 
 def device_info():

@@ -234,6 +234,14 @@ VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap) {
     VITS_CATCH(-1)
 }
 
+VITS_API int vits_set_device(int32_t device) {
+    if (hipSetDevice(device) != hipSuccess) {
+        set_err("hipSetDevice failed");
+        return -1;
+    }
+    return 0;
+}
+
 VITS_API int vits_device_info(char* name, size_t cap, int32_t* cu_count, int32_t* clock_mhz, int64_t* hbm_bytes) {
     VITS_TRY
     int dev = 0;
