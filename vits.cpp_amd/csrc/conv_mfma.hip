@@ -62,9 +62,13 @@ struct ConvParams {
     int ct_stride, ct_crop;
 };
 
-template <int KT, int WM, int WN, int MR, int NR, int EPI>
+// DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
+// immediates of the ds_read instructions (one base VGPR instead of one per tap). DIL == 0: run-time dilation (generic).
+template <int KT, int DIL, int WM, int WN, int MR, int NR, int EPI>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = WN * NR * 32;
+    constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
+    constexpr int STEPS = KT * (CK / 8);  // float4 A-fragments (4 MFMA k-steps each) per chunk and row tile
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][xw]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -79,8 +83,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     if (t0 >= ncols) return;
 
     const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
-    const int xw = p.xw;
-    const int tile_start = t0 - p.pad_l - p.lds_off;  // global time of LDS column 0
+    const int xw = DIL != 0 ? BN + SPAN_C : p.xw;
+    const int dil = DIL != 0 ? DIL : p.dil;
+    const int lds_off = DIL != 0 ? (DIL < 0 ? SPAN_C : 0) : p.lds_off;
+    const int tile_start = t0 - p.pad_l - lds_off;  // global time of LDS column 0
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
 
     floatx16 acc[MR][NR];
@@ -92,9 +98,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int krow = lane >> 5;
-    const int col0 = wn * (NR * 32) + (lane & 31) + p.lds_off;
-    const size_t tile_floats = (size_t)p.nchunks * KT * (CK / 2) * 64;  // packed floats per 32-row tile
-    const float4* __restrict__ wbase = reinterpret_cast<const float4*>(p.wp + (size_t)mt0 * tile_floats) + lane;
+    const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off;  // B operand base of this lane
+    const size_t tile4 = (size_t)p.nchunks * STEPS * 64;                           // float4 per 32-row tile
+    const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.wp) + (size_t)mt0 * tile4 + lane;
+    const int total_steps = p.nchunks * STEPS;
+
+    // Software pipeline. A fragments (float4 = 4 MFMA k-steps per row tile) live in a ring of 4 register sets and
+    // are fetched from L2 TWO steps (32 MFMAs, ~2k cycles) ahead of their use; ring position == step index mod 4,
+    // and a tap is exactly 4 steps, so the ring needs no register moves. B values are read from LDS one k-step ahead.
+    float4 ring[4][MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        ring[0][mr] = wq[(size_t)mr * tile4];
+        ring[1][mr] = wq[(size_t)mr * tile4 + (size_t)(total_steps > 1 ? 1 : 0) * 64];
+    }
+    int gstep = 0;
+    static_assert(CK / 8 == 4, "one tap must be 4 A-steps");
 
     for (int c = 0; c < p.nchunks; ++c) {
         __syncthreads();  // everyone finished reading the previous chunk
@@ -115,28 +134,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             }
         }
         __syncthreads();
-        const float4* __restrict__ wq = wbase + (size_t)c * (KT * (CK / 8) * 64);
+        const float* xj = xrow0;  // advances by `dil` floats per tap
+        float b_nxt[NR];
 #pragma unroll
+        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xj[nr * 32];  // (tap 0, pair 0)
+#pragma unroll 1
         for (int j = 0; j < KT; ++j) {
 #pragma unroll
-            for (int p4 = 0; p4 < CK / 8; ++p4) {
-                float4 a4[MR];
+            for (int p4 = 0; p4 < 4; ++p4) {
+                {
+                    const int nstep = gstep + 2 < total_steps ? gstep + 2 : total_steps - 1;  // clamp: stays in bounds
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a4[mr] = wq[(size_t)mr * (tile_floats / 4) + (j * (CK / 8) + p4) * 64];
+                    for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = wq[(size_t)mr * tile4 + (size_t)nstep * 64];
+                }
+                // pin the prefetch at the top of the step: hipcc otherwise sinks the loads next to their first use
+                // (vmcnt wait right behind the issue) and the L2 latency lands between MFMAs
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float* xr = xs + (2 * (4 * p4 + q) + krow) * xw + col0 + j * p.dil;
-                    float bv[NR];
+                    float b_cur[NR];
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) bv[nr] = xr[nr * 32];
+                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
+                    {
+                        // next k-step: next channel pair of this tap, or pair 0 of the next tap (after the last tap this
+                        // reads a few floats past the row: still inside the tile, value unused)
+                        const int pair = p4 * 4 + q;
+                        const float* nx = pair + 1 < CK / 2 ? xj + (2 * (pair + 1)) * xw : xj + dil;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = nx[nr * 32];
+                    }
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) {
-                        const float av = q == 0 ? a4[mr].x : q == 1 ? a4[mr].y : q == 2 ? a4[mr].z : a4[mr].w;
+                        const float4 a4 = ring[p4][mr];
+                        const float av = q == 0 ? a4.x : q == 1 ? a4.y : q == 2 ? a4.z : a4.w;
 #pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nr], acc[mr][nr], 0, 0, 0);
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[nr], acc[mr][nr], 0, 0, 0);
                     }
                 }
+                ++gstep;
             }
+            xj += dil;
         }
     }
 
@@ -287,14 +324,14 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
     return out;
 }
 
-template <int KT, int EPI>
+template <int KT, int DIL, int EPI>
 static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
     const size_t lds = (size_t)CK * p.xw * sizeof(float);
-#define VITS_LAUNCH(WM, WN, MR, NR) hipLaunchKernelGGL((conv_mfma_kernel<KT, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p)
+#define VITS_LAUNCH(WM, WN, MR, NR) hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p)
     switch (tile) {
         case TILE_128x128:
             if (EPI == EPI_GATE) return hipErrorInvalidValue;
@@ -353,36 +390,49 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     if (w.epi == EPI_CONVT) {
         p.dil = -1;  // tap m reads x[q - m]
         p.pad_l = 0;
-        ncols_max = c.t_in + 1;
     } else {
-        p.dil = c.dil;
+        p.dil = w.kt == 1 ? 1 : c.dil;
         p.pad_l = c.pad_l;
-        ncols_max = c.t_out;
     }
     const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
     p.lds_off = span < 0 ? -span : 0;
     p.xw = bn + (span < 0 ? -span : span);
     if ((size_t)CK * p.xw * 4 > 64 * 1024) return hipErrorInvalidValue;
     const int batch = c.batch;
-#define VITS_KT(K)                                                                                  \
-    case K:                                                                                         \
-        if (w.epi == EPI_STD) return launch_tile<K, EPI_STD>(w, tile, p, ncols_max, batch, s);            \
-        break;
+    // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
+#define VITS_GO(K, D, E) return launch_tile<K, D, E>(w, tile, p, ncols_max, batch, s)
+    if (w.epi == EPI_CONVT) {
+        if (w.kt == 2) VITS_GO(2, -1, EPI_CONVT);
+        return hipErrorInvalidValue;
+    }
+    if (w.epi == EPI_GATE) {
+        if (w.kt == 5 && p.dil == 1) VITS_GO(5, 1, EPI_GATE);
+        if (w.kt == 5) VITS_GO(5, 0, EPI_GATE);
+        return hipErrorInvalidValue;
+    }
     switch (w.kt) {
-        VITS_KT(1)
-        VITS_KT(3)
-        VITS_KT(7)
-        VITS_KT(11)
+        case 1: VITS_GO(1, 1, EPI_STD);
+        case 3:
+            if (p.dil == 1) VITS_GO(3, 1, EPI_STD);
+            if (p.dil == 3) VITS_GO(3, 3, EPI_STD);
+            if (p.dil == 5) VITS_GO(3, 5, EPI_STD);
+            VITS_GO(3, 0, EPI_STD);
         case 5:
-            if (w.epi == EPI_STD) return launch_tile<5, EPI_STD>(w, tile, p, ncols_max, batch, s);
-            if (w.epi == EPI_GATE) return launch_tile<5, EPI_GATE>(w, tile, p, ncols_max, batch, s);
-            break;
-        case 2:
-            if (w.epi == EPI_CONVT) return launch_tile<2, EPI_CONVT>(w, tile, p, ncols_max, batch, s);
-            break;
+            if (p.dil == 1) VITS_GO(5, 1, EPI_STD);
+            VITS_GO(5, 0, EPI_STD);
+        case 7:
+            if (p.dil == 1) VITS_GO(7, 1, EPI_STD);
+            if (p.dil == 3) VITS_GO(7, 3, EPI_STD);
+            if (p.dil == 5) VITS_GO(7, 5, EPI_STD);
+            VITS_GO(7, 0, EPI_STD);
+        case 11:
+            if (p.dil == 1) VITS_GO(11, 1, EPI_STD);
+            if (p.dil == 3) VITS_GO(11, 3, EPI_STD);
+            if (p.dil == 5) VITS_GO(11, 5, EPI_STD);
+            VITS_GO(11, 0, EPI_STD);
         default: break;
     }
-#undef VITS_KT
+#undef VITS_GO
     return hipErrorInvalidValue;
 }
 
