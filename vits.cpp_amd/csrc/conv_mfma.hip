@@ -64,7 +64,8 @@ struct ConvParams {
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
 // immediates of the ds_read instructions (one base VGPR instead of one per tap). DIL == 0: run-time dilation (generic).
-template <int KT, int DIL, int WM, int WN, int MR, int NR, int EPI>
+// DB: double-buffered LDS with register-staged loads (pays when there are several chunks: cin >= 128).
+template <int KT, int DIL, bool DB, int WM, int WN, int MR, int NR, int EPI>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = WN * NR * 32;
     constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
@@ -115,26 +116,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     int gstep = 0;
     static_assert(CK / 8 == 4, "one tap must be 4 A-steps");
 
-    for (int c = 0; c < p.nchunks; ++c) {
-        __syncthreads();  // everyone finished reading the previous chunk
-        // ---- stage CK x xw input tile: masked, pre-activated; one wave per row, lanes along time (coalesced)
-        for (int r = wid; r < CK; r += 4) {
-            const int ch = c * CK + r;
-            const float* __restrict__ src = xb + (int64_t)ch * p.x_cs;
-            float* dst = xs + r * xw;
-            const bool chok = ch < p.cin;
-            for (int i = lane; i < xw; i += 64) {
-                const int t = tile_start + i;
-                float v = 0.f;
-                if (chok && t >= 0 && t < len_in) {
-                    v = src[t];
-                    if (p.pre_act) v = v > 0.f ? v : v * p.slope;
-                }
-                dst[i] = v;
-            }
-        }
-        __syncthreads();
-        const float* xj = xrow0;  // advances by `dil` floats per tap
+    // one chunk of MFMA work on the LDS tile whose lane base is `xrow`
+    auto compute_chunk = [&](const float* xrow) __attribute__((always_inline)) {
+        const float* xj = xrow;  // advances by `dil` floats per tap
         float b_nxt[NR];
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xj[nr * 32];  // (tap 0, pair 0)
@@ -174,6 +158,78 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 ++gstep;
             }
             xj += dil;
+        }
+    };
+
+    static_assert(!DB || DIL != 0, "double buffering needs a compile-time row stride");
+    if constexpr (DB) {
+        // ---- double-buffered LDS, register-staged: the global loads of chunk c+1 are issued BEFORE the MFMA work of
+        // chunk c and written to the other LDS buffer AFTER it, so HBM latency hides under the matrix pipe and one
+        // barrier per chunk suffices. One wave per row group (rows wid, wid+4, ...), lanes along time (coalesced).
+        constexpr int XWC = BN + SPAN_C;
+        constexpr int NM = (XWC + 63) / 64;
+        constexpr int NK = CK / 4;
+        float st[NK][NM];
+        auto stage_load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int ch = c * CK + wid + 4 * k;
+                const bool chok = ch < p.cin;
+                // branch-free: always load from a clamped (valid) address, then select zero for padding positions
+                const float* __restrict__ src = xb + (int64_t)(chok ? ch : p.cin - 1) * p.x_cs;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int t = tile_start + lane + 64 * m;
+                    const int tc = t < 0 ? 0 : (t < len_in ? t : len_in - 1);
+                    const float v = src[tc];
+                    st[k][m] = (chok && t == tc) ? v : 0.f;
+                }
+            }
+        };
+        auto stage_store = [&](int buf) __attribute__((always_inline)) {
+            float* dst = xs + buf * (CK * XWC) + wid * XWC + lane;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    float v = st[k][m];
+                    if (p.pre_act) v = v > 0.f ? v : v * p.slope;
+                    if (NM * 64 == XWC || lane + 64 * m < XWC) dst[(4 * k) * XWC + 64 * m] = v;
+                }
+        };
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        for (int c = 0; c < p.nchunks; ++c) {
+            const bool more = c + 1 < p.nchunks;
+            if (more) stage_load(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_chunk(xrow0 + (c & 1) * (CK * XWC));
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stage_store((c + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < p.nchunks; ++c) {
+            __syncthreads();  // everyone finished reading the previous chunk
+            // ---- stage CK x xw input tile: masked, pre-activated; one wave per row, lanes along time (coalesced)
+            for (int r = wid; r < CK; r += 4) {
+                const int ch = c * CK + r;
+                const float* __restrict__ src = xb + (int64_t)ch * p.x_cs;
+                float* dst = xs + r * xw;
+                const bool chok = ch < p.cin;
+                for (int i = lane; i < xw; i += 64) {
+                    const int t = tile_start + i;
+                    float v = 0.f;
+                    if (chok && t >= 0 && t < len_in) {
+                        v = src[t];
+                        if (p.pre_act) v = v > 0.f ? v : v * p.slope;
+                    }
+                    dst[i] = v;
+                }
+            }
+            __syncthreads();
+            compute_chunk(xrow0);
         }
     }
 
@@ -324,14 +380,24 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
     return out;
 }
 
-template <int KT, int DIL, int EPI>
+template <int KT, int DIL, bool DB, int EPI>
 static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
-    const size_t lds = (size_t)CK * p.xw * sizeof(float);
-#define VITS_LAUNCH(WM, WN, MR, NR) hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p)
+    const size_t lds = (size_t)(DB ? 2 : 1) * CK * p.xw * sizeof(float);
+#define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
+    do {                                                                                                                              \
+        static bool big_lds_set = false;                                                                                              \
+        if (lds > 64 * 1024 && !big_lds_set) {                                                                                        \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>),       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+            if (ea != hipSuccess) return ea;                                                                                          \
+            big_lds_set = true;                                                                                                       \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p);                             \
+    } while (0)
     switch (tile) {
         case TILE_128x128:
             if (EPI == EPI_GATE) return hipErrorInvalidValue;
@@ -397,10 +463,15 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
     p.lds_off = span < 0 ? -span : 0;
     p.xw = bn + (span < 0 ? -span : span);
-    if ((size_t)CK * p.xw * 4 > 64 * 1024) return hipErrorInvalidValue;
+    if ((size_t)2 * CK * p.xw * 4 > 160 * 1024) return hipErrorInvalidValue;
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
-#define VITS_GO(K, D, E) return launch_tile<K, D, E>(w, tile, p, ncols_max, batch, s)
+    const bool db = w.nchunks >= 4;  // double-buffer only when there is a next chunk worth prefetching
+#define VITS_GO(K, D, E)                                                                     \
+    do {                                                                                     \
+        if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
+        return launch_tile<K, D, false, E>(w, tile, p, ncols_max, batch, s);                 \
+    } while (0)
     if (w.epi == EPI_CONVT) {
         if (w.kt == 2) VITS_GO(2, -1, EPI_CONVT);
         return hipErrorInvalidValue;
