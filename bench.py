@@ -99,6 +99,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     pkg = load_package()
     pkg.set_device(local_rank)
+    spec = importlib.util.spec_from_file_location("vits_multi_gpu", os.path.join(ROOT, "vits.cpp_amd", "multi_gpu.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
 
     B, T = args.batch, args.ids_per_utt
     mode = pkg.MODE_REFERENCE if args.mode == "reference" else pkg.MODE_HF
@@ -115,16 +118,8 @@ def main():
         _, lengths, frames = model.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_seed, fixed_duration=args.pinned,
                                                  out_device=out.data_ptr(), out_device_stride=cap, skip_host_copy=True)
         if world > 1:
-            # the path's only exchange: all-gather the PCM (and its lengths) over RCCL/xGMI
-            lt = torch.from_numpy(lengths).cuda()
-            smax = lt.max().clone()
-            dist.all_reduce(smax, op=dist.ReduceOp.MAX)
-            smax = int(smax.item())
-            all_len = torch.empty(world * B, dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(all_len, lt)
-            send = out[:, :smax].contiguous()
-            gathered = torch.empty((world * B, smax), dtype=torch.float32, device="cuda")
-            dist.all_gather_into_tensor(gathered, send)
+            # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
+            mg.gather_pcm(out, torch.from_numpy(lengths).cuda())
         return lengths, frames
 
     def fence():

@@ -138,6 +138,11 @@ VITS_API int64_t vits_model_get_tap(vits_model* model, const char* name, int32_t
 #define VITS_SYNTH_TINY 1 /* hidden 16 / small vocoder: small enough to commit as a fixture */
 VITS_API int vits_synth_model_bytes(uint64_t seed, int32_t arch, char** bytes, size_t* size);
 VITS_API void vits_free_bytes(char* bytes);
+/* Parse a model file and write it back (host only): byte-exact round trip of the reference's format
+ * (reader src/vits_model_data.cpp:29-97 + src/vits_tokenizer.cpp:22-55, writer scripts/export_vits.py:5-70). */
+VITS_API int vits_model_file_reserialize(const char* in, size_t in_size, char** out, size_t* out_size);
+/* Tokenize with the vocabulary stored in a model file, without loading the model onto a device. */
+VITS_API int64_t vits_model_file_tokenize(const char* model_bytes, size_t size, const char* text, int32_t* ids, size_t cap);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------------
  * While enabled every kernel launch is bracketed by hipEventRecord on the launch stream. The report is a

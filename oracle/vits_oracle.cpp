@@ -34,25 +34,85 @@ thread_local std::string g_err;
 // ------------------------------------------------------------------------------------------------
 int default_threads() { return std::max((int)std::thread::hardware_concurrency(), 6); }
 
+// persistent workers (like ggml's pool): spawning threads per op would dominate the small ops on many-core hosts
+class Pool {
+  public:
+    static Pool& get() {
+        static Pool p;
+        return p;
+    }
+    void run(int threads, int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+        std::unique_lock<std::mutex> run_lock(run_mu_);  // one parallel region at a time
+        const int nt = (int)std::min<int64_t>(threads, n);
+        ensure(nt - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            chunk_ = std::max<int64_t>(1, n / (nt * 4));
+            next_.store(0);
+            active_ = nt - 1;
+            pending_ = nt - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+    int64_t n_ = 0, chunk_ = 1;
+    std::atomic<int64_t> next_{0};
+    int active_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+    void work() {
+        for (;;) {
+            const int64_t b = next_.fetch_add(chunk_);
+            if (b >= n_) break;
+            (*fn_)(b, std::min(n_, b + chunk_));
+        }
+    }
+    void ensure(int count) {
+        while ((int)workers_.size() < count) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && id < active_); });
+                    if (stop_) return;
+                    seen = epoch_;
+                    lk.unlock();
+                    work();
+                    lk.lock();
+                    if (--pending_ == 0) done_cv_.notify_all();
+                }
+            });
+        }
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+};
+
 void parallel_for(int threads, int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
     if (threads <= 1 || n <= 1) {
         fn(0, n);
         return;
     }
-    int nt = (int)std::min<int64_t>(threads, n);
-    std::vector<std::thread> th;
-    std::atomic<int64_t> next(0);
-    int64_t chunk = std::max<int64_t>(1, n / (nt * 4));
-    auto work = [&]() {
-        for (;;) {
-            int64_t b = next.fetch_add(chunk);
-            if (b >= n) break;
-            fn(b, std::min(n, b + chunk));
-        }
-    };
-    for (int i = 1; i < nt; ++i) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    Pool::get().run(threads, n, fn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,32 +324,54 @@ void conv1d_raw(const float* x, int cin, int T, int x_stride, const float* w, co
         else
             std::memcpy(dst, src, sizeof(float) * T);
     }
-    const int TT = 512;
+    // register-blocked direct convolution: 4 output channels x 32 time steps of accumulators stay in vector registers
+    // while (ci, tap) runs; each x vector is loaded once for the 4 channels. Same arithmetic as the im2col+GEMM of
+    // the reference (sum over (ci, tap) of w*x, fp32), different summation grouping only.
+    typedef float v8 __attribute__((vector_size(32), aligned(4)));
+    const int TT = 512, TB = 32;
     const int CB = 4;
     const int ncb = (cout + CB - 1) / CB;
     const int ntt = (To + TT - 1) / TT;
     parallel_for(threads, (int64_t)ncb * ntt, [&](int64_t b, int64_t e) {
-        std::vector<float> acc((size_t)CB * TT);
         for (int64_t item = b; item < e; ++item) {
             const int cb = (int)(item / ntt), tt = (int)(item % ntt);
             const int co0 = cb * CB, nco = std::min(CB, cout - co0);
             const int t0 = tt * TT, nt = std::min(TT, To - t0);
-            for (int r = 0; r < nco; ++r) {
-                float bv = bias ? bias[co0 + r] : 0.f;
-                float* a = acc.data() + (size_t)r * TT;
-                for (int t = 0; t < nt; ++t) a[t] = bv;
+            const float* wr[CB];
+            float bv[CB];
+            for (int r = 0; r < CB; ++r) {
+                const int co = co0 + std::min(r, nco - 1);
+                wr[r] = w + (size_t)co * cin * K;
+                bv[r] = bias ? bias[co] : 0.f;
             }
-            for (int ci = 0; ci < cin; ++ci) {
-                for (int j = 0; j < K; ++j) {
-                    const float* xr = xp.data() + (size_t)ci * Tp + t0 + j * dil;
-                    for (int r = 0; r < nco; ++r) {
-                        const float wv = w[((size_t)(co0 + r) * cin + ci) * K + j];
-                        float* a = acc.data() + (size_t)r * TT;
-                        for (int t = 0; t < nt; ++t) a[t] += wv * xr[t];
+            int tb = 0;
+            for (; tb + TB <= nt; tb += TB) {
+                v8 a[CB][TB / 8];
+                for (int r = 0; r < CB; ++r)
+                    for (int v = 0; v < TB / 8; ++v) a[r][v] = v8{bv[r], bv[r], bv[r], bv[r], bv[r], bv[r], bv[r], bv[r]};
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float* xrow = xp.data() + (size_t)ci * Tp + t0 + tb;
+                    for (int j = 0; j < K; ++j) {
+                        const float* xr = xrow + j * dil;
+                        v8 xv[TB / 8];
+                        for (int v = 0; v < TB / 8; ++v) xv[v] = *reinterpret_cast<const v8*>(xr + 8 * v);
+                        for (int r = 0; r < CB; ++r) {
+                            const float wv = wr[r][(size_t)ci * K + j];
+                            for (int v = 0; v < TB / 8; ++v) a[r][v] += wv * xv[v];
+                        }
                     }
                 }
+                for (int r = 0; r < nco; ++r)
+                    for (int v = 0; v < TB / 8; ++v) *reinterpret_cast<v8*>(y + (size_t)(co0 + r) * y_stride + t0 + tb + 8 * v) = a[r][v];
             }
-            for (int r = 0; r < nco; ++r) std::memcpy(y + (size_t)(co0 + r) * y_stride + t0, acc.data() + (size_t)r * TT, sizeof(float) * nt);
+            for (; tb < nt; ++tb) {  // scalar tail
+                for (int r = 0; r < nco; ++r) {
+                    float a = bv[r];
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int j = 0; j < K; ++j) a += wr[r][(size_t)ci * K + j] * xp[(size_t)ci * Tp + t0 + tb + j * dil];
+                    y[(size_t)(co0 + r) * y_stride + t0 + tb] = a;
+                }
+            }
         }
     });
 }

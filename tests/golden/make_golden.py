@@ -38,44 +38,7 @@ def load_package():
     return mod
 
 
-# ---- test-side parser of the model format (third, independent implementation; numpy only) -------------
-def parse_model_file(data):
-    off = 0
-
-    def u32():
-        nonlocal off
-        (v,) = struct.unpack_from("<I", data, off)
-        off += 4
-        return v
-
-    def s():
-        nonlocal off
-        n = u32()
-        v = data[off:off + n].decode("utf-8")
-        off += n
-        return v
-
-    vocab = {}
-    for _ in range(u32()):
-        k = s()
-        vocab[k] = u32()
-    add_blank, normalize = u32(), u32()
-    pad, unk = s(), s()
-    cfg = {}
-    for _ in range(u32()):
-        k = s()
-        cfg[k] = s()
-    tensors = {}
-    for _ in range(u32()):
-        name = s()
-        dt, rank = u32(), u32()
-        ne = [u32() for _ in range(rank)]
-        nb = u32()
-        arr = np.frombuffer(data, dtype=np.float32 if dt == 0 else np.float16, count=nb // (4 if dt == 0 else 2), offset=off)
-        off += nb
-        tensors[name] = (arr.reshape(ne[::-1]).copy(), dt)
-    assert off == len(data)
-    return dict(vocab=vocab, add_blank=add_blank, normalize=normalize, pad=pad, unk=unk, config=cfg, tensors=tensors)
+from modelfile_py import parse_model_file  # noqa: E402  (tests/modelfile_py.py)
 
 
 def config_from_strings(cfg):

@@ -1,0 +1,60 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/vits.h declares, and fails loudly
+(no CPU fallback) when there is no GPU. No compute calls here."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "vits.h")).read()
+    return sorted(set(re.findall(r"VITS_API\s+[\w\s\*]+?\b(vits_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = _declared()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in include/vits.h but not exported"
+    assert sorted(pkg.EXPORTED_SYMBOLS) == declared
+
+
+def test_reference_five_symbols_present(pkg):
+    # /root/reference/src/include/vits.h:94-102
+    for name in ["vits_model_load_from_bytes", "vits_model_load_from_file", "vits_free_model", "vits_free_result", "vits_model_process"]:
+        assert hasattr(pkg.lib(), name)
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback(pkg, tiny_bytes):
+    try:
+        pkg.device_info()
+        has_gpu = True
+    except pkg.VitsError:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.VitsError, match="no HIP device"):
+        pkg.Model(tiny_bytes)
+
+
+def test_bad_inputs_return_null_with_message(pkg):
+    L = pkg.lib()
+    assert not L.vits_model_load_from_bytes(b"\x01\x00\x00\x00", 4)
+    assert "truncated" in pkg.last_error()
+    assert not L.vits_model_load_from_file(b"/nonexistent/model.ggml")
+    assert "failed to open file" in pkg.last_error()  # message of the reference (vits_model_data.cpp:102)
+
+
+def test_product_does_not_link_or_load_the_oracle(pkg):
+    import subprocess
+    out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    src_dir = os.path.join(ROOT, "vits.cpp_amd")
+    for dirpath, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".py")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "vits_oracle" not in text and "oracle_lib" not in text, f

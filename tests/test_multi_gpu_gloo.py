@@ -1,0 +1,77 @@
+"""world_size-2 test of the N>1 path on CPU (gloo): utterance sharding and the ragged all-gather of PCM that bench.py
+uses over RCCL. No GPU, no product compute: the PCM rows are synthetic."""
+import importlib.util
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_multi_gpu():
+    spec = importlib.util.spec_from_file_location("vits_multi_gpu", os.path.join(ROOT, "vits.cpp_amd", "multi_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _fake_pcm(utt, length, cap):
+    row = torch.zeros(cap)
+    row[:length] = torch.arange(length, dtype=torch.float32) * 1e-3 + utt
+    return row
+
+
+def _worker(rank, world, port, total, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = _load_multi_gpu()
+    lo, hi = mg.shard_range(total, world, rank)
+    lengths = torch.tensor([100 + 37 * u for u in range(lo, hi)], dtype=torch.int64)
+    pcm = torch.stack([_fake_pcm(u, int(lengths[i]), cap) for i, u in enumerate(range(lo, hi))])
+    out, all_len = mg.gather_pcm(pcm, lengths)
+    q.put((rank, out.numpy().copy(), all_len.numpy().copy()))  # numpy: pickled by value (torch tensors travel as fds)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_everything():
+    mg = _load_multi_gpu()
+    for total in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [mg.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(120)
+def test_ragged_pcm_all_gather_world2():
+    world, total, cap = 2, 8, 1024
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    want_len = torch.tensor([100 + 37 * u for u in range(total)], dtype=torch.int64)
+    smax = int(want_len.max())
+    for rank, out, all_len in results:
+        out, all_len = torch.from_numpy(out), torch.from_numpy(all_len)
+        assert torch.equal(all_len, want_len)
+        assert out.shape == (total, smax)
+        for u in range(total):
+            assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap)[: want_len[u]])
+            assert float(out[u, want_len[u]:].abs().sum()) == 0.0

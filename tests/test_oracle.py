@@ -1,0 +1,203 @@
+"""CPU tests that PIN THE ORACLE (no GPU): golden taps from transformers.VitsModel, the reference exporter's own
+file, the reference's helper-op known-answer vectors and its libstdc++ noise stream."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+from modelfile_py import parse_model_file
+
+FLOAT_TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "z_p", "z_flow", "pre_tanh", "waveform"]
+
+
+def _bytes_for(name, pkg, tiny_hf_bytes):
+    if name == "tiny_hf_export_taps.npz":
+        return tiny_hf_bytes
+    return pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY if name.startswith("tiny") else pkg.SYNTH_FULL)
+
+
+@pytest.mark.parametrize("fixture", ["tiny_hf_export_taps.npz", "tiny_synth_taps.npz", "full_synth_taps.npz"])
+def test_oracle_hf_mode_reproduces_transformers_taps(pkg, oracle, tiny_hf_bytes, fixture):
+    """oracle(VO_MODE_HF) == transformers.VitsModel stage by stage (<= 1e-4 of each tap's RMS; durations exact).
+    tiny_hf_export.ggml was written by the REFERENCE'S OWN exporter (scripts/export_vits.py), so this also pins the reader."""
+    g = golden(fixture)
+    m = oracle.Model(_bytes_for(fixture, pkg, tiny_hf_bytes))
+    r = m.process_ids(g["ids"], mode=oracle.MODE_HF, noise_kind=oracle.NOISE_EXPLICIT, noise_dur=g["noise_dur"], noise_prior=g["noise_prior"])
+    np.testing.assert_array_equal(r["durations"], g["durations"].ravel())
+    for name in FLOAT_TAPS:
+        assert rel_err(r[name], g[name]) < 1e-4, name
+
+
+def test_readers_agree_with_reference_exporter_file(pkg, oracle, tiny_hf_bytes):
+    """Three readers (product C++, oracle C++, numpy) on the file the reference's exporter wrote."""
+    py = parse_model_file(tiny_hf_bytes)
+    om = oracle.Model(tiny_hf_bytes)
+    assert om.num_tensors() == len(py["tensors"]) == 314
+    for name, (arr, dt) in py["tensors"].items():
+        t, odt = om.tensor(name)
+        assert odt == dt and t.shape == arr.shape
+        np.testing.assert_array_equal(t, arr.astype(np.float32))  # fp16 -> fp32 widening is exact
+    assert om.config("hidden_size") == py["config"]["hidden_size"] == "16"
+    assert om.config("upsample_rates") == "[4, 2]"
+    # export_vits.py:79-88 stores every Conv1d / ConvTranspose1d weight as fp16, everything else fp32
+    assert py["tensors"]["decoder.upsampler.0.weight"][1] == 1 and py["tensors"]["text_encoder.embed_tokens.weight"][1] == 0
+    assert py["tensors"]["decoder.upsampler.0.weight"][0].shape == (32, 16, 8)  # torch ConvTranspose1d [Cin][Cout][K]
+    # product reader + writer: byte-exact round trip of the reference's format
+    assert pkg.reserialize(tiny_hf_bytes) == tiny_hf_bytes
+
+
+def test_synthetic_model_is_deterministic_and_well_formed(pkg, oracle):
+    a = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)
+    b = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)
+    c = pkg.synth_model_bytes(0x5EEE, pkg.SYNTH_TINY)
+    assert a == b and a != c
+    assert pkg.reserialize(a) == a
+    py = parse_model_file(a)
+    assert py["add_blank"] == 1 and py["pad"] == "<pad>" and len(py["vocab"]) == 38
+    w, dt = py["tensors"]["flow.flows.0.wavenet.in_layers.0.weight"]
+    assert dt == 1 and w.shape == (32, 16, 5)
+
+
+def test_reference_mode_applies_the_documented_deviations(pkg, oracle):
+    """VO_MODE_REFERENCE vs VO_MODE_HF on the same inputs: encoder identical, durations differ through Q3-Q5, the vocoder
+    output has the uncropped length S = 256 L + 294 (Q1, vits.cpp:187)."""
+    m = oracle.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL))
+    ids = pkg.synth_ids(1, 10)[0]
+    hf = m.process_ids(ids, mode=oracle.MODE_HF, noise_seed=3)
+    rf = m.process_ids(ids, mode=oracle.MODE_REFERENCE, noise_seed=3)
+    np.testing.assert_array_equal(hf["enc_out"], rf["enc_out"])
+    assert not np.allclose(hf["log_duration"], rf["log_duration"])
+    L_hf, L_rf = int(hf["durations"].sum()), int(rf["durations"].sum())
+    assert hf["waveform"].size == 256 * L_hf
+    assert rf["waveform"].size == 256 * L_rf + 294
+    # pinned durations: identical latents, so the two vocoders differ only by Q1/Q2
+    hf2 = m.process_ids(ids, mode=oracle.MODE_HF, noise_seed=3, fixed_duration=2)
+    rf2 = m.process_ids(ids, mode=oracle.MODE_REFERENCE, noise_seed=3, fixed_duration=2)
+    np.testing.assert_array_equal(hf2["z_flow"], rf2["z_flow"])
+    assert rf2["waveform"].size - hf2["waveform"].size == 294
+
+
+def test_reference_noise_stream_known_answer(oracle):
+    """libstdc++ default_random_engine (minstd_rand0, seed 1) + normal_distribution<float>: the stream the reference draws
+    from (vits.cpp:31, ggml-util.h:187-199). Known answer: SURVEY.md §8c (g++ 11.4)."""
+    first = oracle.reference_noise(8, seed=1)
+    expect = np.array([-0.259093195, 1.60159206, -1.49896121, 0.174767554, 0.119264036, -0.302023172, 0.458181173, 0.188984558], np.float32)
+    np.testing.assert_allclose(first, expect, rtol=0, atol=1e-7)
+    again = oracle.reference_noise(8)  # never reseeded: the stream continues
+    assert not np.allclose(first, again)
+
+
+def test_tokenizer_lowercases_matches_vocab_and_intersperses_blanks(pkg, oracle, tiny_bytes):
+    m = oracle.Model(tiny_bytes)
+    ids = m.tokenize("Hi, a-b!")  # ',' and '!' are not in the vocabulary and are dropped (vits_tokenizer.cpp:72-75)
+    vocab = parse_model_file(tiny_bytes)["vocab"]
+    want = [vocab[c] for c in "hi a-b"]
+    assert list(ids[1::2]) == want and set(ids[0::2]) == {vocab["<pad>"]} and len(ids) == 2 * len(want) + 1
+    np.testing.assert_array_equal(pkg.file_tokenize(tiny_bytes, "Hi, a-b!"), ids)  # product tokenizer (host only)
+
+
+# ---- the reference's helper-op known-answer vectors (test/test_ggml_utils.cpp:458-606) -------------------------
+import ctypes as C  # noqa: E402
+
+
+def _i64(*v):
+    return (C.c_int64 * len(v))(*v)
+
+
+def _i32(*v):
+    return (C.c_int32 * len(v))(*v)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+INPUT = np.array([1, 2, 3, 4, 5, 6], np.float32)  # ne = [3, 2, 1]
+
+
+@pytest.mark.parametrize("pads,expected,shape", [
+    ((0, 0, 0, 0, 0, 0), [1, 2, 3, 4, 5, 6], (3, 2, 1)),
+    ((0, 0, 0, 2, 0, 0), [1, 2, 3, 4, 5, 6, 0, 0, 0, 0, 0, 0], (3, 4, 1)),
+    ((0, 0, 2, 0, 0, 0), [0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6], (3, 4, 1)),
+    ((0, 0, 2, 1, 0, 0), [0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 0, 0, 0], (3, 5, 1)),
+    ((0, 0, 0, 0, 0, 2), [1, 2, 3, 0, 0, 4, 5, 6, 0, 0], (5, 2, 1)),
+    ((0, 0, 0, 0, 3, 0), [0, 0, 0, 1, 2, 3, 0, 0, 0, 4, 5, 6], (6, 2, 1)),
+    ((1, 0, 0, 0, 0, 0), [0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6], (3, 2, 2)),
+    ((0, 1, 0, 0, 0, 0), [1, 2, 3, 4, 5, 6, 0, 0, 0, 0, 0, 0], (3, 2, 2)),
+])
+def test_kat_pad_3d(oracle, pads, expected, shape):  # test_ggml_utils.cpp:458-465
+    out = np.zeros(len(expected), np.float32)
+    one = _i64(0, 0, 0)
+    oracle.lib().vo_pad_3d(_p(INPUT), _i64(3, 2, 1), _i32(*pads), _p(out), one)
+    assert tuple(one) == shape and out.tolist() == expected
+
+
+@pytest.mark.parametrize("src,ne,se,expected,shape", [
+    (INPUT, (3, 2, 1), (0, -1, 0, -1, 0, -1), [1, 2, 3, 4, 5, 6], (3, 2, 1)),
+    (INPUT, (3, 2, 1), (0, -1, 0, -1, 0, 1), [1, 2, 3, 4, 5, 6], (3, 2, 1)),
+    (INPUT, (3, 2, 1), (0, -1, 0, 1, 0, -1), [1, 2, 3], (3, 1, 1)),
+    (INPUT, (3, 2, 1), (0, -1, 1, -1, 0, -1), [4, 5, 6], (3, 1, 1)),
+    (INPUT, (3, 2, 1), (0, 2, 0, -1, 0, -1), [1, 2, 4, 5], (2, 2, 1)),
+    (INPUT, (3, 2, 1), (2, -1, 0, -1, 0, -1), [3, 6], (1, 2, 1)),
+    (np.arange(1, 17, dtype=np.float32), (2, 4, 2), (0, -1, 0, 1, 0, -1), [1, 2, 9, 10], (2, 1, 2)),
+    (np.arange(1, 17, dtype=np.float32), (2, 4, 2), (0, -1, 1, 2, 0, -1), [3, 4, 11, 12], (2, 1, 2)),
+    (np.arange(1, 17, dtype=np.float32), (2, 4, 2), (0, -1, 2, 3, 0, -1), [5, 6, 13, 14], (2, 1, 2)),
+    (np.arange(1, 17, dtype=np.float32), (2, 4, 2), (0, -1, 3, 4, 0, -1), [7, 8, 15, 16], (2, 1, 2)),
+])
+def test_kat_slice_3d(oracle, src, ne, se, expected, shape):  # test_ggml_utils.cpp:469-485 (split :489-491 is two slices)
+    out = np.zeros(len(expected), np.float32)
+    one = _i64(0, 0, 0)
+    oracle.lib().vo_slice_3d(_p(src), _i64(*ne), _i32(*se), _p(out), one)
+    assert tuple(one) == shape and out.tolist() == expected
+
+
+def test_kat_flip_concat_compare_cumsum_max_not(oracle):
+    L = oracle.lib()
+    out = np.zeros(6, np.float32)
+    L.vo_flip_3d(_p(INPUT), _i64(3, 2, 1), 0, _p(out))  # :494
+    assert out.tolist() == [3, 2, 1, 6, 5, 4]
+    L.vo_flip_3d(_p(INPUT), _i64(3, 2, 1), 1, _p(out))  # :495
+    assert out.tolist() == [4, 5, 6, 1, 2, 3]
+    a, b = np.array([1, 2, 3], np.float32), np.array([1, 7, 8], np.float32)
+    one = _i64(0, 0, 0)
+    L.vo_concat_3d(_p(b), _i64(3, 1, 1), _p(a), _i64(3, 1, 1), 1, _p(out), one)  # :500
+    assert out.tolist() == [1, 7, 8, 1, 2, 3] and tuple(one) == (3, 2, 1)
+    L.vo_concat_3d(_p(b), _i64(3, 1, 1), _p(a), _i64(3, 1, 1), 0, _p(out), one)  # :502
+    assert out.tolist() == [1, 7, 8, 1, 2, 3] and tuple(one) == (6, 1, 1)
+    o3 = np.zeros(3, np.float32)
+    L.vo_compare(_p(a), _p(b), 3, 0, _p(o3))  # a < b  :514
+    assert o3.tolist() == [0, 1, 1]
+    L.vo_compare(_p(a), _p(b), 3, 1, _p(o3))  # a >= b :516
+    assert o3.tolist() == [1, 0, 0]
+    L.vo_per_row_cumsum(_p(a), _i64(3, 1, 1), _p(o3))  # :532-533
+    assert o3.tolist() == [1, 3, 6]
+    c = np.array([6, 2, 3, 8, 4, 2], np.float32)
+    assert L.vo_max(_p(c), 6) == 8.0  # :535-536
+    n = np.array([0, 1, 0, 1, 0, 0], np.float32)
+    L.vo_binary_not(_p(n), 6, _p(out))  # :538
+    assert out.tolist() == [1, 0, 1, 0, 1, 1]
+
+
+def test_kat_index_put_add_masked_set_arange(oracle):
+    L = oracle.lib()
+    for index, value, expected in [(0, 10, [10, 2, 3, 10, 5, 6]), (2, 10, [1, 2, 10, 4, 5, 10]), (1, 5, [1, 5, 3, 4, 5, 6])]:  # :540-565
+        t = INPUT.copy()
+        L.vo_index_put_last_dim(_p(t), _i64(3, 2, 1), index, C.c_float(value))
+        assert t.tolist() == expected
+    t = INPUT.copy()
+    L.vo_index_add_last_dim(_p(t), _i64(3, 2, 1), 1, C.c_float(9))  # :568-575
+    assert t.tolist() == [1, 11, 3, 4, 14, 6]
+    # Q4: index -1 wraps to "one float before each row" (ggml-util.h:235-236): row r's write lands on row r-1's last
+    # element, the last row's own last element is never written (and row 0's write is out of bounds, dropped here)
+    t = INPUT.copy()
+    L.vo_index_put_last_dim(_p(t), _i64(3, 2, 1), -1, C.c_float(10))
+    assert t.tolist() == [1, 2, 10, 4, 5, 6]
+    mask = np.array([0, 1, 0, 1, 1, 0], np.float32)
+    vals = np.full(6, 10, np.float32)
+    out = np.zeros(6, np.float32)
+    L.vo_masked_set(_p(INPUT), _p(mask), _p(vals), 6, _p(out))  # :577-583
+    assert out.tolist() == [1, 10, 3, 10, 10, 6]
+    o3 = np.zeros(6, np.float32)
+    assert L.vo_masked_get_compact(_p(INPUT), _p(mask), 6, _p(o3)) == 3 and o3[:3].tolist() == [2, 4, 5]  # :585-590
+    ar = np.zeros(6, np.float32)
+    L.vo_arange(6, _p(ar))  # :600-605
+    assert ar.tolist() == [0, 1, 2, 3, 4, 5]

@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [
     "vits_model_sync", "vits_model_tokenize", "vits_model_sampling_rate", "vits_model_vocab_size",
     "vits_model_weight_bytes", "vits_model_get_tap", "vits_synth_model_bytes", "vits_free_bytes",
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
-    "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device",
+    "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
+    "vits_model_file_tokenize",
 ]
 
 
@@ -130,6 +131,10 @@ def lib():
     L.vits_op_rel_attention.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.vits_op_add_layer_norm.restype = i32
     L.vits_op_add_layer_norm.argtypes = [i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, vp]
+    L.vits_model_file_reserialize.restype = i32
+    L.vits_model_file_reserialize.argtypes = [C.c_char_p, sz, C.POINTER(C.c_void_p), C.POINTER(sz)]
+    L.vits_model_file_tokenize.restype = i64
+    L.vits_model_file_tokenize.argtypes = [C.c_char_p, sz, C.c_char_p, vp, sz]
     L.vits_set_device.restype = i32
     L.vits_set_device.argtypes = [i32]
     L.vits_device_info.restype = i32
@@ -163,6 +168,25 @@ def synth_model_bytes(seed=0x5EED, arch=SYNTH_FULL):
         return C.string_at(p, n.value)
     finally:
         lib().vits_free_bytes(p)
+
+
+def reserialize(data):
+    """parse + write back a model file (host only)"""
+    p, n = C.c_void_p(), C.c_size_t()
+    if lib().vits_model_file_reserialize(data, len(data), C.byref(p), C.byref(n)) != 0:
+        raise VitsError(last_error())
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().vits_free_bytes(p)
+
+
+def file_tokenize(data, text):
+    buf = np.zeros(4 * len(text.encode("utf-8")) + 8, np.int32)
+    n = lib().vits_model_file_tokenize(data, len(data), text.encode("utf-8"), _ptr(buf), buf.size)
+    if n < 0:
+        raise VitsError(last_error())
+    return buf[:n].copy()
 
 
 def synth_ids(batch, n_ids, vocab=38, ids_seed=1234):

@@ -211,6 +211,40 @@ VITS_API int vits_synth_model_bytes(uint64_t seed, int32_t arch, char** bytes, s
 }
 VITS_API void vits_free_bytes(char* bytes) { delete[] bytes; }
 
+VITS_API int vits_model_file_reserialize(const char* in, size_t in_size, char** out, size_t* out_size) {
+    VITS_TRY
+    if (!in || !out || !out_size) return -1;
+    vits::ModelFile f;
+    std::string err;
+    if (!f.parse(reinterpret_cast<const uint8_t*>(in), in_size, err)) {
+        set_err(err);
+        return -1;
+    }
+    std::vector<uint8_t> v = f.serialize();
+    *out = new char[v.size()];
+    std::memcpy(*out, v.data(), v.size());
+    *out_size = v.size();
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int64_t vits_model_file_tokenize(const char* model_bytes, size_t size, const char* text, int32_t* ids, size_t cap) {
+    VITS_TRY
+    if (!model_bytes || !text) return -1;
+    vits::ModelFile f;
+    std::string err;
+    if (!f.parse(reinterpret_cast<const uint8_t*>(model_bytes), size, err)) {
+        set_err(err);
+        return -1;
+    }
+    vits::Tokenizer t;
+    t.init(f);
+    std::vector<int32_t> v = t.tokenize(text);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) ids[i] = v[i];
+    return (int64_t)v.size();
+    VITS_CATCH(-1)
+}
+
 VITS_API int vits_prof_enable(vits_model* model, int32_t on) {
     if (!model) return -1;
     model->eng.prof.on = on != 0;
