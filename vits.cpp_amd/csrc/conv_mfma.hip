@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -162,41 +163,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     };
 
     static_assert(!DB || DIL != 0, "double buffering needs a compile-time row stride");
-    if constexpr (DB) {
-        // ---- double-buffered LDS, register-staged: the global loads of chunk c+1 are issued BEFORE the MFMA work of
-        // chunk c and written to the other LDS buffer AFTER it, so HBM latency hides under the matrix pipe and one
-        // barrier per chunk suffices. One wave per row group (rows wid, wid+4, ...), lanes along time (coalesced).
-        constexpr int XWC = BN + SPAN_C;
-        constexpr int NM = (XWC + 63) / 64;
-        constexpr int NK = CK / 4;
-        float st[NK][NM];
-        auto stage_load = [&](int c) __attribute__((always_inline)) {
+    // ---- staging: global -> registers -> LDS. One wave per row group (rows wid, wid+4, ...), lanes along time
+    // (coalesced 256 B). Loads are BRANCH-FREE (clamped address + select), so all NK*NM loads of a chunk are in flight
+    // together; with a per-element bounds branch hipcc serialises them (one HBM latency each).
+    constexpr int NM = DIL != 0 ? (BN + SPAN_C + 63) / 64 : BN / 64 + 1;  // 64-column groups per row (generic: span <= 64)
+    constexpr int NK = CK / 4;
+    float st[NK][NM];
+    auto stage_load = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int ch = c * CK + wid + 4 * k;
-                const bool chok = ch < p.cin;
-                // branch-free: always load from a clamped (valid) address, then select zero for padding positions
-                const float* __restrict__ src = xb + (int64_t)(chok ? ch : p.cin - 1) * p.x_cs;
+        for (int k = 0; k < NK; ++k) {
+            const int ch = c * CK + wid + 4 * k;
+            const bool chok = ch < p.cin;
+            const float* __restrict__ src = xb + (int64_t)(chok ? ch : p.cin - 1) * p.x_cs;
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int t = tile_start + lane + 64 * m;
-                    const int tc = t < 0 ? 0 : (t < len_in ? t : len_in - 1);
-                    const float v = src[tc];
-                    st[k][m] = (chok && t == tc) ? v : 0.f;
-                }
+            for (int m = 0; m < NM; ++m) {
+                const int t = tile_start + lane + 64 * m;
+                const int tc = t < 0 ? 0 : (t < len_in ? t : len_in - 1);
+                const float v = src[tc];
+                st[k][m] = (chok && t == tc) ? v : 0.f;
             }
-        };
-        auto stage_store = [&](int buf) __attribute__((always_inline)) {
-            float* dst = xs + buf * (CK * XWC) + wid * XWC + lane;
+        }
+    };
+    auto stage_store = [&](int buf) __attribute__((always_inline)) {
+        float* dst = xs + buf * (CK * xw) + wid * xw + lane;
 #pragma unroll
-            for (int k = 0; k < NK; ++k)
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    float v = st[k][m];
-                    if (p.pre_act) v = v > 0.f ? v : v * p.slope;
-                    if (NM * 64 == XWC || lane + 64 * m < XWC) dst[(4 * k) * XWC + 64 * m] = v;
-                }
-        };
+            for (int m = 0; m < NM; ++m) {
+                float v = st[k][m];
+                if (p.pre_act) v = v > 0.f ? v : v * p.slope;
+                if (lane + 64 * m < xw) dst[(4 * k) * xw + 64 * m] = v;
+            }
+    };
+    if constexpr (DB) {
+        // double-buffered LDS: the global loads of chunk c+1 are issued BEFORE the MFMA work of chunk c and written to
+        // the other LDS buffer AFTER it, so HBM latency hides under the matrix pipe and one barrier per chunk suffices
         stage_load(0);
         stage_store(0);
         __syncthreads();
@@ -204,31 +205,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             const bool more = c + 1 < p.nchunks;
             if (more) stage_load(c + 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute_chunk(xrow0 + (c & 1) * (CK * XWC));
+            compute_chunk(xrow0 + (c & 1) * (CK * xw));
             __builtin_amdgcn_sched_barrier(0);
             if (more) stage_store((c + 1) & 1);
             __syncthreads();
         }
     } else {
+        // single LDS buffer (few chunks: nothing to overlap inside the block; other resident blocks hide the latency)
+        stage_load(0);
         for (int c = 0; c < p.nchunks; ++c) {
-            __syncthreads();  // everyone finished reading the previous chunk
-            // ---- stage CK x xw input tile: masked, pre-activated; one wave per row, lanes along time (coalesced)
-            for (int r = wid; r < CK; r += 4) {
-                const int ch = c * CK + r;
-                const float* __restrict__ src = xb + (int64_t)ch * p.x_cs;
-                float* dst = xs + r * xw;
-                const bool chok = ch < p.cin;
-                for (int i = lane; i < xw; i += 64) {
-                    const int t = tile_start + i;
-                    float v = 0.f;
-                    if (chok && t >= 0 && t < len_in) {
-                        v = src[t];
-                        if (p.pre_act) v = v > 0.f ? v : v * p.slope;
-                    }
-                    dst[i] = v;
-                }
-            }
+            if (c > 0) __syncthreads();  // everyone finished reading the previous chunk
+            stage_store(0);
             __syncthreads();
+            if (c + 1 < p.nchunks) stage_load(c + 1);  // in flight during the MFMA work
+            __builtin_amdgcn_sched_barrier(0);
             compute_chunk(xrow0);
         }
     }
@@ -320,7 +310,10 @@ static TileShape tile_shape(int tile) {
 }
 
 int choose_conv_tile(int rows, int epi, int t_hint) {
-    const bool small_t = t_hint <= 128;
+    // rows <= 64 (few MFMAs per staged tile): 128-column tiles -> twice as many independent blocks per CU keep more
+    // loads in flight (measured 120.5 -> 116.4 ms per step); VITS_NARROW_TILES=0 restores 256-column tiles
+    static const int narrow = getenv("VITS_NARROW_TILES") ? atoi(getenv("VITS_NARROW_TILES")) : 64;
+    const bool small_t = t_hint <= 128 || (narrow && rows <= narrow);
     if (epi == EPI_GATE) return small_t ? TILE_64x64 : TILE_64x256;
     if (rows % 128 == 0) return TILE_128x128;
     if (rows % 64 == 0) return small_t ? TILE_64x64 : TILE_64x256;
@@ -464,6 +457,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.lds_off = span < 0 ? -span : 0;
     p.xw = bn + (span < 0 ? -span : span);
     if ((size_t)2 * CK * p.xw * 4 > 160 * 1024) return hipErrorInvalidValue;
+    if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
     const bool db = w.nchunks >= 4;  // double-buffer only when there is a next chunk worth prefetching
