@@ -430,12 +430,13 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
 // ---- forward ------------------------------------------------------------------------------------------------
 hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c) {
     if (prof.on) {
-        // name = label|k<taps>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
+        // name = label|k<taps>|d<dilation>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
         // bench can line entries up with rocprofv3's per-kernel-name statistics
         const int ncols = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
         const int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols);
         char full[160];
-        std::snprintf(full, sizeof(full), "%s|k%d|t%d|e%d|c%dx%d", name, w.kt, tile, w.epi, w.cin, w.cout);
+        std::snprintf(full, sizeof(full), "%s|k%d|d%d|t%d|e%d|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, w.cin,
+                      w.cout);
         const int64_t cols = (int64_t)c.batch * (w.epi == EPI_CONVT ? c.t_in : c.t_out);
         // algorithmic bytes: input read once, output written once, residual/accumulator read once, weights once
         double bytes = 4.0 * ((double)c.batch * w.cin * c.t_in + (double)c.batch * w.cout * c.t_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0))) +
