@@ -443,7 +443,19 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.ct_stride = w.ct_stride;
     p.ct_crop = c.ct_crop;
     int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
-    const int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
+    int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
+    if (c.tile < 0 && w.epi != EPI_GATE) {
+        // small grids (batch 1, short inputs): fewer than ~2 blocks per CU leaves matrix pipes idle -> step down to
+        // smaller tiles until the launch has >= 512 blocks (latency case, BASELINE.json config 2)
+        auto blocks = [&](int tl) {
+            const TileShape t2 = tile_shape(tl);
+            const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
+            const int64_t mb = (w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
+            return nb * mb * c.batch;
+        };
+        if (blocks(tile) < 512 && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
+        if (blocks(tile) < 512 && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
+    }
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     if (w.epi == EPI_CONVT) {
