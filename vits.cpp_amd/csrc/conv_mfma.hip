@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             for (int p4 = 0; p4 < 4; ++p4) {
                 {
                     const int nstep = gstep + 2 < total_steps ? gstep + 2 : total_steps - 1;  // clamp: stays in bounds
+#ifndef VAR_NOA
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = wq[(size_t)mr * tile4 + (size_t)nstep * 64];
+#endif
                 }
                 // pin the prefetch at the top of the step: hipcc otherwise sinks the loads next to their first use
                 // (vmcnt wait right behind the issue) and the L2 latency lands between MFMAs
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                         // reads a few floats past the row: still inside the tile, value unused)
                         const int pair = p4 * 4 + q;
                         const float* nx = pair + 1 < CK / 2 ? xj + (2 * (pair + 1)) * xw : xj + dil;
+#ifndef VAR_NOB
 #pragma unroll
                         for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = nx[nr * 32];
+#endif
                     }
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) {
@@ -170,6 +174,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NK = CK / 4;
     float st[NK][NM];
     auto stage_load = [&](int c) __attribute__((always_inline)) {
+#ifdef VAR_NOSTAGE
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int ch = c * CK + wid + 4 * k;
@@ -185,6 +192,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         }
     };
     auto stage_store = [&](int buf) __attribute__((always_inline)) {
+#ifdef VAR_NOSTAGE
+        return;
+#endif
         float* dst = xs + buf * (CK * xw) + wid * xw + lane;
 #pragma unroll
         for (int k = 0; k < NK; ++k)
@@ -478,6 +488,9 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
         if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
         return launch_tile<K, D, false, E>(w, tile, p, ncols_max, batch, s);                 \
     } while (0)
+#ifdef VITS_MICRO_KT  // developer microbenchmark (tools/conv_micro.hip): instantiate a single (taps, dilation) pair
+    VITS_GO(VITS_MICRO_KT, VITS_MICRO_DIL, EPI_STD);
+#else
     if (w.epi == EPI_CONVT) {
         if (w.kt == 2) VITS_GO(2, -1, EPI_CONVT);
         return hipErrorInvalidValue;
@@ -509,6 +522,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
             VITS_GO(11, 0, EPI_STD);
         default: break;
     }
+#endif
 #undef VITS_GO
     return hipErrorInvalidValue;
 }
