@@ -65,9 +65,15 @@ struct ConvParams {
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
 // immediates of the ds_read instructions (one base VGPR instead of one per tap). DIL == 0: run-time dilation (generic).
-// DB: double-buffered LDS with register-staged loads (pays when there are several chunks: cin >= 128).
+// DB: wave-specialised double buffering (used when there are several chunks: cin >= 128). The block has FIVE waves:
+//     waves 0-3 only run MFMAs (their only global loads are the L2-resident weight fragments), wave 4 is a PRODUCER that
+//     streams the next 32-channel input tile from HBM straight into the other LDS buffer with LDS-DMA
+//     (global_load_lds_dword: no data VGPRs, no ds_write pass). Reason: vmcnt retires in order, so a compute wave that
+//     issues HBM tile loads itself makes every later weight load wait a full HBM latency (measured: k=3 72 -> 103
+//     TFLOP/s without those stalls). LeakyReLU moves to the B-operand read (max(x, slope*x)), zero padding at the
+//     sequence ends is done by a masked register path in the producer (boundary tiles only).
 template <int KT, int DIL, bool DB, int WM, int WN, int MR, int NR, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = WN * NR * 32;
     constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
     constexpr int STEPS = KT * (CK / 8);  // float4 A-fragments (4 MFMA k-steps each) per chunk and row tile
@@ -85,11 +91,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     if (t0 >= ncols) return;
 
     const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
-    const int xw = DIL != 0 ? BN + SPAN_C : p.xw;
+    constexpr int XWP = (BN + SPAN_C + 63) / 64 * 64;  // DB: rows padded to whole 64-float DMA pieces
+    const int xw = DB ? XWP : (DIL != 0 ? BN + SPAN_C : p.xw);
     const int dil = DIL != 0 ? DIL : p.dil;
     const int lds_off = DIL != 0 ? (DIL < 0 ? SPAN_C : 0) : p.lds_off;
     const int tile_start = t0 - p.pad_l - lds_off;  // global time of LDS column 0
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+
+    if constexpr (DB) {
+        if (wid == 4) {
+            // ------------------------------- producer wave -------------------------------------------------------
+            // barrier protocol (n = nchunks, both sides execute n+1 barriers):
+            //   producer: fill(0); B0; for c: { fill(c+1) into buffer (c+1)&1; B(c+1) }
+            //   compute : B0; for c: { MFMA on buffer c&1; B(c+1) }
+            // buffer (c+1)&1 was last read during chunk c-1, which every compute wave finished before B(c).
+            const bool interior = tile_start >= 0 && tile_start + XWP <= len_in;
+            constexpr int NMP = XWP / 64;
+            // per-lane clamped time offsets of the NMP 64-column pieces of a row (same for every row and chunk)
+            int tcl[NMP];
+            bool oob[NMP];
+#pragma unroll
+            for (int m = 0; m < NMP; ++m) {
+                const int t = tile_start + lane + 64 * m;
+                tcl[m] = t < 0 ? 0 : (t < len_in ? t : len_in - 1);
+                oob[m] = t != tcl[m];
+            }
+            auto fill = [&](int c) __attribute__((always_inline)) {
+                float* lbase = xs + (c & 1) * (CK * XWP);
+                // LDS-DMA of the whole 32 x XWP tile from clamped (always valid) addresses ...
+#pragma unroll 4
+                for (int r = 0; r < CK; ++r) {
+                    const int ch = c * CK + r;
+                    const float* src = xb + (int64_t)(ch < p.cin ? ch : p.cin - 1) * p.x_cs;
+#pragma unroll
+                    for (int m = 0; m < NMP; ++m)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tcl[m]),
+                                                         (__attribute__((address_space(3))) void*)(lbase + r * XWP + 64 * m), 4, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ... then zero what lies outside the sequence (boundary tiles) or beyond the last input channel
+                if (!interior || (c + 1) * CK > p.cin) {
+#pragma unroll 4
+                    for (int r = 0; r < CK; ++r) {
+                        const bool chbad = c * CK + r >= p.cin;
+#pragma unroll
+                        for (int m = 0; m < NMP; ++m)
+                            if (oob[m] || chbad) lbase[r * XWP + 64 * m + lane] = 0.f;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            };
+            fill(0);
+            __syncthreads();
+            for (int c = 0; c < p.nchunks; ++c) {
+                if (c + 1 < p.nchunks) fill(c + 1);
+                __syncthreads();
+            }
+            return;
+        }
+    }
 
     floatx16 acc[MR][NR];
 #pragma unroll
@@ -99,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const float slope_eff = p.pre_act ? p.slope : 1.0f;  // DB: leaky_relu(x) = max(x, slope*x) applied at the B-operand read
     const int krow = lane >> 5;
     const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off;  // B operand base of this lane
     const size_t tile4 = (size_t)p.nchunks * STEPS * 64;                           // float4 per 32-row tile
@@ -141,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 for (int q = 0; q < 4; ++q) {
                     float b_cur[NR];
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
+                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = DB ? fmaxf(b_nxt[nr], b_nxt[nr] * slope_eff) : b_nxt[nr];
                     {
                         // next k-step: next channel pair of this tap, or pair 0 of the next tap (after the last tap this
                         // reads a few floats past the row: still inside the tile, value unused)
@@ -170,8 +231,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // ---- staging: global -> registers -> LDS. One wave per row group (rows wid, wid+4, ...), lanes along time
     // (coalesced 256 B). Loads are BRANCH-FREE (clamped address + select), so all NK*NM loads of a chunk are in flight
     // together; with a per-element bounds branch hipcc serialises them (one HBM latency each).
-    constexpr int NM = DIL != 0 ? (BN + SPAN_C + 63) / 64 : BN / 64 + 1;  // 64-column groups per row (generic: span <= 64)
-    constexpr int NK = CK / 4;
+    constexpr int NM = DB ? 1 : (DIL != 0 ? (BN + SPAN_C + 63) / 64 : BN / 64 + 1);  // 64-column groups per row (generic: span <= 64)
+    constexpr int NK = DB ? 1 : CK / 4;
     float st[NK][NM];
     auto stage_load = [&](int c) __attribute__((always_inline)) {
 #ifdef VAR_NOSTAGE
@@ -206,18 +267,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             }
     };
     if constexpr (DB) {
-        // double-buffered LDS: the global loads of chunk c+1 are issued BEFORE the MFMA work of chunk c and written to
-        // the other LDS buffer AFTER it, so HBM latency hides under the matrix pipe and one barrier per chunk suffices
-        stage_load(0);
-        stage_store(0);
+        // compute waves of the wave-specialised path (see the producer above)
         __syncthreads();
         for (int c = 0; c < p.nchunks; ++c) {
-            const bool more = c + 1 < p.nchunks;
-            if (more) stage_load(c + 1);
-            __builtin_amdgcn_sched_barrier(0);
             compute_chunk(xrow0 + (c & 1) * (CK * xw));
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) stage_store((c + 1) & 1);
             __syncthreads();
         }
     } else {
@@ -234,6 +287,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
+#ifdef VAR_NOEPI  // ablation: keep the accumulators alive, store one value per lane
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) p.y[tid] = sacc;
+        return;
+    }
+#endif
     const int colbase = t0 + wn * (NR * 32) + (lane & 31);
     const int rowoff = 4 * (lane >> 5);
     if (EPI == EPI_STD) {
@@ -389,7 +455,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
-    const size_t lds = (size_t)(DB ? 2 : 1) * CK * p.xw * sizeof(float);
+    const size_t lds = DB ? (size_t)2 * CK * ((p.xw + 63) / 64 * 64) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
 #define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
     do {                                                                                                                              \
         static bool big_lds_set = false;                                                                                              \
@@ -399,7 +465,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
             if (ea != hipSuccess) return ea;                                                                                          \
             big_lds_set = true;                                                                                                       \
         }                                                                                                                             \
-        hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(256), lds, s, p);                             \
+        hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(DB ? 320 : 256), lds, s, p);                             \
     } while (0)
     switch (tile) {
         case TILE_128x128:
