@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -303,9 +304,78 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     const int colbase = t0 + wn * (NR * 32) + (lane & 31);
     const int rowoff = 4 * (lane >> 5);
     if (EPI == EPI_STD) {
-        float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
-        const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
-        const float* __restrict__ ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
+        // no __restrict__: residual / accumulator may alias the output (in-place updates)
+        float* yb = p.y + (int64_t)b * p.y_bs;
+        const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+        const float* ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
+        // ---- wide path (interior tile, 16-byte aligned rows): the MFMA C layout gives a lane ONE column and 16 rows, i.e.
+        // 64 dword stores (+64 dword loads with a residual) per lane and the epilogue becomes store-issue bound (16 % of a
+        // k=3 conv). A 4x4 transpose inside each quad of lanes (two DPP quad_perm butterflies, no LDS) gives every lane
+        // 4 CONSECUTIVE columns of one row instead -> dwordx4 loads / stores: 4x fewer memory instructions.
+        const bool wide = (t0 + BN <= ncols) && ((mt0 + MR) * 32 <= p.cout) && (((p.y_cs | p.r_cs | p.a_cs) & 3) == 0) &&
+                          ((((uintptr_t)yb | (uintptr_t)rb | (uintptr_t)ab) & 15) == 0);
+        if (wide) {
+            const int qi = lane & 3;                     // position in the quad == row offset after the transpose
+            const int cq = (lane & 31) & ~3;             // first of this lane's 4 columns within the 32-column tile
+            const bool odd1 = lane & 1, odd2 = lane & 2;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int tcol = t0 + wn * (NR * 32) + nr * 32 + cq;
+                    float4 rv[4], av[4];
+                    if (rb) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
+                            rv[g] = *reinterpret_cast<const float4*>(rb + (int64_t)co * p.r_cs + tcol);
+                        }
+                    }
+                    if (ab) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
+                            av[g] = *reinterpret_cast<const float4*>(ab + (int64_t)co * p.a_cs + tcol);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v0 = acc[mr][nr][4 * g + 0], v1 = acc[mr][nr][4 * g + 1], v2 = acc[mr][nr][4 * g + 2], v3 = acc[mr][nr][4 * g + 3];
+                        // butterfly 1: exchange with lane ^ 1 (quad_perm [1,0,3,2] = 0xB1)
+                        {
+                            float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+                            s01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                            s23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                            if (odd1) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
+                        }
+                        // butterfly 2: exchange with lane ^ 2 (quad_perm [2,3,0,1] = 0x4E)
+                        {
+                            float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+                            s02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                            s13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                            if (odd2) { v0 = s02; v1 = s13; } else { v2 = s02; v3 = s13; }
+                        }
+                        // now (v0..v3) = columns tcol..tcol+3 of row co
+                        const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
+                        const float bias = p.bias ? p.bias[co] : 0.f;
+                        float o[4] = {v0 + bias, v1 + bias, v2 + bias, v3 + bias};
+                        const float r4[4] = {rv[g].x, rv[g].y, rv[g].z, rv[g].w}, a4[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = o[e];
+                            if (p.post_act == 1) v = v > 0.f ? v : 0.f;
+                            if (rb) v = r4[e] + v;
+                            if (ab) {
+                                v = a4[e] + v;
+                                v = p.scale_div ? v / p.scale : v * p.scale;
+                            }
+                            o[e] = v;
+                        }
+                        *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + tcol) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -548,7 +618,8 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
-    const bool db = w.nchunks >= 4;  // double-buffer only when there is a next chunk worth prefetching
+    static const int db_min = getenv("VITS_DB_MIN") ? atoi(getenv("VITS_DB_MIN")) : 2;  // measured: 2 chunks (cin 64) gain, 1 chunk (cin 32) loses
+    const bool db = w.nchunks >= db_min;  // producer-wave path only when there is a next chunk worth prefetching
 #define VITS_GO(K, D, E)                                                                     \
     do {                                                                                     \
         if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
