@@ -400,9 +400,44 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
         }
     } else if (EPI == EPI_GATE) {
         // packed tile 2i = tanh rows (channels 32i..), tile 2i+1 = sigmoid rows (half + 32i..): MR == 2
-        float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+        float* yb = p.y + (int64_t)b * p.y_bs;
         const int half = p.cout / 2;
         const int chbase = (mt0 / 2) * 32;
+        const bool wide = (t0 + BN <= ncols) && (chbase + 32 <= half) && ((p.y_cs & 3) == 0) && (((uintptr_t)yb & 15) == 0);
+        if (wide) {
+            // same quad transpose as the standard epilogue: 4 consecutive time steps of one channel per lane -> dwordx4 stores
+            const int qi = lane & 3, cq = (lane & 31) & ~3;
+            const bool odd1 = lane & 1, odd2 = lane & 2;
+            auto xpose = [&](float& v0, float& v1, float& v2, float& v3) __attribute__((always_inline)) {
+                float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+                s01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                s23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                if (odd1) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
+                float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+                s02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                s13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                if (odd2) { v0 = s02; v1 = s13; } else { v2 = s02; v3 = s13; }
+            };
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int tcol = t0 + wn * (NR * 32) + nr * 32 + cq;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a0 = acc[0][nr][4 * g], a1 = acc[0][nr][4 * g + 1], a2 = acc[0][nr][4 * g + 2], a3 = acc[0][nr][4 * g + 3];
+                    float s0 = acc[MR - 1][nr][4 * g], s1 = acc[MR - 1][nr][4 * g + 1], s2 = acc[MR - 1][nr][4 * g + 2], s3 = acc[MR - 1][nr][4 * g + 3];
+                    xpose(a0, a1, a2, a3);
+                    xpose(s0, s1, s2, s3);
+                    const int ch = chbase + 8 * g + qi + rowoff;
+                    const float b0 = p.bias ? p.bias[ch] : 0.f, b1 = p.bias ? p.bias[ch + half] : 0.f;
+                    float4 o;
+                    o.x = tanhf(a0 + b0) * (1.0f / (1.0f + expf(-(s0 + b1))));
+                    o.y = tanhf(a1 + b0) * (1.0f / (1.0f + expf(-(s1 + b1))));
+                    o.z = tanhf(a2 + b0) * (1.0f / (1.0f + expf(-(s2 + b1))));
+                    o.w = tanhf(a3 + b0) * (1.0f / (1.0f + expf(-(s3 + b1))));
+                    *reinterpret_cast<float4*>(yb + (int64_t)ch * p.y_cs + tcol) = o;
+                }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = chbase + (r & 3) + 8 * (r >> 2) + rowoff;
@@ -421,6 +456,30 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
         float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
         const int s = p.ct_stride;
         const int out_len = p.len_out ? p.len_out[b] : p.t_out;
+        // stride 8: the 4 registers of a group are phases 4h..4h+3 of ONE output channel at one input position, i.e. 4
+        // consecutive output samples -> one dwordx4 store (interior tiles; crop is 0 or 4 so the address stays 16-B aligned)
+        const bool wide8 = s == 8 && (p.ct_crop & 3) == 0 && (t0 + BN <= ncols - 1) && t0 > 0 && ((mt0 + MR) * 32 <= p.rows) &&
+                           ((p.y_cs & 3) == 0) && (((uintptr_t)yb & 15) == 0);
+        if (wide8) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (mt0 + mr) * 4 + g;
+                    const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int q = colbase + nr * 32;
+                        const int n = 8 * q + rowoff - p.ct_crop;
+                        if (n + 3 < out_len)
+                            *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + n) = make_float4(
+                                acc[mr][nr][4 * g] + bias, acc[mr][nr][4 * g + 1] + bias, acc[mr][nr][4 * g + 2] + bias, acc[mr][nr][4 * g + 3] + bias);
+                        else
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < out_len) yb[(int64_t)co * p.y_cs + n + e] = acc[mr][nr][4 * g + e] + bias;
+                    }
+                }
+        } else
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -590,6 +649,11 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.ct_crop = c.ct_crop;
     int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
+    if (c.tile < 0 && w.epi == EPI_GATE) {
+        const TileShape t2 = tile_shape(tile);
+        const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
+        if (nb * ((w.mtiles_used + 1) / 2) * c.batch < 512) tile = TILE_64x64;  // 64 x 128 keeps the tanh/sigmoid row pairing
+    }
     if (c.tile < 0 && w.epi != EPI_GATE) {
         // small grids (batch 1, short inputs): fewer than ~2 blocks per CU leaves matrix pipes idle -> step down to
         // smaller tiles until the launch has >= 512 blocks (latency case, BASELINE.json config 2)
