@@ -1,0 +1,134 @@
+"""GPU edge cases (shortest / ragged / long inputs, two resident models, device output) and size-independent properties at
+the full benchmark size (BASELINE.json configs 3 and 5), through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def ids_for(T, seed, vocab=38):
+    rng = np.random.default_rng(seed)
+    ids = np.zeros(T, np.int32)
+    ids[1::2] = rng.integers(1, vocab, size=len(ids[1::2]))
+    return ids
+
+
+@pytest.fixture(scope="module")
+def full_model(pkg, full_bytes):
+    m = pkg.Model(full_bytes)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 9])  # T < window+1 exercises the sliced relative-position table (vits.cpp:202-204)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shortest_inputs_match_oracle(pkg, oracle, full_model, full_bytes, T, mode):
+    om = oracle.Model(full_bytes)
+    ids = ids_for(T, 40 + T)
+    pcm, lengths, frames = full_model.process_batch(ids, mode=mode, noise_seed=5, collect_taps=True)
+    ref = om.process_ids(ids, mode=mode, noise_kind=oracle.NOISE_COUNTER, noise_seed=5)
+    np.testing.assert_array_equal(full_model.tap("durations"), ref["durations"])
+    assert rel_err(full_model.tap("enc_out"), ref["enc_out"]) < 1e-4
+    assert rel_err(pcm[0], ref["waveform"]) < 1e-4
+
+
+def test_long_input_matches_oracle(pkg, oracle, full_model, full_bytes):
+    """300 ids (~8 s of audio): several time tiles per vocoder stage, multi-block attention."""
+    om = oracle.Model(full_bytes)
+    ids = ids_for(300, 77)
+    pcm, lengths, frames = full_model.process_batch(ids, noise_seed=11, collect_taps=True)
+    ref = om.process_ids(ids, noise_kind=oracle.NOISE_COUNTER, noise_seed=11)
+    np.testing.assert_array_equal(full_model.tap("durations"), ref["durations"])
+    for name in ["z_p", "z_flow", "pre_tanh"]:
+        assert rel_err(full_model.tap(name), ref[name]) < 1e-4, name
+    assert rel_err(pcm[0], ref["waveform"]) < 1e-4
+
+
+def test_invalid_inputs_are_rejected(pkg, full_model):
+    with pytest.raises(pkg.VitsError, match="out of range"):
+        full_model.process_batch(np.array([0, 99, 0], np.int32))
+    with pytest.raises(pkg.VitsError):
+        full_model.process_batch(np.zeros((1, 4), np.int32), id_lengths=[9])
+    r = pkg.lib().vits_model_process(full_model._h, b"!!!???")  # no known symbol -> blanks only (one id)
+    assert r.size > 0
+    pkg.lib().vits_free_result(r)
+
+
+def test_two_models_resident_and_interleaved(pkg, oracle, full_bytes):
+    """BASELINE.json config 5 keeps two models (english + spanish) resident: two synthetic weight sets, interleaved calls."""
+    other = pkg.synth_model_bytes(0xBEEF, pkg.SYNTH_FULL)
+    assert other != full_bytes
+    ids = ids_for(14, 3)
+    with pkg.Model(full_bytes) as a, pkg.Model(other) as b:
+        pa1 = a.process_batch(ids, noise_seed=1)[0][0]
+        pb1 = b.process_batch(ids, noise_seed=1)[0][0]
+        pa2 = a.process_batch(ids, noise_seed=1)[0][0]
+        pb2 = b.process_batch(ids, noise_seed=1)[0][0]
+        np.testing.assert_array_equal(pa1, pa2)
+        np.testing.assert_array_equal(pb1, pb2)
+        assert pa1.size != pb1.size or not np.allclose(pa1, pb1)
+        ref_b = oracle.Model(other).process_ids(ids, noise_kind=oracle.NOISE_COUNTER, noise_seed=1)
+        assert rel_err(pb1, ref_b["waveform"]) < 1e-4
+
+
+def test_full_benchmark_size_properties(pkg, full_model):
+    """BASELINE.json config 3 shape (batch 64 x 128 ids). Too big for the oracle, so: exact determinism, exact sample
+    counts, bounded output, and batch invariance (utterance b of the batch == the same utterance alone)."""
+    ids = pkg.synth_ids(64, 128)
+    pcm1, len1, fr1 = full_model.process_batch(ids, noise_seed=4321)
+    pcm2, len2, fr2 = full_model.process_batch(ids, noise_seed=4321)
+    assert np.array_equal(len1, len2) and np.array_equal(fr1, fr2)
+    assert np.array_equal(len1, 256 * fr1 + 294)  # reference mode: S = 256 L + 294 (Q1)
+    for b in range(64):
+        assert np.array_equal(pcm1[b], pcm2[b])  # bitwise reproducible
+        assert np.isfinite(pcm1[b]).all() and np.abs(pcm1[b]).max() <= 1.0
+    for b in (0, 17, 63):
+        one, l1, f1 = full_model.process_batch(ids[b:b + 1], noise_seed=4321 + b)
+        assert l1[0] == len1[b]
+        assert rel_err(pcm1[b], one[0]) < 1e-5
+    # pinned durations (SURVEY §8d run ii): L = 2 T exactly
+    _, lp, fp = full_model.process_batch(ids[:8], noise_seed=1, fixed_duration=2, mode=pkg.MODE_HF)
+    assert (fp == 256).all() and (lp == 65536).all()
+
+
+def test_long_form_1024_ids(pkg, full_model):
+    """BASELINE.json config 5 input length (1024 ids; the reference's fixed 512 MB arena cannot hold this)."""
+    ids = pkg.synth_ids(2, 1024)
+    pcm, lengths, frames = full_model.process_batch(ids, noise_seed=9)
+    assert (frames > 1024).all() and np.array_equal(lengths, 256 * frames + 294)
+    for p_ in pcm:
+        assert np.isfinite(p_).all() and np.abs(p_).max() <= 1.0
+    # the first 64 ids alone give the same opening audio up to the receptive field of the model (prefix consistency does not
+    # hold exactly for a global-attention encoder), so only check the ragged pairing instead: second row alone == batch row
+    one, l1, _ = full_model.process_batch(ids[1:2], noise_seed=10)
+    assert l1[0] == lengths[1] and rel_err(pcm[1], one[0]) < 1e-5
+
+
+def test_device_output_buffer_and_async(pkg, full_model):
+    """PCM written straight into a caller-owned device buffer, asynchronously (the bench path). The buffer comes from the
+    HIP runtime the library itself is linked against (plain hipMalloc through ctypes)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    ids = pkg.synth_ids(4, 32)
+    host, lengths, frames = full_model.process_batch(ids, noise_seed=3, fixed_duration=2)
+    cap = int(lengths.max()) + 100
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), 4 * cap * 4) == 0
+    try:
+        none, l2, f2 = full_model.process_batch(ids, noise_seed=3, fixed_duration=2, out_device=dev.value, out_device_stride=cap,
+                                                skip_host_copy=True, async_=True)
+        assert none is None and np.array_equal(l2, lengths)
+        full_model.sync()
+        got = np.zeros((4, cap), np.float32)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, got.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        for b in range(4):
+            np.testing.assert_array_equal(got[b, : lengths[b]], host[b])
+        with pytest.raises(pkg.VitsError, match="out_device_stride"):
+            full_model.process_batch(ids, out_device=dev.value, out_device_stride=10, skip_host_copy=True)
+    finally:
+        hip.hipFree(dev)
