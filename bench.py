@@ -142,6 +142,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     model.prof_enable(False)
+    # second, un-instrumented pass of the same K steps: what the per-kernel HIP events cost (reported, not the headline)
+    elapsed_plain = None
+    if not args.no_prof:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed_plain = time.perf_counter() - t1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -168,6 +177,9 @@ def main():
             "algorithmic_tflops": flops_step * args.steps / elapsed / 1e12,
             "frac_fp32_peak_whole_path": flops_step * args.steps / elapsed / 1e12 / (PEAK_F32_TFLOPS * world),
         }
+        if elapsed_plain is not None and world == 1:
+            res["value_without_kernel_events"] = total_samples / elapsed_plain
+            res["ms_per_step_without_kernel_events"] = 1000.0 * elapsed_plain / args.steps
         if not args.no_prof:
             rep = model.prof_report()["kernels"]
             # group by kernel instantiation (taps, tile, epilogue) == one rocprofv3 kernel name

@@ -136,6 +136,7 @@ VITS_API int64_t vits_model_get_tap(vits_model* model, const char* name, int32_t
  * deterministic weights derived from `seed`. Conv weights are stored as fp16 like export_vits.py:87. */
 #define VITS_SYNTH_FULL 0 /* VitsConfig defaults == facebook/mms-tts-* architecture */
 #define VITS_SYNTH_TINY 1 /* hidden 16 / small vocoder: small enough to commit as a fixture */
+#define VITS_SYNTH_BF16 0x100 /* OR-ed in: store conv weights as bf16 (tensor type tag 2, an extension of the format) */
 VITS_API int vits_synth_model_bytes(uint64_t seed, int32_t arch, char** bytes, size_t* size);
 VITS_API void vits_free_bytes(char* bytes);
 /* Parse a model file and write it back (host only): byte-exact round trip of the reference's format
@@ -194,6 +195,11 @@ VITS_API int vits_op_rel_attention(int32_t batch, int32_t heads, int32_t head_di
 VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, int32_t t_stride, float eps,
                                     const float* x, const float* residual, const float* gamma, const float* beta,
                                     float* y);
+
+/* ---- PCM16 / WAV sink (reference driver test/main.cpp:23-63: clamp to [-1,1], * 32767, truncate; 16 kHz mono) ------ */
+VITS_API void vits_pcm16_from_float(const float* pcm, size_t n, int16_t* out);
+/* Writes a canonical 44-byte-header RIFF/WAVE file exactly like test/main.cpp:36-60. Returns 0 on success. */
+VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int32_t sample_rate);
 
 /* Select the HIP device used by subsequent loads on this thread (one process per GPU: pass LOCAL_RANK). */
 VITS_API int vits_set_device(int32_t device);

@@ -874,12 +874,16 @@ VO_API vo_model* vo_load(const char* bytes, size_t size) {
             if (t.dtype == 0) {
                 if (nbytes != n * 4) throw std::runtime_error("bad f32 size " + name);
                 std::memcpy(t.d.data(), r.p + r.off, nbytes);
-            } else if (t.dtype == 1) {
-                if (nbytes != n * 2) throw std::runtime_error("bad f16 size " + name);
+            } else if (t.dtype == 1 || t.dtype == 2) {  // 2 = bf16, this repo's extension of the format
+                if (nbytes != n * 2) throw std::runtime_error("bad 16-bit size " + name);
                 for (int64_t e = 0; e < n; ++e) {
                     uint16_t hv;
                     std::memcpy(&hv, r.p + r.off + 2 * e, 2);
-                    t.d[(size_t)e] = half_to_float(hv);
+                    if (t.dtype == 1) t.d[(size_t)e] = half_to_float(hv);
+                    else {
+                        uint32_t bits = (uint32_t)hv << 16;
+                        std::memcpy(&t.d[(size_t)e], &bits, 4);
+                    }
                 }
             } else
                 throw std::runtime_error("Unsupported tensor type");  // ref: vits_model_data.cpp:85

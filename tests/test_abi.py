@@ -58,3 +58,22 @@ def test_product_does_not_link_or_load_the_oracle(pkg):
             if f.endswith((".cpp", ".hip", ".h", ".py")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "vits_oracle" not in text and "oracle_lib" not in text, f
+
+
+def test_pcm16_and_wav_writer_match_the_reference_driver(pkg, tmp_path):
+    """/root/reference/test/main.cpp:23-63: clamp to [-1,1], * 32767, truncating cast; canonical 44-byte header, 16 kHz mono."""
+    import struct
+
+    import numpy as np
+    x = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 1.7, -3.0, 0.99999, -1e-9, 3.0517578e-05], np.float32)
+    want = (np.clip(x, -1.0, 1.0) * np.float32(32767)).astype(np.int16)  # C cast truncates toward zero, like numpy astype
+    np.testing.assert_array_equal(pkg.pcm16(x), want)
+    path = tmp_path / "o.wav"
+    pkg.write_wav16(str(path), x, 16000)
+    raw = path.read_bytes()
+    assert len(raw) == 44 + 2 * x.size
+    riff, size, wave, fmt, fsz, afmt, ch, sr, br, align, bits, data, dbytes = struct.unpack("<4sI4s4sIHHIIHH4sI", raw[:44])
+    assert (riff, wave, fmt, data) == (b"RIFF", b"WAVE", b"fmt ", b"data")
+    assert (fsz, afmt, ch, sr, br, align, bits, dbytes) == (16, 1, 1, 16000, 32000, 2, 16, 2 * x.size)
+    assert size == 4 + (8 + 16) + (8 + dbytes)
+    np.testing.assert_array_equal(np.frombuffer(raw[44:], np.int16), want)

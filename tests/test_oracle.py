@@ -201,3 +201,18 @@ def test_kat_index_put_add_masked_set_arange(oracle):
     ar = np.zeros(6, np.float32)
     L.vo_arange(6, _p(ar))  # :600-605
     assert ar.tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_bf16_storage_extension_round_trips(pkg, oracle):
+    """Type tag 2 (bf16) is this repo's extension for BASELINE.json config 5 ("bf16 weights"): same tensors, bf16-rounded."""
+    a = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)
+    b = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY | pkg.SYNTH_BF16)
+    assert len(a) == len(b) and a != b and pkg.reserialize(b) == b
+    ma, mb = oracle.Model(a), oracle.Model(b)
+    wa, ta = ma.tensor("decoder.conv_pre.weight")
+    wb, tb = mb.tensor("decoder.conv_pre.weight")
+    assert (ta, tb) == (1, 2)
+    assert np.abs(wa - wb).max() <= np.abs(wa).max() * 2.0 ** -8  # bf16 has 8 mantissa bits
+    ea, _ = ma.tensor("text_encoder.embed_tokens.weight")
+    eb, _ = mb.tensor("text_encoder.embed_tokens.weight")
+    np.testing.assert_array_equal(ea, eb)  # fp32 tensors untouched

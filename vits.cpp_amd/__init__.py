@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("VITS_HIP_LIB", os.path.join(_HERE, "csrc", "libvits_h
 
 MODE_DEFAULT, MODE_REFERENCE, MODE_HF = -1, 0, 1
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
-SYNTH_FULL, SYNTH_TINY = 0, 1
+SYNTH_FULL, SYNTH_TINY, SYNTH_BF16 = 0, 1, 0x100
 
 #: every symbol include/vits.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "vits_model_weight_bytes", "vits_model_get_tap", "vits_synth_model_bytes", "vits_free_bytes",
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
-    "vits_model_file_tokenize",
+    "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16",
 ]
 
 
@@ -135,6 +135,10 @@ def lib():
     L.vits_model_file_reserialize.argtypes = [C.c_char_p, sz, C.POINTER(C.c_void_p), C.POINTER(sz)]
     L.vits_model_file_tokenize.restype = i64
     L.vits_model_file_tokenize.argtypes = [C.c_char_p, sz, C.c_char_p, vp, sz]
+    L.vits_pcm16_from_float.restype = None
+    L.vits_pcm16_from_float.argtypes = [vp, sz, vp]
+    L.vits_write_wav16.restype = i32
+    L.vits_write_wav16.argtypes = [C.c_char_p, vp, sz, i32]
     L.vits_set_device.restype = i32
     L.vits_set_device.argtypes = [i32]
     L.vits_device_info.restype = i32
@@ -391,6 +395,19 @@ def op_add_layer_norm(x, residual, gamma, beta, eps=1e-5):
     if lib().vits_op_add_layer_norm(B, Cc, T, T, eps, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y)) != 0:
         raise VitsError(last_error())
     return y
+
+
+def pcm16(pcm):
+    pcm = _f32(pcm)
+    out = np.zeros(pcm.size, np.int16)
+    lib().vits_pcm16_from_float(_ptr(pcm), pcm.size, _ptr(out))
+    return out
+
+
+def write_wav16(path, pcm, sample_rate=16000):
+    pcm = _f32(pcm)
+    if lib().vits_write_wav16(os.fsencode(path), _ptr(pcm), pcm.size, sample_rate) != 0:
+        raise VitsError(last_error())
 
 
 def set_device(index):

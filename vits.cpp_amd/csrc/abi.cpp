@@ -1,6 +1,7 @@
 // abi.cpp — the C ABI of include/vits.h. Nothing below throws across the boundary (the reference lets
 // std::runtime_error escape and calls exit(1) from ASSERT: /root/reference/src/vits_model_data.cpp:102,144,
 // src/include/debug.h:29-36); failures return NULL / {NULL,0} / -1 and set vits_last_error().
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -265,6 +266,46 @@ VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap) {
     std::memcpy(buf, s.data(), n);
     buf[n] = 0;
     return (int64_t)s.size();
+    VITS_CATCH(-1)
+}
+
+// reference: test/main.cpp:31-33 (static_cast<short>(clamp(x, -1, 1) * 32767))
+VITS_API void vits_pcm16_from_float(const float* pcm, size_t n, int16_t* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<int16_t>(std::max(-1.0f, std::min(1.0f, pcm[i])) * 32767);
+}
+
+// reference: test/main.cpp:23-63 (struct WAVHeader + write_wav)
+VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int32_t sample_rate) {
+    VITS_TRY
+    if (!path || (!pcm && n)) return -1;
+    std::vector<int16_t> s(n);
+    vits_pcm16_from_float(pcm, n, s.data());
+    const int32_t channels = 1, bits = 16;
+    const int32_t data_bytes = (int32_t)(n * 2);
+    unsigned char h[44];
+    auto put32 = [&](int off, int32_t v) { std::memcpy(h + off, &v, 4); };
+    auto put16 = [&](int off, int16_t v) { std::memcpy(h + off, &v, 2); };
+    std::memcpy(h, "RIFF", 4);
+    put32(4, 4 + (8 + 16) + (8 + data_bytes));
+    std::memcpy(h + 8, "WAVE", 4);
+    std::memcpy(h + 12, "fmt ", 4);
+    put32(16, 16);
+    put16(20, 1);
+    put16(22, (int16_t)channels);
+    put32(24, sample_rate);
+    put32(28, sample_rate * channels * (bits / 8));
+    put16(32, (int16_t)(channels * (bits / 8)));
+    put16(34, (int16_t)bits);
+    std::memcpy(h + 36, "data", 4);
+    put32(40, data_bytes);
+    std::ofstream f(path, std::ios::binary);
+    if (!f.is_open()) {
+        set_err(std::string("cannot open ") + path);
+        return -1;
+    }
+    f.write(reinterpret_cast<const char*>(h), 44);
+    f.write(reinterpret_cast<const char*>(s.data()), data_bytes);
+    return f.good() ? 0 : -1;
     VITS_CATCH(-1)
 }
 

@@ -346,11 +346,12 @@ struct Synth {
     ModelFile f;
     uint64_t seed;
     uint32_t ordinal = 0;
+    bool bf16 = false;  // store the 16-bit tensors as bf16 (type tag 2, extension) instead of fp16
     // torch-shaped tensor filled with scale * N(0,1); stored fp16 or fp32
     void add(const std::string& name, std::vector<int64_t> shape, bool half, float scale, float offset = 0.f) {
         TensorEntry t;
         t.name = name;
-        t.dtype = half ? DT_F16 : DT_F32;
+        t.dtype = half ? (bf16 ? DT_BF16 : DT_F16) : DT_F32;
         t.rank = (uint32_t)shape.size();
         int64_t n = 1;
         for (size_t i = 0; i < shape.size(); ++i) {
@@ -362,7 +363,7 @@ struct Synth {
         for (int64_t i = 0; i < n; ++i) {
             const float v = offset + scale * vits_counter_normal(seed, stream, (uint64_t)i);
             if (half) {
-                const uint16_t h = f32_to_f16(v);
+                const uint16_t h = bf16 ? f32_to_bf16(v) : f32_to_f16(v);
                 std::memcpy(t.raw.data() + 2 * i, &h, 2);
             } else
                 std::memcpy(t.raw.data() + 4 * i, &v, 4);
@@ -389,7 +390,8 @@ std::string list_str(const std::vector<int>& v) {  // python repr, like str(valu
 }
 }  // namespace
 
-ModelFile make_synthetic_model(uint64_t seed, int arch) {
+ModelFile make_synthetic_model(uint64_t seed, int arch_flags) {
+    const int arch = arch_flags & 0xFF;
     HParams h;  // defaults == MMS-TTS
     if (arch == VITS_SYNTH_TINY) {
         h.hidden = 16;
@@ -409,6 +411,7 @@ ModelFile make_synthetic_model(uint64_t seed, int arch) {
     }
     Synth s;
     s.seed = seed;
+    s.bf16 = (arch_flags & VITS_SYNTH_BF16) != 0;
     ModelFile& f = s.f;
     // tokenizer block: a 38-entry single-character vocabulary in the style of the MMS checkpoints
     {
