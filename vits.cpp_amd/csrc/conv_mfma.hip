@@ -78,6 +78,10 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     constexpr int BN = WN * NR * 32;
     constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
     constexpr int STEPS = KT * (CK / 8);  // float4 A-fragments (4 MFMA k-steps each) per chunk and row tile
+    // DB path: where the fused leaky_relu runs. Short chunks (k <= 3: 12 steps) leave the producer wave no slack, so the
+    // compute waves apply it at the B-operand read (max(x, slope*x), ~2 % there); for k >= 5 the producer rewrites the
+    // landed tile in place instead (at-read costs 9 % on the k=11 kernels: two VALU ops between every ds_read and its MFMAs)
+    constexpr bool LRELU_AT_READ = KT <= 3;
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][xw]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -130,6 +134,22 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                                                          (__attribute__((address_space(3))) void*)(lbase + r * XWP + 64 * m), 4, 0, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ... leaky_relu in place (the producer has slack; doing it at the B-operand read of the compute waves
+                // instead puts two VALU ops between every ds_read and its MFMAs: measured -9 % on the k=11 kernels) ...
+                if (!LRELU_AT_READ && p.pre_act) {
+                    // whole buffer as a linear array of float4 (XWP is a multiple of 4): 16-byte LDS reads / writes
+                    float4* l4 = reinterpret_cast<float4*>(lbase);
+                    constexpr int N4 = CK * XWP / 4;
+#pragma unroll 4
+                    for (int i = lane; i < N4; i += 64) {
+                        float4 v = l4[i];
+                        v.x = fmaxf(v.x, v.x * p.slope);
+                        v.y = fmaxf(v.y, v.y * p.slope);
+                        v.z = fmaxf(v.z, v.z * p.slope);
+                        v.w = fmaxf(v.w, v.w * p.slope);
+                        l4[i] = v;
+                    }
+                }
                 // ... then zero what lies outside the sequence (boundary tiles) or beyond the last input channel
                 if (!interior || (c + 1) * CK > p.cin) {
 #pragma unroll 4
@@ -139,8 +159,8 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                         for (int m = 0; m < NMP; ++m)
                             if (oob[m] || chbad) lbase[r * XWP + 64 * m + lane] = 0.f;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS writes of this wave done before the barrier
             };
             fill(0);
             __syncthreads();
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const float slope_eff = p.pre_act ? p.slope : 1.0f;  // DB: leaky_relu(x) = max(x, slope*x) applied at the B-operand read
+    const float slope_eff = p.pre_act ? p.slope : 1.0f;  // leaky_relu(x) = max(x, slope*x); slope 1 = identity
     const int krow = lane >> 5;
     const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off;  // B operand base of this lane
     const size_t tile4 = (size_t)p.nchunks * STEPS * 64;                           // float4 per 32-row tile
@@ -203,7 +223,9 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                 for (int q = 0; q < 4; ++q) {
                     float b_cur[NR];
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = DB ? fmaxf(b_nxt[nr], b_nxt[nr] * slope_eff) : b_nxt[nr];
+                    for (int nr = 0; nr < NR; ++nr) {
+                        b_cur[nr] = (DB && LRELU_AT_READ) ? fmaxf(b_nxt[nr], b_nxt[nr] * slope_eff) : b_nxt[nr];
+                    }
                     {
                         // next k-step: next channel pair of this tap, or pair 0 of the next tap (after the last tap this
                         // reads a few floats past the row: still inside the tile, value unused)
