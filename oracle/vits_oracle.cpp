@@ -11,6 +11,9 @@
 #include "vits_oracle.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -315,20 +318,25 @@ void conv1d_raw(const float* x, int cin, int T, int x_stride, const float* w, co
                 int pad_l, int pad_r, bool pre_lrelu, float slope, float* y, int y_stride, int threads) {
     const int Tp = T + pad_l + pad_r;
     const int To = Tp - (K - 1) * dil;
-    std::vector<float> xp((size_t)cin * Tp, 0.f);
-    for (int ci = 0; ci < cin; ++ci) {
-        float* dst = xp.data() + (size_t)ci * Tp + pad_l;
-        const float* src = x + (size_t)ci * x_stride;
-        if (pre_lrelu)
-            for (int t = 0; t < T; ++t) dst[t] = leaky(src[t], slope);
-        else
-            std::memcpy(dst, src, sizeof(float) * T);
-    }
+    std::vector<float> xp((size_t)cin * Tp);
+    parallel_for(threads, cin, [&](int64_t b0, int64_t e0) {
+        for (int64_t ci = b0; ci < e0; ++ci) {
+            float* row = xp.data() + (size_t)ci * Tp;
+            std::fill(row, row + pad_l, 0.f);
+            std::fill(row + pad_l + T, row + Tp, 0.f);
+            float* dst = row + pad_l;
+            const float* src = x + (size_t)ci * x_stride;
+            if (pre_lrelu)
+                for (int t = 0; t < T; ++t) dst[t] = leaky(src[t], slope);
+            else
+                std::memcpy(dst, src, sizeof(float) * T);
+        }
+    });
     // register-blocked direct convolution: 4 output channels x 32 time steps of accumulators stay in vector registers
     // while (ci, tap) runs; each x vector is loaded once for the 4 channels. Same arithmetic as the im2col+GEMM of
     // the reference (sum over (ci, tap) of w*x, fp32), different summation grouping only.
     typedef float v8 __attribute__((vector_size(32), aligned(4)));
-    const int TT = 512, TB = 32;
+    const int TT = To <= 4096 ? 128 : 512, TB = 32;  // short sequences: smaller time tiles so that every thread gets work
     const int CB = 4;
     const int ncb = (cout + CB - 1) / CB;
     const int ntt = (To + TT - 1) / TT;
@@ -394,27 +402,45 @@ Act conv1d(const Act& x, const Tensor& w, const Tensor* b, int dil, int pad_l, i
  * ne=[K,Cout,Cin]). y_full[co][i*s + k] += x[ci][i]*w[ci][co][k]; output = y_full[crop : len-crop].
  */
 void conv_transpose1d_raw(const float* x, int cin, int T, int x_stride, const float* w, const float* bias, int cout, int K, int s,
-                          int crop, float pre_slope, float* y, int y_stride) {
+                          int crop, float pre_slope, float* y, int y_stride, int threads = 0) {
+    // y_full[co][i*s + k] += x[ci][i] * w[ci][co][k]  ==  per output phase r = n mod s (n = s*q + r):
+    //   y_full[co][s*q + r] = sum_ci sum_m x[ci][q - m] * w[ci][co][r + s*m],  m < K/s   (same sum, regrouped so that the
+    //   inner loop runs over q with unit stride). Output = y_full[crop : full - crop] + bias.
     const int full = (T - 1) * s + K;
     const int To = full - 2 * crop;
-    std::vector<float> acc((size_t)full);
-    std::vector<float> xa((size_t)cin * T);
+    const int taps = (K + s - 1) / s;        // taps per phase
+    const int Q = T + taps - 1;              // q range: 0 .. T + taps - 2
+    std::vector<float> xa((size_t)cin * (Q + taps), 0.f);  // x with (taps-1) zeros in front: xa[ci][q + taps-1 - m] = x[ci][q - m]
+    const int XS = Q + taps;
     for (int ci = 0; ci < cin; ++ci)
-        for (int t = 0; t < T; ++t) xa[(size_t)ci * T + t] = leaky(x[(size_t)ci * x_stride + t], pre_slope);
-    for (int co = 0; co < cout; ++co) {
-        std::fill(acc.begin(), acc.end(), 0.f);
-        for (int ci = 0; ci < cin; ++ci) {
-            const float* wk = w + ((size_t)ci * cout + co) * K;
-            const float* xr = xa.data() + (size_t)ci * T;
-            for (int i = 0; i < T; ++i) {
-                const float xv = xr[i];
-                float* a = acc.data() + (size_t)i * s;
-                for (int k = 0; k < K; ++k) a[k] += xv * wk[k];
+        for (int t = 0; t < T; ++t) xa[(size_t)ci * XS + (taps - 1) + t] = leaky(x[(size_t)ci * x_stride + t], pre_slope);
+    if (threads <= 0) threads = default_threads();
+    parallel_for(threads, cout, [&](int64_t b, int64_t e) {
+        std::vector<float> ph((size_t)s * Q);
+        for (int64_t co = b; co < e; ++co) {
+            std::fill(ph.begin(), ph.end(), 0.f);
+            for (int ci = 0; ci < cin; ++ci) {
+                const float* wk = w + ((size_t)ci * cout + co) * K;
+                const float* xr = xa.data() + (size_t)ci * XS + (taps - 1);
+                for (int r = 0; r < s; ++r) {
+                    float* pr = ph.data() + (size_t)r * Q;
+                    for (int mm = 0; mm < taps; ++mm) {
+                        const int k = r + s * mm;
+                        if (k >= K) break;
+                        const float wv = wk[k];
+                        const float* xs = xr - mm;  // x[q - mm]
+                        for (int q = 0; q < Q; ++q) pr[q] += wv * xs[q];
+                    }
+                }
+            }
+            const float bv = bias ? bias[co] : 0.f;
+            float* yo = y + (size_t)co * y_stride;
+            for (int n = 0; n < To; ++n) {
+                const int nf = n + crop;
+                yo[n] = ph[(size_t)(nf % s) * Q + nf / s] + bv;
             }
         }
-        const float bv = bias ? bias[co] : 0.f;
-        for (int t = 0; t < To; ++t) y[(size_t)co * y_stride + t] = acc[t + crop] + bv;
-    }
+    });
 }
 
 /* layer_norm over channels, ref: vits.cpp:115-120 (ggml_norm_inplace + mul + add); HF nn.LayerNorm. */
@@ -779,6 +805,16 @@ Act flow_reverse(const Ctx& c, Act x) {
 }
 
 /* HiFiGAN, ref: vits.cpp:583-644, resblock :545-581, conv transpose :178-193; HF:519-551,455-463 */
+struct StageTimer {  // VO_TIMING=1 prints where the CPU time goes (developer aid for the cpu_baseline leg)
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() {
+        static const bool on = std::getenv("VO_TIMING") != nullptr;
+        if (on) std::fprintf(stderr, "[oracle] %-18s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 void hifigan(const Ctx& c, const Act& z, Act& pre_tanh, Act& wave) {
     const vo_model& m = c.m;
     const float slope = m.lrelu;
@@ -791,7 +827,10 @@ void hifigan(const Ctx& c, const Act& z, Act& pre_tanh, Act& wave) {
         const int crop = (c.mode == VO_MODE_REFERENCE) ? 0 : (m.up_k[i] - s) / 2;  // ref :187 (Q1) / HF:488
         const int To = (h.T - 1) * s + K - 2 * crop;
         Act u(cout, To);
+        StageTimer* tt = new StageTimer("convT");
         conv_transpose1d_raw(h.d.data(), cin, h.T, h.T, w.d.data(), b.d.data(), cout, K, s, crop, slope, u.d.data(), To);  // lrelu ref :613
+        delete tt;
+        StageTimer trb("resblocks(stage)");
         Act sum;
         for (int j = 0; j < nk; ++j) {
             const int idx = (int)i * nk + j;
@@ -805,11 +844,15 @@ void hifigan(const Ctx& c, const Act& z, Act& pre_tanh, Act& wave) {
                                 slope, c.threads);
                 Act t2 = conv1d(t1, m.T(rb + "convs2." + std::to_string(di) + ".weight"), &m.T(rb + "convs2." + std::to_string(di) + ".bias"), 1, p2, p2, true,
                                 slope, c.threads);
-                for (size_t e = 0; e < y.d.size(); ++e) y.d[e] = y.d[e] + t2.d[e];  // ref :578
+                parallel_for(c.threads, y.C, [&](int64_t b0, int64_t e0) {
+                    for (size_t e = (size_t)b0 * y.T; e < (size_t)e0 * y.T; ++e) y.d[e] = y.d[e] + t2.d[e];  // ref :578
+                });
             }
             if (j == 0) sum = y;
             else
-                for (size_t e = 0; e < sum.d.size(); ++e) sum.d[e] += y.d[e];  // ref :630
+                parallel_for(c.threads, sum.C, [&](int64_t b0, int64_t e0) {
+                    for (size_t e = (size_t)b0 * sum.T; e < (size_t)e0 * sum.T; ++e) sum.d[e] += y.d[e];  // ref :630
+                });
         }
         if (c.mode == VO_MODE_REFERENCE) {
             const float sc = (float)(1.0 / nk);  // ref :607,635
@@ -932,7 +975,10 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         auto run = std::make_unique<vo_run>();
         Act enc, m_p, logs_p;
-        text_encoder(c, ids, T, enc, m_p, logs_p);
+        {
+            StageTimer t("text_encoder");
+            text_encoder(c, ids, T, enc, m_p, logs_p);
+        }
         // duration noise [2][T], ref: vits.cpp:948 tensor_randn{T,2,1} (memory order: channel-major, time fastest)
         Act nd(2, T);
         const int nk = opts ? opts->noise_kind : VO_NOISE_REFERENCE;
@@ -941,7 +987,11 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
             for (int i = 0; i < 2 * T; ++i) nd.d[i] = vits_counter_normal(opts->noise_seed, VITS_STREAM_NOISE_DUR, (uint64_t)i);
         else
             ref_noise_fill(nd.d.data(), (size_t)2 * T);
-        Act logw = duration_predictor(c, enc, nd.d.data());
+        Act logw;
+        {
+            StageTimer t("duration_predictor");
+            logw = duration_predictor(c, enc, nd.d.data());
+        }
         // durations, ref: vits.cpp:995-1001 ; HF:1348-1349
         Act dur(1, T);
         const float length_scale = (float)(1.0 / m.speaking_rate);
@@ -983,9 +1033,16 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
                 n = n * m.noise_scale;                                // ref :1061
                 z_p.d[(size_t)ch * L + j] = mu + n;                   // ref :1063
             }
-        Act z = flow_reverse(c, z_p);
+        Act z;
+        {
+            StageTimer t("flow");
+            z = flow_reverse(c, z_p);
+        }
         Act pre, wave;
-        hifigan(c, z, pre, wave);
+        {
+            StageTimer t("hifigan");
+            hifigan(c, z, pre, wave);
+        }
         run->taps["enc_out"] = enc;
         run->taps["prior_mean"] = m_p;
         run->taps["prior_logvar"] = logs_p;
