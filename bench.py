@@ -47,27 +47,40 @@ def algorithmic_flops(T, frames):
     return enc + dur + 14155776 * L + 614907904 * L
 
 
-def cpu_baseline(model_bytes, ids, seed, budget_s=20.0):
-    """Times the CPU oracle (restatement of the reference ggml graph; the ggml fork itself is not vendored) on this
-    host's cores, reference thread rule max(hardware_concurrency, 6) (src/include/common.h:19-21), reference method
-    (sequential batch-1 calls, wall time; test/bench_e2e.cpp:79-89), on a bounded sample of the same workload."""
+def cpu_baseline(model_bytes, ids, seed, budget_s=15.0):
+    """Times the CPU oracle (restatement of the reference ggml graph; the ggml fork itself is not vendored) on this host's
+    cores with the reference's method (sequential batch-1 calls, wall clock; test/bench_e2e.cpp:79-89) on a bounded sample
+    of the same workload. Thread count: the reference would use max(hardware_concurrency, 6) (src/include/common.h:19-21),
+    which on a 256-thread host is far past the oracle's scaling knee, so a short sweep picks the FASTEST thread count and that
+    one is reported (`cores`); the figure at the reference's rule is kept alongside for transparency."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     m = O.Model(model_bytes)
-    cores = max(os.cpu_count() or 1, 6)
+    hw = max(os.cpu_count() or 1, 6)
+
+    def run(u, threads):
+        t = time.perf_counter()
+        r = m.process_ids(ids[u], mode=O.MODE_REFERENCE, noise_kind=O.NOISE_COUNTER, noise_seed=seed + u, threads=threads, taps=["waveform"])
+        return r["waveform"].size, time.perf_counter() - t
+
+    sweep = {}
+    for th in sorted({min(hw, c) for c in (8, 16, 32, 64)} | {hw}):
+        n, dt = run(0, th)
+        sweep[th] = n / dt
+    best = max(sweep, key=sweep.get)
     t0 = time.perf_counter()
     samples, n = 0, 0
     for u in range(ids.shape[0]):
-        r = m.process_ids(ids[u], mode=O.MODE_REFERENCE, noise_kind=O.NOISE_COUNTER, noise_seed=seed + u, threads=cores, taps=["waveform"])
-        samples += r["waveform"].size
+        sz, _ = run(u, best)
+        samples += sz
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": samples / dt, "unit": "samples/s", "cores": best, "kind": "port",
             "sample": f"{n} utterance(s) of the same workload ({ids.shape[1]} ids each, reference mode), {dt:.1f} s wall, "
-                      f"CPU restatement of the reference ggml graph (ggml fork not vendored)",
-            "rtf_16k": dt / (samples / 16000.0)}
+                      f"CPU restatement of the reference ggml graph (ggml fork not vendored); thread count = fastest of a sweep",
+            "rtf_16k": dt / (samples / 16000.0), "host_threads": hw, "thread_sweep_samples_per_s": {str(k): v for k, v in sweep.items()}}
 
 
 def main():
@@ -204,18 +217,18 @@ def main():
                                "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
                                "hbm_frac_if_algorithmic": dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             # HBM bytes per launch of that kernel from the PMC passes (collected separately with rocprofv3 --pmc on this
-            # same command; PMC cannot be sampled from inside the run): profiles/round1_v4_pmc_traffic.json
+            # same command; PMC cannot be sampled from inside the run): profiles/round1_v6_pmc_traffic.json
             try:
                 tiles = {"t0": "2, 2, 2, 2", "t1": "1, 4, 2, 2", "t2": "1, 4, 1, 2", "t3": "1, 4, 2, 1", "t4": "1, 4, 1, 1"}
                 kk, dd, tt, ee = dom_key.split("|")
-                with open(os.path.join(ROOT, "profiles", "round1_v4_pmc_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "round1_v6_pmc_traffic.json")) as fh:
                     pmc = json.load(fh)["kernels"]
                 cands = [v for n, v in pmc.items() if n.startswith(f"void vits::conv_mfma_kernel<{kk[1:]}, {dd[1:]}, ")
                          and n.endswith(f"{tiles[tt]}, {ee[1:]}>(vits::ConvParams)")]
                 if cands:
                     best = max(cands, key=lambda v: v["launches_sampled"])
                     res["roofline"]["traffic"] = best["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE calibrated x1.143 + WRITE_SIZE, profiles/round1_v4_pmc_traffic.json)"
+                    res["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE calibrated x1.143 + WRITE_SIZE, profiles/round1_v6_pmc_traffic.json)"
                     res["roofline"]["traffic_over_algorithmic"] = best["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
             except Exception:
                 pass
