@@ -1,6 +1,6 @@
 """Developer helper: CPU-oracle throughput vs thread count on this host (picks the cpu_baseline thread count)."""
 import sys, time, importlib.util, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O
 spec = importlib.util.spec_from_file_location("vits_cpp_amd", os.path.join(ROOT, "vits.cpp_amd", "__init__.py"))

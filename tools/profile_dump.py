@@ -1,6 +1,6 @@
 """Developer helper: runs the benchmark workload once with the HIP-event profiler and prints every kernel entry."""
 import sys, json, importlib.util, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("vits_cpp_amd", os.path.join(ROOT, "vits.cpp_amd", "__init__.py"))
 pkg = importlib.util.module_from_spec(spec); spec.loader.exec_module(pkg)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

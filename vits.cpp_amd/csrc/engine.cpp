@@ -954,9 +954,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         } else {
                             c2.scale = 1.f;
                         }
-                        if (j == 0 && nk == 1) {
-                            // single-kernel vocoder: nothing to accumulate, scale is 1
-                        }
+                        // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
+                        // scale 1/1 is the identity, so no special case is needed)
                     }
                     HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2));
                 }
