@@ -159,8 +159,15 @@ Arena::~Arena() {
 // ---- load -------------------------------------------------------------------------------------------------
 Engine::~Engine() {
     if (stream) hipStreamSynchronize(stream);
+    for (hipStream_t s : side_)
+        if (s) hipStreamSynchronize(s);
     clear_taps();
     for (void* p : owned_) hipFree(p);
+    if (ev_fork_) hipEventDestroy(ev_fork_);
+    for (hipEvent_t e : ev_done_)
+        if (e) hipEventDestroy(e);
+    for (hipStream_t s : side_)
+        if (s) hipStreamDestroy(s);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -295,6 +302,16 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         err = "hipStreamCreate failed";
         return false;
     }
+    if (const char* e = std::getenv("VITS_RB_STREAMS")) rb_streams_ = std::atoi(e) >= 2 ? 3 : 1;
+    if (rb_streams_ > 1) {
+        bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
+        for (auto& s : side_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+        for (auto& ev : ev_done_) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            err = "hipStreamCreate failed";
+            return false;
+        }
+    }
     const int H = hp.hidden;
     if (!(emb_ = upload_tensor(f, "text_encoder.embed_tokens.weight", err))) return false;
     {
@@ -428,7 +445,8 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
-hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c) {
+hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on) {
+    hipStream_t stream = on ? on : this->stream;
     if (prof.on) {
         // name = label|k<taps>|d<dilation>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
         // bench can line entries up with rocprofv3's per-kernel-name statistics
@@ -767,7 +785,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     for (int i = 0; i <= n_up; ++i) sts[i] = round_up(smax[i], 32);
     for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
     struct S2 {
-        float *zp, *noise, *hout, *gate, *h0, *bu, *by, *bt, *bs, *pre, *wave;
+        float *zp, *noise, *hout, *gate, *h0, *bu, *by[3], *bt[3], *bs, *pre, *wave;
     } s2;
     const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
     const int S_stride = sts[n_up];
@@ -778,8 +796,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         s2.gate = a.alloc<float>((size_t)B * H * ls);
         s2.h0 = a.alloc<float>((size_t)B * hp.up_init * ls);
         s2.bu = a.alloc<float>(big);
-        s2.by = a.alloc<float>(big);
-        s2.bt = a.alloc<float>(big);
+        for (int j = 0; j < 3; ++j) {
+            // one (y, t) pair per concurrently running resblock
+            const bool own = j == 0 || (rb_streams_ > 1 && (size_t)j < hp.rb_k.size());
+            s2.by[j] = own ? a.alloc<float>(big) : s2.by[0];
+            s2.bt[j] = own ? a.alloc<float>(big) : s2.bt[0];
+        }
         s2.bs = a.alloc<float>(big);
         s2.pre = o.collect_taps ? a.alloc<float>((size_t)B * S_stride) : nullptr;
         s2.wave = a.alloc<float>((size_t)B * S_stride);
@@ -902,7 +924,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         for (int i = 0; i < n_up; ++i) {
             const UpStageW& U = ups_[i];
             const int C = U.channels, st_in = i, st_out = i + 1;
-            TensorRef bu = TR(s2.bu, C, sts[st_out]), by = TR(s2.by, C, sts[st_out]), bt = TR(s2.bt, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
+            TensorRef bu = TR(s2.bu, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
             {
                 ConvCall c;
                 c.x = cur;
@@ -917,9 +939,19 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
                 HIP_OK(conv("hifigan_upsample_convT", U.up, c));
             }
+            // resblock j runs on its own stream (engine.h); only the LAST convolution of each resblock touches the shared
+            // sum, and those are chained j-1 -> j by events so the additions keep the reference's order (vits.cpp:622-635)
+            // (per-kernel event timing needs kernels that do not overlap: the profiler serialises the stage)
+            const bool par = rb_streams_ > 1 && nk >= 2 && nk <= 3 && !prof.on;
+            if (par) {
+                HIP_OK(hipEventRecord(ev_fork_, stream));
+                for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
+            }
             for (size_t j = 0; j < nk; ++j) {
                 const ResBlockW& R = U.rbs[j];
                 const size_t nd = R.dil.size();
+                hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
+                TensorRef by = TR(s2.by[par ? j : 0], C, sts[st_out]), bt = TR(s2.bt[par ? j : 0], C, sts[st_out]);
                 for (size_t d = 0; d < nd; ++d) {
                     TensorRef resid = d == 0 ? bu : by;
                     ConvCall c1;
@@ -932,7 +964,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
                     c1.pre_act = 1;
                     c1.slope = hp.lrelu;
-                    HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1));
+                    HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1, sj));
                     ConvCall c2 = c1;
                     c2.x = bt;
                     c2.dil = 1;
@@ -957,9 +989,13 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
                         // scale 1/1 is the identity, so no special case is needed)
                     }
-                    HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2));
+                    const bool last = d + 1 == nd;
+                    if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                    HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2, sj));
+                    if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
                 }
             }
+            if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
             cur = bsum;
         }
         TensorRef pre;

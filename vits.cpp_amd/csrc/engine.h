@@ -131,6 +131,11 @@ class Engine {
     std::vector<void*> owned_;  // every device allocation made at load
 
     Arena a1_, a2_;
+    // The three resblocks of a vocoder stage (kernel sizes 3/7/11) are independent chains of six convolutions; they run on
+    // three streams so that the tail of one kernel's grid overlaps the head of another's. side_[j-1] carries resblock j.
+    hipStream_t side_[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork_ = nullptr, ev_done_[3] = {nullptr, nullptr, nullptr};
+    int rb_streams_ = 3;  // VITS_RB_STREAMS=1 serialises everything on the main stream
     std::map<std::string, Tap> taps_;
     int tap_batch_ = 0;
 
@@ -139,7 +144,7 @@ class Engine {
     bool pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, int t_hint, PackedConv& out, std::string& err,
               int ct_stride = 0, int transform = 0);
     bool load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err);
-    hipError_t conv(const char* name, const PackedConv& w, ConvCall c);
+    hipError_t conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on = nullptr);  // on == nullptr: the main stream
     hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax);
     void snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens);
     void clear_taps();
