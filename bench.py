@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--mode", choices=["reference", "hf"], default="reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--pcm16", action="store_true", help="multi-GPU: convert to int16 on the device and gather that (half the bytes)")
+    ap.add_argument("--chunk-frames", type=int, default=0,
+                    help="run the vocoder in windows of this many frames (vits_process_opts.vocoder_chunk_frames); 0 = whole utterance")
     ap.add_argument("--single-pass", action="store_true",
                     help="instrumented (serialised) warmup + timed region only, no second pass: every launch of the run is then one "
                          "the HIP events timed, which is what a rocprofv3 --kernel-trace of this command is compared against")
@@ -132,10 +135,12 @@ def main():
 
     def step(profile=False):
         _, lengths, frames = model.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_seed, fixed_duration=args.pinned,
-                                                 out_device=out.data_ptr(), out_device_stride=cap, skip_host_copy=True)
+                                                 out_device=out.data_ptr(), out_device_stride=cap, skip_host_copy=True,
+                                                 vocoder_chunk_frames=args.chunk_frames)
         if world > 1:
             # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
-            mg.gather_pcm(out, torch.from_numpy(lengths).cuda())
+            lens_d = torch.from_numpy(lengths).cuda()
+            mg.gather_pcm(mg.to_pcm16(pkg, out, lens_d) if args.pcm16 else out, lens_d)
         return lengths, frames
 
     def fence():
@@ -192,7 +197,7 @@ def main():
                                    f"{'predicted' if not args.pinned else 'pinned %d frames/id' % args.pinned} durations, mode={args.mode}",
                        "batch_per_gpu": B, "ids_per_utterance": T, "frames_per_utterance_mean": float(np.mean(frames)),
                        "samples_per_step": total_samples // args.steps, "sampling_rate": sr, "parallelism": f"utterance-sharded x{world}",
-                       "pcm_destination": "device (HBM)"},
+                       "pcm_destination": "device (HBM)", "vocoder_chunk_frames": args.chunk_frames},
             "rtf": elapsed / (total_samples / float(sr)), "rtf_22050": elapsed / (total_samples / 22050.0),
             "algorithmic_tflops": flops_step * args.steps / elapsed / 1e12,
             "frac_fp32_peak_whole_path": flops_step * args.steps / elapsed / 1e12 / (PEAK_F32_TFLOPS * world),

@@ -77,8 +77,12 @@ VITS_API int vits_model_get_mode(const vits_model* model);
 /* Re-seed the reference noise stream (the reference never does: default seed 1, vits.cpp:31). */
 VITS_API void vits_reference_noise_seed(uint32_t seed);
 
+/* Streaming sink: `pcm` points at samples [offset, offset+n) of utterance `utt` (host memory owned by the library,
+ * valid during the call only). Chunks of one utterance arrive in order and tile it exactly. */
+typedef int (*vits_chunk_callback)(void* user, int32_t utt, size_t offset, const float* pcm, size_t n);
+
 typedef struct vits_process_opts {
-    uint32_t struct_size;        /* = sizeof(vits_process_opts) */
+    uint32_t struct_size;       /* = sizeof(vits_process_opts) */
     int32_t mode;                /* VITS_MODE_*; VITS_MODE_DEFAULT = model default */
     int32_t noise_kind;          /* VITS_NOISE_* */
     uint64_t noise_seed;         /* VITS_NOISE_COUNTER: utterance u uses seed noise_seed + u */
@@ -93,6 +97,17 @@ typedef struct vits_process_opts {
     int32_t async;               /* 1: return without synchronising the stream (requires skip_host_copy and
                                     fixed_duration>0, the only case with no data-dependent host read);
                                     call vits_model_sync() before touching out_device */
+    /* ---- long-form / streaming (the reference cannot run 1024-id inputs at all: its 512 MB
+     * arena at vits.cpp:1145 overflows) ---- */
+    int32_t vocoder_chunk_frames; /* >0: run HiFiGAN over windows of this many frames (plus the exact receptive-
+                                     field halo on both sides) instead of the whole utterance: activation memory is
+                                     bounded by the window, and the PCM is BIT-IDENTICAL to the unchunked result.
+                                     Ignored with collect_taps. 0 = whole utterance. */
+    int32_t reserved0;
+    vits_chunk_callback on_chunk; /* optional: called on the calling thread as each window's PCM reaches the host,
+                                     while the device already works on the next windows (needs vocoder_chunk_frames>0
+                                     and a host copy, i.e. skip_host_copy=0). Non-zero return aborts the call. */
+    void* on_chunk_user;
 } vits_process_opts;
 
 typedef struct vits_batch_result {
@@ -198,6 +213,12 @@ VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, 
 
 /* ---- PCM16 / WAV sink (reference driver test/main.cpp:23-63: clamp to [-1,1], * 32767, truncate; 16 kHz mono) ------ */
 VITS_API void vits_pcm16_from_float(const float* pcm, size_t n, int16_t* out);
+/* The same conversion on the device, row by row: src [rows][src_stride] fp32 -> dst [rows][dst_stride] int16, the first
+ * `cols` samples of each row (or lengths[r] of them when `lengths`, a DEVICE int64 array, is given). All pointers are
+ * device pointers; runs on `hip_stream` (a hipStream_t, NULL = the default stream) without synchronising. Halves the
+ * bytes of the multi-GPU PCM gather and of the host copy. Returns 0 on success. */
+VITS_API int vits_pcm16_from_float_device(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride,
+                                          const int64_t* lengths, int32_t rows, int64_t cols, void* hip_stream);
 /* Writes a canonical 44-byte-header RIFF/WAVE file exactly like test/main.cpp:36-60. Returns 0 on success. */
 VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int32_t sample_rate);
 

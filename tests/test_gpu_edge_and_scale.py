@@ -132,3 +132,41 @@ def test_device_output_buffer_and_async(pkg, full_model):
             full_model.process_batch(ids, out_device=dev.value, out_device_stride=10, skip_host_copy=True)
     finally:
         hip.hipFree(dev)
+
+
+def test_device_pcm16_matches_the_host_conversion(pkg):
+    """vits_pcm16_from_float_device == vits_pcm16_from_float (the reference driver's clamp * 32767 truncate, test/main.cpp:31-33)
+    bit for bit, on aligned and unaligned rows, with and without per-row lengths."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    pkg.lib()  # the library picks the device
+    rng = np.random.default_rng(5)
+    rows, stride = 3, 4104
+    src = (rng.standard_normal((rows, stride)) * 0.7).astype(np.float32)
+    src[0, :6] = [1.0, -1.0, 1.5, -1.5, 0.99999, -3e-5]
+    lens = np.array([4104, 2049, 7], np.int64)
+    bufs = [C.c_void_p() for _ in range(3)]
+    assert hip.hipMalloc(C.byref(bufs[0]), src.nbytes + 64) == 0
+    assert hip.hipMalloc(C.byref(bufs[1]), rows * stride * 2 + 64) == 0
+    assert hip.hipMalloc(C.byref(bufs[2]), lens.nbytes) == 0
+    try:
+        hip.hipMemcpy(bufs[2], lens.ctypes.data, lens.nbytes, 1)
+        for shift in (0, 4):  # second pass: rows start 4 bytes off a 16-byte boundary -> scalar path
+            for use_lens in (False, True):
+                hip.hipMemcpy(bufs[0].value + shift, src.ctypes.data, src.nbytes, 1)
+                hip.hipMemset(bufs[1], 0, rows * stride * 2 + 64)
+                pkg.pcm16_device(bufs[0].value + shift, stride, bufs[1].value + shift // 2 * 2, stride, rows, stride,
+                                 lengths_ptr=bufs[2].value if use_lens else None)
+                out = np.zeros((rows, stride), np.int16)
+                assert hip.hipMemcpy(out.ctypes.data, bufs[1].value + shift // 2 * 2, out.nbytes, 2) == 0  # synchronises
+                for r in range(rows):
+                    n = int(lens[r]) if use_lens else stride
+                    assert np.array_equal(out[r, :n], pkg.pcm16(src[r, :n]))
+                    assert not out[r, n:].any()
+    finally:
+        for b in bufs:
+            hip.hipFree(b)

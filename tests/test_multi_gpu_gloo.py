@@ -20,20 +20,24 @@ def _load_multi_gpu():
     return mod
 
 
-def _fake_pcm(utt, length, cap):
+def _fake_pcm(utt, length, cap, dtype="float32"):
+    if dtype == "int16":  # what mg.to_pcm16 hands to the gather on the GPU (half the bytes)
+        row = torch.zeros(cap, dtype=torch.int16)
+        row[:length] = ((torch.arange(length) * 7 + 1000 * utt) % 65536 - 32768).to(torch.int16)
+        return row
     row = torch.zeros(cap)
     row[:length] = torch.arange(length, dtype=torch.float32) * 1e-3 + utt
     return row
 
 
-def _worker(rank, world, port, total, cap, q):
+def _worker(rank, world, port, total, cap, q, dtype="float32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mg = _load_multi_gpu()
     lo, hi = mg.shard_range(total, world, rank)
     lengths = torch.tensor([100 + 37 * u for u in range(lo, hi)], dtype=torch.int64)
-    pcm = torch.stack([_fake_pcm(u, int(lengths[i]), cap) for i, u in enumerate(range(lo, hi))])
+    pcm = torch.stack([_fake_pcm(u, int(lengths[i]), cap, dtype) for i, u in enumerate(range(lo, hi))])
     out, all_len = mg.gather_pcm(pcm, lengths)
     q.put((rank, out.numpy().copy(), all_len.numpy().copy()))  # numpy: pickled by value (torch tensors travel as fds)
     dist.barrier()
@@ -52,14 +56,15 @@ def test_shard_range_partitions_everything():
 
 
 @pytest.mark.timeout(120)
-def test_ragged_pcm_all_gather_world2():
+@pytest.mark.parametrize("dtype", ["float32", "int16"])
+def test_ragged_pcm_all_gather_world2(dtype):
     world, total, cap = 2, 8, 1024
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, cap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, cap, q, dtype)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=100) for _ in range(world)]
@@ -71,7 +76,7 @@ def test_ragged_pcm_all_gather_world2():
     for rank, out, all_len in results:
         out, all_len = torch.from_numpy(out), torch.from_numpy(all_len)
         assert torch.equal(all_len, want_len)
-        assert out.shape == (total, smax)
+        assert out.shape == (total, smax) and str(out.dtype) == "torch." + dtype
         for u in range(total):
-            assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap)[: want_len[u]])
-            assert float(out[u, want_len[u]:].abs().sum()) == 0.0
+            assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap, dtype)[: want_len[u]])
+            assert float(out[u, want_len[u]:].float().abs().sum()) == 0.0

@@ -31,12 +31,16 @@ EXPORTED_SYMBOLS = [
     "vits_model_weight_bytes", "vits_model_get_tap", "vits_synth_model_bytes", "vits_free_bytes",
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
-    "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16",
+    "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
 ]
 
 
 class VitsResult(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_float)), ("size", C.c_size_t)]
+
+
+# int on_chunk(void* user, int32 utt, size_t offset, const float* pcm, size_t n)  (include/vits.h vits_chunk_callback)
+ChunkCallback = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_size_t, C.POINTER(C.c_float), C.c_size_t)
 
 
 class ProcessOpts(C.Structure):
@@ -45,6 +49,7 @@ class ProcessOpts(C.Structure):
         ("noise_dur", C.c_void_p), ("noise_prior", C.c_void_p), ("noise_prior_stride", C.c_int64),
         ("fixed_duration", C.c_int32), ("collect_taps", C.c_int32), ("out_device", C.c_void_p),
         ("out_device_stride", C.c_int64), ("skip_host_copy", C.c_int32), ("async_", C.c_int32),
+        ("vocoder_chunk_frames", C.c_int32), ("reserved0", C.c_int32), ("on_chunk", ChunkCallback), ("on_chunk_user", C.c_void_p),
     ]
 
 
@@ -290,8 +295,10 @@ class Model:
 
     def process_batch(self, ids, id_lengths=None, mode=MODE_DEFAULT, noise_kind=NOISE_COUNTER, noise_seed=4321,
                       noise_dur=None, noise_prior=None, fixed_duration=0, collect_taps=False, out_device=None,
-                      out_device_stride=0, skip_host_copy=False, async_=False):
-        """ids: int32 [B, id_stride]. Returns (list of per-utterance PCM arrays or None, lengths, frames)."""
+                      out_device_stride=0, skip_host_copy=False, async_=False, vocoder_chunk_frames=0, on_chunk=None):
+        """ids: int32 [B, id_stride]. Returns (list of per-utterance PCM arrays or None, lengths, frames).
+        vocoder_chunk_frames > 0 runs the vocoder window by window (bit-identical PCM, bounded activations);
+        on_chunk(utt, offset, pcm ndarray) is then called as each window's samples reach the host (return True to abort)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         if ids.ndim == 1:
             ids = ids[None, :]
@@ -307,8 +314,20 @@ class Model:
         o.out_device = out_device
         o.out_device_stride = out_device_stride
         o.skip_host_copy, o.async_ = int(skip_host_copy), int(async_)
+        o.vocoder_chunk_frames = int(vocoder_chunk_frames)
+        cb_error = []
+        if on_chunk is not None:
+            def _cb(_user, utt, offset, pcm, n):
+                try:
+                    return 1 if on_chunk(int(utt), int(offset), np.ctypeslib.as_array(pcm, shape=(n,)).copy()) else 0
+                except BaseException as e:  # never let an exception unwind through the C frames
+                    cb_error.append(e)
+                    return 1
+            o.on_chunk = ChunkCallback(_cb)
         res = BatchResult()
         if lib().vits_model_process_batch(self._h, _ptr(ids), _ptr(lens), B, stride, C.byref(o), C.byref(res)) != 0:
+            if cb_error:
+                raise cb_error[0]
             raise VitsError(last_error())
         try:
             lengths = np.ctypeslib.as_array(res.lengths, shape=(B,)).copy()
@@ -402,6 +421,16 @@ def pcm16(pcm):
     out = np.zeros(pcm.size, np.int16)
     lib().vits_pcm16_from_float(_ptr(pcm), pcm.size, _ptr(out))
     return out
+
+
+def pcm16_device(src_ptr, src_stride, dst_ptr, dst_stride, rows, cols, lengths_ptr=None, stream=None):
+    """Device fp32 -> int16 rows (vits_pcm16_from_float_device). All pointers are integer device addresses; lengths_ptr
+    (optional) is a device int64 [rows] array; stream a hipStream_t value (None = default stream). Asynchronous."""
+    f = lib().vits_pcm16_from_float_device
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    f.restype = C.c_int
+    if f(src_ptr, src_stride, dst_ptr, dst_stride, lengths_ptr, rows, cols, stream) != 0:
+        raise VitsError(last_error())
 
 
 def write_wav16(path, pcm, sample_rate=16000):

@@ -274,6 +274,22 @@ VITS_API void vits_pcm16_from_float(const float* pcm, size_t n, int16_t* out) {
     for (size_t i = 0; i < n; ++i) out[i] = static_cast<int16_t>(std::max(-1.0f, std::min(1.0f, pcm[i])) * 32767);
 }
 
+VITS_API int vits_pcm16_from_float_device(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride, const int64_t* lengths, int32_t rows,
+                                          int64_t cols, void* hip_stream) {
+    VITS_TRY
+    if ((!src || !dst) && rows > 0 && cols > 0) {
+        set_err("null argument");
+        return -1;
+    }
+    const hipError_t e = vits::launch_pcm16(src, src_stride, dst, dst_stride, lengths, rows, cols, (hipStream_t)hip_stream);
+    if (e != hipSuccess) {
+        set_err(std::string("pcm16 kernel launch failed: ") + hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+    VITS_CATCH(-1)
+}
+
 // reference: test/main.cpp:23-63 (struct WAVHeader + write_wav)
 VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int32_t sample_rate) {
     VITS_TRY

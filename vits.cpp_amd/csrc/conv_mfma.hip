@@ -93,7 +93,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     int ncols;
     if (EPI == EPI_CONVT) ncols = len_in + 1;  // q in [0, L_in]: the last phase group only sees the m=1 tap
     else ncols = p.len_out ? p.len_out[b] : p.t_out;
-    if (t0 >= ncols) return;
+    if (t0 >= ncols || len_in <= 0) return;  // (an utterance that has no frames in this vocoder window has length 0)
 
     const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
     constexpr int XWP = (BN + SPAN_C + 63) / 64 * 64;  // DB: rows padded to whole 64-float DMA pieces

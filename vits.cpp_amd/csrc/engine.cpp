@@ -163,6 +163,7 @@ Engine::~Engine() {
         if (s) hipStreamSynchronize(s);
     clear_taps();
     for (void* p : owned_) hipFree(p);
+    if (pinned_) hipHostFree(pinned_);
     if (ev_fork_) hipEventDestroy(ev_fork_);
     for (hipEvent_t e : ev_done_)
         if (e) hipEventDestroy(e);
@@ -436,6 +437,19 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         dec_post_k_ = (int)pw->ne[0];
         dec_post_cin_ = (int)pw->ne[1];
         if (!(dec_post_w_ = upload_tensor(f, "decoder.conv_post.weight", err))) return false;
+        // one-sided receptive field of the vocoder, walked from the waveform back to the frames: conv_post, then per stage
+        // the deepest resblock chain (k/2 * (d + 1) per conv pair) and the transposed conv (K taps over stride s)
+        int h = dec_post_k_ / 2;
+        for (int i = (int)ups_.size() - 1; i >= 0; --i) {
+            int reach = 0;
+            for (const ResBlockW& R : ups_[i].rbs) {
+                int r = 0;
+                for (int d : R.dil) r += (R.k / 2) * (d + 1);
+                reach = std::max(reach, r);
+            }
+            h = (h + reach + ups_[i].k + ups_[i].stride - 1) / ups_[i].stride + 1;
+        }
+        halo_frames_ = h + dec_pre_.kt / 2 + 1;
     }
     if (hipDeviceSynchronize() != hipSuccess) {
         err = "device error while uploading weights";
@@ -778,23 +792,51 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         snapshot("durations", d, 1, Tmax, B, tlen);
     }
 
+    // ---- vocoder windows (long-form / streaming, vits.h vocoder_chunk_frames) ------------------------------------
+    // Window w owns frames [f0, f1) and computes frames [lo, hi) = the owned range widened by the vocoder's receptive
+    // field (halo_frames_): every sample it emits sees exactly the inputs it sees in a whole-utterance run, in the same
+    // order of accumulation, so the PCM is bit-identical while the activations are bounded by the window.
+    struct Win {
+        int f0, f1, lo, hi;
+    };
+    std::vector<Win> wins;
+    {
+        const int W = (o.vocoder_chunk_frames > 0 && !o.collect_taps && o.vocoder_chunk_frames < Lmax) ? o.vocoder_chunk_frames : 0;
+        if (!W) wins.push_back({0, Lmax, 0, Lmax});
+        else
+            for (int f0 = 0; f0 < Lmax; f0 += W) {
+                const int f1 = std::min(Lmax, f0 + W);
+                wins.push_back({f0, f1, std::max(0, f0 - halo_frames_), std::min(Lmax, f1 + halo_frames_)});
+            }
+    }
+    const bool windowed = wins.size() > 1;
+    if (o.on_chunk && (!windowed || o.skip_host_copy)) {
+        err = "on_chunk needs vocoder_chunk_frames > 0 (smaller than the utterance), no collect_taps and a host copy";
+        return -1;
+    }
+    int Lw_max = 0;
+    for (const Win& w : wins) Lw_max = std::max(Lw_max, w.hi - w.lo);
+    const int M = smul[n_up];  // samples per frame
+
     // ---- stage two buffers -------------------------------------------------------------------------------------
-    const int ls = round_up(Lmax, 32);
-    size_t big = 0;  // floats of the largest vocoder activation
+    const int ls = round_up(Lmax, 32), lws = round_up(Lw_max, 32);
+    size_t big = 0;  // floats of the largest vocoder activation (of one window)
     std::vector<int> sts(n_up + 1);
-    for (int i = 0; i <= n_up; ++i) sts[i] = round_up(smax[i], 32);
+    for (int i = 0; i <= n_up; ++i) sts[i] = round_up(Lw_max * smul[i] + sadd[i], 32);
     for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
     struct S2 {
         float *zp, *noise, *hout, *gate, *h0, *bu, *by[3], *bt[3], *bs, *pre, *wave;
+        int* win_lens;  // [window][n_up + 2][B]: stage lengths of each utterance inside the window, then its emit end
     } s2;
     const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
-    const int S_stride = sts[n_up];
+    const int S_stride = round_up(smax[n_up], 32);
     auto layout2 = [&](Arena& a) {
         s2.zp = a.alloc<float>((size_t)B * F * ls);
         s2.noise = need_noise_buf ? a.alloc<float>((size_t)B * F * ls) : nullptr;
         s2.hout = a.alloc<float>((size_t)B * 2 * H * ls);
         s2.gate = a.alloc<float>((size_t)B * H * ls);
-        s2.h0 = a.alloc<float>((size_t)B * hp.up_init * ls);
+        s2.h0 = a.alloc<float>((size_t)B * hp.up_init * lws);
+        s2.win_lens = windowed ? a.alloc<int>(wins.size() * (size_t)(n_up + 2) * B) : nullptr;
         s2.bu = a.alloc<float>(big);
         for (int j = 0; j < 3; ++j) {
             // one (y, t) pair per concurrently running resblock
@@ -816,8 +858,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         HIP_OK(a2_.reserve(need));
         layout2(a2_);
     }
-    const int* d_len[8];
-    for (int i = 0; i <= n_up && i < 8; ++i) d_len[i] = s1.stage_lens + (size_t)i * B;
+    const int* d_len_full[8];
+    for (int i = 0; i <= n_up && i < 8; ++i) d_len_full[i] = s1.stage_lens + (size_t)i * B;
+    const int* const* d_len = d_len_full;  // (the vocoder loop below shadows this with window-local lengths)
 
     // ---- prior sampling through the alignment (vits.cpp:1028-1064) -------------------------------------------
     TensorRef zp = TR(s2.zp, F, ls), noise = TR(s2.noise, F, ls);
@@ -906,16 +949,77 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         wave_dst = (float*)o.out_device;
         wave_stride = o.out_device_stride;
     }
-    {
-        TensorRef h0 = TR(s2.h0, hp.up_init, ls);
+    std::vector<hipEvent_t> chunk_ev;
+    struct EvGuard {
+        std::vector<hipEvent_t>& v;
+        ~EvGuard() {
+            for (hipEvent_t e : v) hipEventDestroy(e);
+        }
+    } chunk_ev_guard{chunk_ev};
+    float* host_pcm = nullptr;  // pinned [B][smax] staging of the streamed PCM
+    const size_t out_stride = (size_t)smax[n_up];
+    if (windowed) {
+        // per window and utterance: frames inside the window -> stage lengths (0 everywhere when the utterance has none),
+        // and the end of the sample range this window emits for it (window-local index)
+        std::vector<int> wl(wins.size() * (size_t)(n_up + 2) * B, 0);
+        for (size_t w = 0; w < wins.size(); ++w)
+            for (int b = 0; b < B; ++b) {
+                const Win& wn = wins[w];
+                const int lf = std::min(frames[b], wn.hi) - wn.lo;
+                int* row = wl.data() + w * (size_t)(n_up + 2) * B;
+                if (lf <= 0) continue;
+                for (int i = 0; i <= n_up; ++i) row[(size_t)i * B + b] = lf * smul[i] + sadd[i];
+                if (frames[b] > wn.f0)  // owns frames here; the window holding the utterance's end also emits its tail (Q1)
+                    row[(size_t)(n_up + 1) * B + b] = frames[b] <= wn.f1 ? (frames[b] - wn.lo) * M + sadd[n_up] : (wn.f1 - wn.lo) * M;
+            }
+        HIP_OK(hipMemcpyAsync(s2.win_lens, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // wl goes out of scope
+        if (o.on_chunk) {
+            const size_t need = (size_t)B * out_stride * sizeof(float);
+            if (need > pinned_cap_) {
+                if (pinned_) hipHostFree(pinned_);
+                pinned_ = nullptr;
+                pinned_cap_ = 0;
+                HIP_OK(hipHostMalloc((void**)&pinned_, need, hipHostMallocDefault));
+                pinned_cap_ = need;
+            }
+            host_pcm = (float*)pinned_;
+        }
+    }
+    // hands the finished window `w` to the caller's sink (blocks until its PCM is on the host)
+    auto deliver = [&](size_t w) -> int {
+        const Win& wn = wins[w];
+        if (hipEventSynchronize(chunk_ev[w]) != hipSuccess) return -1;
+        for (int b = 0; b < B; ++b) {
+            if (frames[b] <= wn.f0) continue;
+            const size_t off = (size_t)wn.f0 * M;
+            const size_t end = frames[b] <= wn.f1 ? (size_t)slen[n_up][b] : (size_t)wn.f1 * M;
+            if (o.on_chunk(o.on_chunk_user, b, off, host_pcm + (size_t)b * out_stride + off, end - off)) return 1;
+        }
+        return 0;
+    };
+    for (size_t wi = 0; wi < wins.size(); ++wi) {
+        const Win& wn = wins[wi];
+        const int Lw = wn.hi - wn.lo;
+        const int* d_len[8];
+        std::vector<int> smax(n_up + 1);  // (shadows the whole-utterance maxima: everything below is window-local)
+        for (int i = 0; i <= n_up && i < 8; ++i) {
+            d_len[i] = windowed ? s2.win_lens + (wi * (size_t)(n_up + 2) + i) * B : d_len_full[i];
+            smax[i] = Lw * smul[i] + sadd[i];
+        }
+        const int* emit_hi = windowed ? s2.win_lens + (wi * (size_t)(n_up + 2) + n_up + 1) * B : nullptr;
+        const int emit_lo = (wn.f0 - wn.lo) * M;
+        TensorRef zwin = zp;
+        zwin.p += wn.lo;
+        TensorRef h0 = TR(s2.h0, hp.up_init, lws);
         {
             ConvCall c;
-            c.x = zp;
+            c.x = zwin;
             c.y = h0;
             c.len_in = d_len[0];
             c.len_out = d_len[0];
             c.batch = B;
-            c.t_in = c.t_out = Lmax;
+            c.t_in = c.t_out = Lw;
             c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
             HIP_OK(conv("hifigan_conv_pre", dec_pre_, c));
         }
@@ -1003,17 +1107,41 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         pre.bs = S_stride;
         pre.cs = S_stride;
         TensorRef wv;
-        wv.p = wave_dst;
+        wv.p = wave_dst + (int64_t)wn.lo * M;  // window-local sample 0 is global sample lo * M
         wv.bs = wave_stride;
         wv.cs = (int)wave_stride;
         prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)B * smax[n_up], 0, stream);
-        HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, refmode ? hp.lrelu : 0.01f, pre, wv, d_len[n_up], B, smax[n_up], stream));  // Q2
+        HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, refmode ? hp.lrelu : 0.01f, pre, wv, d_len[n_up], B, smax[n_up], stream, emit_lo, emit_hi));  // Q2
         prof.end(stream);
+        if (o.on_chunk) {
+            // ship this window's samples to the host behind the kernels, then serve the PREVIOUS window's callbacks while
+            // the device works on this one
+            // (+ the no-crop tail of utterances that end inside this window, Q1; the same columns of longer utterances are not
+            // final yet and travel again with the next window)
+            const size_t g0 = (size_t)wn.f0 * M, g1 = std::min(out_stride, (size_t)wn.f1 * M + (size_t)sadd[n_up]);
+            HIP_OK(hipMemcpy2DAsync(host_pcm + g0, out_stride * 4, wave_dst + g0, (size_t)wave_stride * 4, (g1 - g0) * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+            hipEvent_t ev;
+            HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            chunk_ev.push_back(ev);
+            HIP_OK(hipEventRecord(ev, stream));
+            if (wi > 0)
+                if (int rc = deliver(wi - 1)) {
+                    hipStreamSynchronize(stream);
+                    err = rc > 0 ? "aborted by the on_chunk callback" : "hipEventSynchronize failed";
+                    return -1;
+                }
+        }
         if (o.collect_taps) {
             snapshot("pre_tanh", pre, 1, smax[n_up], B, slen[n_up]);
             snapshot("waveform", wv, 1, smax[n_up], B, slen[n_up]);
         }
     }
+    if (o.on_chunk)
+        if (int rc = deliver(wins.size() - 1)) {
+            hipStreamSynchronize(stream);
+            err = rc > 0 ? "aborted by the on_chunk callback" : "hipEventSynchronize failed";
+            return -1;
+        }
 
     // ---- results ------------------------------------------------------------------------------------------------
     if (out) {
@@ -1028,7 +1156,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         out->data = nullptr;
         if (!o.skip_host_copy) {
             out->data = new float[(size_t)B * out->stride];
-            HIP_OK(hipMemcpy2DAsync(out->data, out->stride * 4, wave_dst, (size_t)wave_stride * 4, out->stride * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+            if (o.on_chunk) std::memcpy(out->data, host_pcm, sizeof(float) * (size_t)B * out->stride);  // already streamed to the host
+            else
+                HIP_OK(hipMemcpy2DAsync(out->data, out->stride * 4, wave_dst, (size_t)wave_stride * 4, out->stride * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
         }
     }
     if (!want_async) {

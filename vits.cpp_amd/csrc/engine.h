@@ -135,7 +135,10 @@ class Engine {
     // three streams so that the tail of one kernel's grid overlaps the head of another's. side_[j-1] carries resblock j.
     hipStream_t side_[2] = {nullptr, nullptr};
     hipEvent_t ev_fork_ = nullptr, ev_done_[3] = {nullptr, nullptr, nullptr};
-    int rb_streams_ = 3;  // VITS_RB_STREAMS=1 serialises everything on the main stream
+    int rb_streams_ = 3;
+    int halo_frames_ = 0;      // receptive field of the vocoder in frames, one side (computed at load)
+    void* pinned_ = nullptr;   // grow-only pinned staging for streamed PCM
+    size_t pinned_cap_ = 0;  // VITS_RB_STREAMS=1 serialises everything on the main stream
     std::map<std::string, Tap> taps_;
     int tap_batch_ = 0;
 

@@ -83,7 +83,9 @@ hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_s
                      uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s);
+// fp32 -> int16 PCM rows on the device (test/main.cpp:31-33); lens (device, optional) limits each row
+hipError_t launch_pcm16(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride, const int64_t* lens, int rows, int64_t cols, hipStream_t s);
 hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch,
-                            int tmax, hipStream_t s);
+                            int tmax, hipStream_t s, int emit_lo = 0, const int* emit_hi = nullptr);
 
 }  // namespace vits

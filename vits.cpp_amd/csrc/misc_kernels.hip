@@ -604,19 +604,22 @@ hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_s
 // tile would be 31/32 empty, so this is a VALU kernel; HBM-bound (reads C floats per output sample).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t x_bs, int x_cs, const float* w, int cin, int k, float slope, float* pre,
-                                                        int64_t p_bs, float* wave, int64_t w_bs, const int* lens, int tmax) {
+                                                        int64_t p_bs, float* wave, int64_t w_bs, const int* lens, int tmax, int emit_lo, const int* emit_hi) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [cin][k]
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : tmax;
-    const int t0 = blockIdx.x * 1024;
-    if (t0 >= len) return;
+    // windowed vocoder (engine.cpp): only samples [emit_lo, emit_hi[b]) of this window are the utterance's own; the rest
+    // is halo, computed from a cut edge and owned by a neighbouring window
+    const int hi = emit_hi ? min(emit_hi[b], len) : len;
+    const int t0 = emit_lo + blockIdx.x * 1024;
+    if (t0 >= hi) return;
     for (int i = threadIdx.x; i < cin * k; i += 256) sm[i] = w[i];
     __syncthreads();
     const int pad = (k - 1) / 2;
     const float* xb = x + (int64_t)b * x_bs;
     for (int u = 0; u < 4; ++u) {
         const int t = t0 + u * 256 + threadIdx.x;
-        if (t >= len) continue;
+        if (t >= hi) continue;
         float a = 0.f;
         for (int c = 0; c < cin; ++c) {
             const float* xr = xb + (int64_t)c * x_cs;
@@ -633,10 +636,46 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
 }
 
 hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch, int tmax,
-                            hipStream_t s) {
-    dim3 grid((tmax + 1023) / 1024, batch);
+                            hipStream_t s, int emit_lo, const int* emit_hi) {
+    dim3 grid((std::max(tmax - emit_lo, 1) + 1023) / 1024, batch);
     hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * cin * k, s, x.p, x.bs, x.cs, w, cin, k, slope, pre_tanh.p, pre_tanh.bs, wave.p, wave.bs,
-                       lens, tmax);
+                       lens, tmax, emit_lo, emit_hi);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 PCM -> int16 PCM on the device (test/main.cpp:31-33: static_cast<short>(clamp(x, -1, 1) * 32767)), so that the
+// multi-GPU gather and the host copy move half the bytes. Pure streaming kernel: 8 samples per thread when both rows
+// are 16-byte aligned (2 x dwordx4 in, 1 x dwordx4 out), scalar otherwise.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ short pcm16_of(float x) { return static_cast<short>(fmaxf(-1.0f, fminf(1.0f, x)) * 32767); }
+
+__global__ __launch_bounds__(256) void pcm16_kernel(const float* src, int64_t s_bs, short* dst, int64_t d_bs, const int64_t* lens, int64_t cols, int vec) {
+    const int b = blockIdx.y;
+    const int64_t n = lens ? min(lens[b], cols) : cols;
+    const float* sr = src + (int64_t)b * s_bs;
+    short* dr = dst + (int64_t)b * d_bs;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    if (vec && i0 + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(sr + i0), c = *reinterpret_cast<const float4*>(sr + i0 + 4);
+        union {
+            short h[8];
+            int4 v;
+        } o;
+        o.h[0] = pcm16_of(a.x), o.h[1] = pcm16_of(a.y), o.h[2] = pcm16_of(a.z), o.h[3] = pcm16_of(a.w);
+        o.h[4] = pcm16_of(c.x), o.h[5] = pcm16_of(c.y), o.h[6] = pcm16_of(c.z), o.h[7] = pcm16_of(c.w);
+        *reinterpret_cast<int4*>(dr + i0) = o.v;
+    } else {
+        for (int64_t i = i0; i < min(i0 + 8, n); ++i) dr[i] = pcm16_of(sr[i]);
+    }
+}
+
+hipError_t launch_pcm16(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride, const int64_t* lens, int rows, int64_t cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const int vec = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (src_stride & 3) == 0 && (dst_stride & 7) == 0;
+    dim3 grid((unsigned)((cols + 2047) / 2048), rows);
+    hipLaunchKernelGGL(pcm16_kernel, grid, dim3(256), 0, s, src, src_stride, reinterpret_cast<short*>(dst), dst_stride, lens, cols, vec);
     return hipGetLastError();
 }
 

@@ -17,8 +17,22 @@ def shard_range(total, world, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def to_pcm16(pkg, pcm, lengths=None):
+    """fp32 PCM [B, cap] on the GPU -> int16 [B, cap] with the library's device kernel (vits_pcm16_from_float_device, the
+    reference driver's conversion test/main.cpp:31-33), on torch's current stream. Halves the bytes gather_pcm moves."""
+    assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.stride(1) == 1
+    out = torch.zeros(pcm.shape, dtype=torch.int16, device=pcm.device)
+    lp = None
+    if lengths is not None:
+        lengths = lengths.to(device=pcm.device, dtype=torch.int64).contiguous()
+        lp = lengths.data_ptr()
+    pkg.pcm16_device(pcm.data_ptr(), pcm.stride(0), out.data_ptr(), out.stride(0), pcm.shape[0], pcm.shape[1], lengths_ptr=lp,
+                     stream=torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 def gather_pcm(pcm, lengths):
-    """pcm: [B, cap] fp32 on this rank's device (rows valid up to lengths[b]); lengths: [B] int64 (same device).
+    """pcm: [B, cap] fp32 (or int16, see to_pcm16) on this rank's device (rows valid up to lengths[b]); lengths: [B] int64 (same device).
     Returns (gathered [world*B, smax] fp32, all_lengths [world*B] int64) on every rank; world == 1 is a no-op view."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         smax = int(lengths.max().item())
@@ -34,5 +48,9 @@ def gather_pcm(pcm, lengths):
     dist.all_gather_into_tensor(all_len, lengths.contiguous())
     send = pcm[:, :smax].contiguous()
     out = torch.empty((world * B, smax), dtype=pcm.dtype, device=pcm.device)
-    dist.all_gather_into_tensor(out, send)
+    if pcm.dtype == torch.float32:
+        dist.all_gather_into_tensor(out, send)
+    else:
+        # an all-gather only copies: int16 (which neither RCCL nor gloo has as an element type) travels as bytes
+        dist.all_gather_into_tensor(out.view(torch.uint8), send.view(torch.uint8))
     return out, all_len
