@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
+#include <map>
+#include <array>
 #ifndef KT_
 #define KT_ 11
 #endif
@@ -55,6 +58,108 @@ int main() {
     hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     double fl = 2.0 * C * C * K * (double)B * T;
+    {
+        int nb_occ = -1;
+#if CIN_ <= 32
+        auto kfn = conv_mfma_kernel<KT_, DIL_, false, 1, 4, 1, 1, EPI_STD>;
+        const size_t lds = 32 * (128 + (KT_ - 1) * DIL_) * 4;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_occ, kfn, 256, lds);
+#else
+        auto kfn = conv_mfma_kernel<KT_, DIL_, true, 2, 2, 2, 2, EPI_STD>;
+        const size_t lds = 2 * 32 * ((128 + (KT_ - 1) * DIL_ + 3 + 63) / 64 * 64) * 4;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_occ, kfn, 320, lds);
+#endif
+        hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)kfn);
+        printf("128x128 DB kernel: occupancy API says %d blocks/CU at %zu B LDS (%s); numRegs %d, sharedSizeBytes %zu, maxThreadsPerBlock %d\n", nb_occ, lds,
+               hipGetErrorString(oe), fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+    }
+#ifdef VITS_PHASE_TIMING
+    {
+        // per-block phases of the LAST launch: prologue (start -> first tile ready), K loop, epilogue; and how busy the
+        // device was: sum of K-loop time over blocks / (launch span x resident block slots)
+        std::vector<unsigned long long> ph(8 * 65536);
+        hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(vits_phase_buf), ph.size() * 8);
+        const size_t nb = 65536;
+        const int bm = 0, bn = 0;
+        double pro = 0, kl = 0, epi = 0, cyc = 0; unsigned long long tmin = ~0ull, tmax = 0; size_t cnt = 0;
+        std::vector<double> kls;
+        for (size_t i = 0; i < nb; ++i) {
+            const unsigned long long* q = &ph[8 * i];
+            if (!q[0] || !q[3] || q[3] < q[0]) continue;
+            pro += (double)(q[1] - q[0]); kl += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]);
+            kls.push_back((double)(q[2] - q[1]));
+            cyc += (double)(q[5] - q[4]);
+            tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[3]); ++cnt;
+        }
+        {
+            // per-CU view: HW_ID bits [11:8] CU, [12] SH, [15:13] SE (gfx9), XCC_ID low bits; events (+1 at start, -1 at end)
+            std::map<unsigned, std::vector<std::pair<unsigned long long, int>>> percu;
+            unsigned long long tmin0 = ~0ull;
+            for (size_t i = 0; i < nb; ++i)
+                if (ph[8 * i] && ph[8 * i + 3]) tmin0 = std::min(tmin0, ph[8 * i]);
+            for (size_t i = 0; i < nb; ++i) {
+                const unsigned long long* q = &ph[8 * i];
+                if (!q[0] || !q[3] || q[3] < q[0]) continue;
+                const unsigned hw = (unsigned)q[6], xcc = (unsigned)q[7] & 0xf;
+                const unsigned key = (xcc << 16) | ((hw >> 8) & 0xff);
+                percu[key].push_back({q[0], +1});
+                percu[key].push_back({q[3], -1});
+            }
+            double t1 = 0, t2 = 0, t3 = 0, t0 = 0, tc = 0; size_t maxc = 0;
+            for (auto& kv : percu) {
+                auto& ev = kv.second;
+                std::sort(ev.begin(), ev.end());
+                int c = 0;
+                for (size_t e = 0; e + 1 < ev.size(); ++e) {
+                    c += ev[e].second;
+                    const double dt = (double)(ev[e + 1].first - ev[e].first);
+                    (c == 0 ? t0 : c == 1 ? t1 : c == 2 ? t2 : t3) += dt; tc += c * dt;
+                    maxc = std::max(maxc, (size_t)c);
+                }
+            }
+            {
+                // timeline of one CU in the middle of the run: block start / K-loop start / K-loop end / end, us from the first start
+                std::vector<std::array<double, 4>> tl;
+                const unsigned want = percu.begin()->first;
+                for (size_t i = 0; i < nb; ++i) {
+                    const unsigned long long* q = &ph[8 * i];
+                    if (!q[0] || !q[3] || q[3] < q[0]) continue;
+                    const unsigned hw = (unsigned)q[6], xcc = (unsigned)q[7] & 0xf;
+                    if (((xcc << 16) | ((hw >> 8) & 0xff)) != want) continue;
+                    tl.push_back({(q[0] - tmin0) / 100.0, (q[1] - tmin0) / 100.0, (q[2] - tmin0) / 100.0, (q[3] - tmin0) / 100.0});
+                }
+                std::sort(tl.begin(), tl.end());
+                for (size_t i = 8; i < tl.size() && i < 20; ++i) printf("   cu0 block %2zu: start %8.2f  kloop %8.2f .. %8.2f  end %8.2f\n", i, tl[i][0], tl[i][1], tl[i][2], tl[i][3]);
+            }
+            const double tt = t0 + t1 + t2 + t3;
+            printf("per-CU residency over %zu distinct CUs: 0 blocks %.1f %%, 1 block %.1f %%, 2 blocks %.1f %%, >=3 %.1f %% of the time (max %zu, mean %.2f)\n", percu.size(),
+                   100 * t0 / tt, 100 * t1 / tt, 100 * t2 / tt, 100 * t3 / tt, maxc, tc / tt);
+        }
+        {
+            std::vector<unsigned long long> cb(8 * 65536);
+            hipMemcpyFromSymbol(cb.data(), HIP_SYMBOL(vits_chunk_buf), cb.size() * 8);
+            double comp[4] = {0, 0, 0, 0}, bar[4] = {0, 0, 0, 0}; size_t n = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                const unsigned long long* q = &ph[8 * i];
+                if (!q[0] || !q[3] || q[3] < q[0]) continue;
+                unsigned long long prev = q[4];  // K loop start (shader clock)
+                for (int c = 0; c < 4; ++c) {
+                    comp[c] += (double)(cb[8 * i + 2 * c] - prev);
+                    bar[c] += (double)(cb[8 * i + 2 * c + 1] - cb[8 * i + 2 * c]);
+                    prev = cb[8 * i + 2 * c + 1];
+                }
+                ++n;
+            }
+            printf("per chunk (cycles): ");
+            for (int c = 0; c < 4; ++c) printf(" c%d compute %.0f barrier-wait %.0f |", c, comp[c] / n, bar[c] / n);
+            printf(" ideal compute %d\n", KT_ * 16 * 4 * 64);
+        }
+        std::sort(kls.begin(), kls.end());
+        printf("phases over %zu blocks (tile %dx%d), 10 ns ticks -> us: prologue %.2f  k-loop %.2f (p10 %.2f p90 %.2f)  epilogue %.2f; span %.1f us; blocks*life/span = %.1f resident; shader clock in the K loop %.3f GHz, MFMA issue efficiency of the K loop %.3f\n",
+               cnt, bm, bn, pro / cnt / 100, kl / cnt / 100, kls[kls.size() / 10] / 100, kls[kls.size() * 9 / 10] / 100, epi / cnt / 100, (tmax - tmin) / 100.0,
+               (pro + kl + epi) / (double)(tmax - tmin), cyc / (kl * 10.0), (double)cnt * ((CIN_ + 31) / 32) * KT_ * 16 * 4 * 64.0 / cyc);
+    }
+#endif
     printf("C=%d k=%d d=%d T=%d B=%d: %.3f ms  %.1f TFLOP/s  (%s)\n", C, K, DIL_, T, B, ms, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -59,6 +59,8 @@ struct ConvParams {
     int pre_act;
     float slope;
     int post_act;
+    float post_slope;
+    float* y2;  // optional second output: leaky_relu(post_slope) of what goes to y (same strides as y)
     float scale;
     int scale_div;
     int ct_stride, ct_crop;
@@ -73,15 +75,46 @@ struct ConvParams {
 //     issues HBM tile loads itself makes every later weight load wait a full HBM latency (measured: k=3 72 -> 103
 //     TFLOP/s without those stalls). LeakyReLU moves to the B-operand read (max(x, slope*x)), zero padding at the
 //     sequence ends is done by a masked register path in the producer (boundary tiles only).
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/conv_micro.hip): per-block phase timestamps, 100 MHz clock
+__device__ unsigned long long vits_phase_buf[8 * 65536];
+__device__ unsigned long long vits_chunk_buf[8 * 65536];
+__device__ unsigned long long vits_tap_buf[16 * 8192];  // [block < 8192][k-step group]: shader clock inside chunk 1  // shader-clock stamp at the end of chunk c < 8  // [block][0..3] 100 MHz stamps, [4..5] shader-clock stamps of the K loop
+#define VITS_STAMP(k)                                                                                               \
+    do {                                                                                                            \
+        if (tid == 0) {                                                                                             \
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
+            if (lin < 65536) {                                                                                      \
+                vits_phase_buf[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                                   \
+                if ((k) == 1 || (k) == 2) vits_phase_buf[8 * lin + 3 + (k)] = __builtin_amdgcn_s_memtime();         \
+                if ((k) == 0) {                                                                                     \
+                    unsigned hw, xcc;                                                                               \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
+                    vits_phase_buf[8 * lin + 6] = hw;                                                               \
+                    vits_phase_buf[8 * lin + 7] = xcc;                                                              \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#else
+#define VITS_STAMP(k)
+#endif
+
+#ifndef VITS_WAVES_ATTR
+#define VITS_WAVES_ATTR
+#endif
 template <int KT, int DIL, bool DB, int WM, int WN, int MR, int NR, int EPI>
-__global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = WN * NR * 32;
     constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
     constexpr int STEPS = KT * (CK / 8);  // float4 A-fragments (4 MFMA k-steps each) per chunk and row tile
     // DB path: where the fused leaky_relu runs. Short chunks (k <= 3: 12 steps) leave the producer wave no slack, so the
     // compute waves apply it at the B-operand read (max(x, slope*x), ~2 % there); for k >= 5 the producer rewrites the
     // landed tile in place instead (at-read costs 9 % on the k=11 kernels: two VALU ops between every ds_read and its MFMAs)
-    constexpr bool LRELU_AT_READ = KT <= 3;
+#ifndef VITS_LRELU_AT_READ_MAXK
+#define VITS_LRELU_AT_READ_MAXK 3
+#endif
+    constexpr bool LRELU_AT_READ = KT <= VITS_LRELU_AT_READ_MAXK;
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][xw]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -94,15 +127,20 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     if (EPI == EPI_CONVT) ncols = len_in + 1;  // q in [0, L_in]: the last phase group only sees the m=1 tap
     else ncols = p.len_out ? p.len_out[b] : p.t_out;
     if (t0 >= ncols || len_in <= 0) return;  // (an utterance that has no frames in this vocoder window has length 0)
+    VITS_STAMP(0);
 
     const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
-    constexpr int XWP = (BN + SPAN_C + 63) / 64 * 64;  // DB: rows padded to whole 64-float DMA pieces
+    constexpr int XWP = (BN + SPAN_C + 3 + 63) / 64 * 64;  // DB: rows padded to whole 64-float DMA pieces (+3: 16-byte aligned origin)
     const int xw = DB ? XWP : (DIL != 0 ? BN + SPAN_C : p.xw);
     const int dil = DIL != 0 ? DIL : p.dil;
     const int lds_off = DIL != 0 ? (DIL < 0 ? SPAN_C : 0) : p.lds_off;
     const int tile_start = t0 - p.pad_l - lds_off;  // global time of LDS column 0
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
 
+    // DB path: 16-byte aligned rows let the producer stream with dwordx4 LDS-DMA into a tile whose column 0 is the
+    // 4-aligned time below tile_start; the compute waves then read their B operands `shift` floats further right
+    const bool x4 = DB && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0) && ((p.x_cs & 3) == 0);
+    const int shift = x4 ? (tile_start & 3) : 0;
     if constexpr (DB) {
         if (wid == 4) {
             // ------------------------------- producer wave -------------------------------------------------------
@@ -110,28 +148,60 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
             //   producer: fill(0); B0; for c: { fill(c+1) into buffer (c+1)&1; B(c+1) }
             //   compute : B0; for c: { MFMA on buffer c&1; B(c+1) }
             // buffer (c+1)&1 was last read during chunk c-1, which every compute wave finished before B(c).
-            const bool interior = tile_start >= 0 && tile_start + XWP <= len_in;
+            // LDS column 0 holds global time ts = tile_start rounded DOWN to a multiple of 4 (when the rows themselves are
+            // 16-byte aligned): every DMA source address is then 16-byte aligned and one global_load_lds_dwordx4 moves
+            // 1 KB per wave instruction instead of 256 B — the dword version needs 96 issues (~4 us) per 32 x 192 chunk,
+            // which puts the producer on the critical path of the k = 3 kernels (5.7 us of MFMA work per chunk)
+            const int ts = tile_start - shift;
+            const bool interior = ts >= 0 && ts + XWP <= len_in;
             constexpr int NMP = XWP / 64;
             // per-lane clamped time offsets of the NMP 64-column pieces of a row (same for every row and chunk)
             int tcl[NMP];
             bool oob[NMP];
 #pragma unroll
             for (int m = 0; m < NMP; ++m) {
-                const int t = tile_start + lane + 64 * m;
+                const int t = ts + lane + 64 * m;
                 tcl[m] = t < 0 ? 0 : (t < len_in ? t : len_in - 1);
                 oob[m] = t != tcl[m];
+            }
+            // dwordx4 pattern: the tile is a linear array of float4; XW4 float4 per row, 64 per instruction -> the
+            // (row, column) of a lane repeats every P4 instructions, which cover R4 whole rows
+            constexpr int XW4 = XWP / 4;
+            constexpr int G4 = XW4 % 64 == 0 ? 64 : (XW4 % 32 == 0 ? 32 : 16);  // gcd(XW4, 64); XWP is a multiple of 64
+            constexpr int P4 = XW4 / G4, R4 = 64 / G4;
+            int64_t off4[P4];
+#pragma unroll
+            for (int j = 0; j < P4; ++j) {
+                const int g = j * 64 + lane;
+                const int r = g / XW4, c4 = g - r * XW4;
+                int t = ts + 4 * c4;  // multiple of 4
+                const int tlast = (len_in - 1) & ~3;  // last float4 that starts inside the sequence (rows are padded to x4)
+                t = t < 0 ? 0 : (t > tlast ? tlast : t);
+                off4[j] = (int64_t)r * p.x_cs + t;
             }
             auto fill = [&](int c) __attribute__((always_inline)) {
                 float* lbase = xs + (c & 1) * (CK * XWP);
                 // LDS-DMA of the whole 32 x XWP tile from clamped (always valid) addresses ...
-#pragma unroll 4
-                for (int r = 0; r < CK; ++r) {
-                    const int ch = c * CK + r;
-                    const float* src = xb + (int64_t)(ch < p.cin ? ch : p.cin - 1) * p.x_cs;
+                if (x4 && (c + 1) * CK <= p.cin) {
+                    const float* src = xb + (int64_t)(c * CK) * p.x_cs;
+#pragma unroll 2
+                    for (int i = 0; i < CK / R4; ++i) {
 #pragma unroll
-                    for (int m = 0; m < NMP; ++m)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tcl[m]),
-                                                         (__attribute__((address_space(3))) void*)(lbase + r * XWP + 64 * m), 4, 0, 0);
+                        for (int j = 0; j < P4; ++j)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off4[j]),
+                                                             (__attribute__((address_space(3))) void*)(lbase + (i * P4 + j) * 256), 16, 0, 0);
+                        src += (int64_t)R4 * p.x_cs;
+                    }
+                } else {
+#pragma unroll 4
+                    for (int r = 0; r < CK; ++r) {
+                        const int ch = c * CK + r;
+                        const float* src = xb + (int64_t)(ch < p.cin ? ch : p.cin - 1) * p.x_cs;
+#pragma unroll
+                        for (int m = 0; m < NMP; ++m)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tcl[m]),
+                                                             (__attribute__((address_space(3))) void*)(lbase + r * XWP + 64 * m), 4, 0, 0);
+                    }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // ... leaky_relu in place (the producer has slack; doing it at the B-operand read of the compute waves
@@ -164,8 +234,11 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
             };
             fill(0);
             __syncthreads();
-            for (int c = 0; c < p.nchunks; ++c) {
-                if (c + 1 < p.nchunks) fill(c + 1);
+            // (no barrier after the LAST chunk: nothing reuses its buffer. The producer therefore retires a whole chunk
+            // before the block does, and with it the fifth wave that keeps a second block from being placed on this CU —
+            // the next block's launch and prologue overlap this block's last chunk instead of following its K loop)
+            for (int c = 0; c + 1 < p.nchunks; ++c) {
+                fill(c + 1);
                 __syncthreads();
             }
             return;
@@ -180,9 +253,24 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Per-lane bias values of the wide (dwordx4) epilogues, fetched NOW so that their latency hides behind the K loop.
+    // Loaded inside the epilogue each one costs an s_waitcnt vmcnt(0), which on gfx9 also waits for every store issued
+    // before it: measured 12 us of a 16 us epilogue on the 128x128 tiles.
+    float bias_w[MR][4];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int idx;
+            if (EPI == EPI_STD) idx = (mt0 + mr) * 32 + 8 * g + (lane & 3) + 4 * (lane >> 5);
+            else if (EPI == EPI_GATE) idx = (mt0 / 2) * 32 + 8 * g + (lane & 3) + 4 * (lane >> 5) + (mr == 0 ? 0 : p.cout / 2);
+            else idx = (mt0 + mr) * 4 + g;  // stride-8 transposed conv: 8 phases = 8 GEMM rows per output channel
+            bias_w[mr][g] = p.bias ? p.bias[idx < p.cout ? idx : p.cout - 1] : 0.f;
+        }
+
     const float slope_eff = p.pre_act ? p.slope : 1.0f;  // leaky_relu(x) = max(x, slope*x); slope 1 = identity
     const int krow = lane >> 5;
-    const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off;  // B operand base of this lane
+    const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off + shift;  // B operand base of this lane
     const size_t tile4 = (size_t)p.nchunks * STEPS * 64;                           // float4 per 32-row tile
     const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.wp) + (size_t)mt0 * tile4 + lane;
     const int total_steps = p.nchunks * STEPS;
@@ -205,7 +293,13 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
         float b_nxt[NR];
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xj[nr * 32];  // (tap 0, pair 0)
+        // fully unrolled taps: a taken branch every 64 MFMAs costs ~240 cycles of MFMA issue (measured on k = 11: K-loop
+        // efficiency 0.871 -> 0.915); VITS_TAP_ROLLED keeps the rolled loop for comparison
+#ifdef VITS_TAP_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
         for (int j = 0; j < KT; ++j) {
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) {
@@ -236,6 +330,13 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                         for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = nx[nr * 32];
 #endif
                     }
+#ifndef VAR_NOBPIN
+                    // pin the LDS read of the NEXT k-step in front of this step's MFMAs: left alone, hipcc reuses the
+                    // registers of b_cur for b_nxt and therefore sinks the ds_read behind the last MFMA that reads them —
+                    // one MFMA (64 cycles) in front of the s_waitcnt, less than the LDS latency: measured 14 % of the
+                    // K loop of the k = 11 kernel idle on lgkmcnt
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) {
                         const float4 a4 = ring[p4][mr];
@@ -291,13 +392,47 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     };
     if constexpr (DB) {
         // compute waves of the wave-specialised path (see the producer above)
-        __syncthreads();
-        for (int c = 0; c < p.nchunks; ++c) {
-            compute_chunk(xrow0 + (c & 1) * (CK * xw));
-            __syncthreads();
+#ifdef VITS_STAGGER
+        {
+            // the second block that lands on each CU in the first round of the grid starts half a K loop late, so that
+            // co-resident blocks are out of phase (one computes while the other runs its epilogue / prologue)
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            if (lin >= 256 && lin < 512) {
+                const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)p.nchunks * KT * 16 * MR * NR * 64 / 2;
+                while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
+            }
         }
+#endif
+        __syncthreads();
+        VITS_STAMP(1);
+        for (int c = 0; c < p.nchunks; ++c) {
+#ifdef VITS_PRIO
+            // the further along a block is, the higher its priority on the shared SIMD: two co-resident blocks that start
+            // together would otherwise stay in lock-step (prologues and epilogues coincide, nothing overlaps them)
+            if (2 * c >= p.nchunks) __builtin_amdgcn_s_setprio(2);
+#endif
+            compute_chunk(xrow0 + (c & 1) * (CK * xw));
+#ifdef VITS_PHASE_TIMING
+            if (tid == 0 && c < 4) {
+                const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
+            }
+#endif
+            if (c + 1 < p.nchunks) __syncthreads();  // (see the producer: the last chunk needs no barrier)
+#ifdef VITS_PHASE_TIMING
+            if (tid == 0 && c < 4) {
+                const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c + 1] = __builtin_amdgcn_s_memtime();
+            }
+#endif
+        }
+#ifdef VITS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        VITS_STAMP(2);
     } else {
         // single LDS buffer (few chunks: nothing to overlap inside the block; other resident blocks hide the latency)
+        VITS_STAMP(1);
         stage_load(0);
         for (int c = 0; c < p.nchunks; ++c) {
             if (c > 0) __syncthreads();  // everyone finished reading the previous chunk
@@ -307,6 +442,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
             __builtin_amdgcn_sched_barrier(0);
             compute_chunk(xrow0);
         }
+        VITS_STAMP(2);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
@@ -328,6 +464,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
     if (EPI == EPI_STD) {
         // no __restrict__: residual / accumulator may alias the output (in-place updates)
         float* yb = p.y + (int64_t)b * p.y_bs;
+        float* y2b = p.y2 ? p.y2 + (int64_t)b * p.y_bs : nullptr;
         const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
         const float* ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
         // ---- wide path (interior tile, 16-byte aligned rows): the MFMA C layout gives a lane ONE column and 16 rows, i.e.
@@ -335,24 +472,30 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
         // k=3 conv). A 4x4 transpose inside each quad of lanes (two DPP quad_perm butterflies, no LDS) gives every lane
         // 4 CONSECUTIVE columns of one row instead -> dwordx4 loads / stores: 4x fewer memory instructions.
         const bool wide = (t0 + BN <= ncols) && ((mt0 + MR) * 32 <= p.cout) && (((p.y_cs | p.r_cs | p.a_cs) & 3) == 0) &&
-                          ((((uintptr_t)yb | (uintptr_t)rb | (uintptr_t)ab) & 15) == 0);
+                          ((((uintptr_t)yb | (uintptr_t)y2b | (uintptr_t)rb | (uintptr_t)ab) & 15) == 0);
         if (wide) {
             const int qi = lane & 3;                     // position in the quad == row offset after the transpose
             const int cq = (lane & 31) & ~3;             // first of this lane's 4 columns within the 32-column tile
             const bool odd1 = lane & 1, odd2 = lane & 2;
+            // residual rows are fetched one (mr, nr) sub-tile AHEAD, i.e. before the stores of the current one: a load
+            // issued behind stores can only be waited for together with them (one in-order vmcnt on gfx9)
+            float4 rv[2][4], av[4];
+            auto load_res = [&](int it, float4* dst) __attribute__((always_inline)) {
+                const int mr = it / NR, nr = it % NR;
+                const int tcol = t0 + wn * (NR * 32) + nr * 32 + cq;
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
+                    dst[g] = *reinterpret_cast<const float4*>(rb + (int64_t)co * p.r_cs + tcol);
+                }
+            };
+            if (rb) load_res(0, rv[0]);
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
+            for (int it = 0; it < MR * NR; ++it) {
+                const int mr = it / NR, nr = it % NR;
+                {
                     const int tcol = t0 + wn * (NR * 32) + nr * 32 + cq;
-                    float4 rv[4], av[4];
-                    if (rb) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
-                            rv[g] = *reinterpret_cast<const float4*>(rb + (int64_t)co * p.r_cs + tcol);
-                        }
-                    }
+                    if (rb && it + 1 < MR * NR) load_res(it + 1, rv[(it + 1) & 1]);
                     if (ab) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -360,6 +503,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                             av[g] = *reinterpret_cast<const float4*>(ab + (int64_t)co * p.a_cs + tcol);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead loads in front of this sub-tile's stores
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float v0 = acc[mr][nr][4 * g + 0], v1 = acc[mr][nr][4 * g + 1], v2 = acc[mr][nr][4 * g + 2], v3 = acc[mr][nr][4 * g + 3];
@@ -379,9 +523,10 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                         }
                         // now (v0..v3) = columns tcol..tcol+3 of row co
                         const int co = (mt0 + mr) * 32 + 8 * g + qi + rowoff;
-                        const float bias = p.bias ? p.bias[co] : 0.f;
+                        const float bias = bias_w[mr][g];
                         float o[4] = {v0 + bias, v1 + bias, v2 + bias, v3 + bias};
-                        const float r4[4] = {rv[g].x, rv[g].y, rv[g].z, rv[g].w}, a4[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+                        const float4 rg = rv[it & 1][g];
+                        const float r4[4] = {rg.x, rg.y, rg.z, rg.w}, a4[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float v = o[e];
@@ -391,9 +536,14 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                                 v = a4[e] + v;
                                 v = p.scale_div ? v / p.scale : v * p.scale;
                             }
+                            if (p.post_act == 2) v = fmaxf(v, v * p.post_slope);
                             o[e] = v;
                         }
                         *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + tcol) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (y2b)
+                            *reinterpret_cast<float4*>(y2b + (int64_t)co * p.y_cs + tcol) =
+                                make_float4(fmaxf(o[0], o[0] * p.post_slope), fmaxf(o[1], o[1] * p.post_slope), fmaxf(o[2], o[2] * p.post_slope),
+                                            fmaxf(o[3], o[3] * p.post_slope));
                     }
                 }
             }
@@ -416,7 +566,9 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                         v = ab[(int64_t)co * p.a_cs + t] + v;
                         v = p.scale_div ? v / p.scale : v * p.scale;
                     }
+                    if (p.post_act == 2) v = fmaxf(v, v * p.post_slope);
                     yb[(int64_t)co * p.y_cs + t] = v;
+                    if (y2b) y2b[(int64_t)co * p.y_cs + t] = fmaxf(v, v * p.post_slope);
                 }
             }
         }
@@ -450,7 +602,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
                     xpose(a0, a1, a2, a3);
                     xpose(s0, s1, s2, s3);
                     const int ch = chbase + 8 * g + qi + rowoff;
-                    const float b0 = p.bias ? p.bias[ch] : 0.f, b1 = p.bias ? p.bias[ch + half] : 0.f;
+                    const float b0 = bias_w[0][g], b1 = bias_w[MR - 1][g];
                     float4 o;
                     o.x = tanhf(a0 + b0) * (1.0f / (1.0f + expf(-(s0 + b1))));
                     o.y = tanhf(a1 + b0) * (1.0f / (1.0f + expf(-(s1 + b1))));
@@ -488,7 +640,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = (mt0 + mr) * 4 + g;
-                    const float bias = p.bias ? p.bias[co] : 0.f;
+                    const float bias = bias_w[mr][g];
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr) {
                         const int q = colbase + nr * 32;
@@ -520,6 +672,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) void conv_mfma_kernel(const ConvPar
             }
         }
     }
+    VITS_STAMP(3);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------
@@ -606,7 +759,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
-    const size_t lds = DB ? (size_t)2 * CK * ((p.xw + 63) / 64 * 64) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
+    const size_t lds = DB ? (size_t)2 * CK * ((p.xw + 3 + 63) / 64 * 64) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
 #define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
     do {                                                                                                                              \
         static bool big_lds_set = false;                                                                                              \
@@ -665,6 +818,8 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.pre_act = c.pre_act;
     p.slope = c.slope;
     p.post_act = c.post_act;
+    p.post_slope = c.post_slope;
+    p.y2 = c.y2;
     p.scale = c.scale;
     p.scale_div = c.scale_div;
     p.ct_stride = w.ct_stride;

@@ -304,6 +304,7 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         return false;
     }
     if (const char* e = std::getenv("VITS_RB_STREAMS")) rb_streams_ = std::atoi(e) >= 2 ? 3 : 1;
+    if (const char* e = std::getenv("VITS_LRELU_COPY_MINC")) lrelu_copy_minc_ = std::atoi(e);
     if (rb_streams_ > 1) {
         bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
         for (auto& s : side_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
@@ -825,7 +826,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     for (int i = 0; i <= n_up; ++i) sts[i] = round_up(Lw_max * smul[i] + sadd[i], 32);
     for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
     struct S2 {
-        float *zp, *noise, *hout, *gate, *h0, *bu, *by[3], *bt[3], *bs, *pre, *wave;
+        float *zp, *noise, *hout, *gate, *h0, *bu, *by[3], *bt[3], *byl[3], *bs, *pre, *wave;
         int* win_lens;  // [window][n_up + 2][B]: stage lengths of each utterance inside the window, then its emit end
     } s2;
     const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
@@ -843,6 +844,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             const bool own = j == 0 || (rb_streams_ > 1 && (size_t)j < hp.rb_k.size());
             s2.by[j] = own ? a.alloc<float>(big) : s2.by[0];
             s2.bt[j] = own ? a.alloc<float>(big) : s2.bt[0];
+            s2.byl[j] = own ? a.alloc<float>(big) : s2.byl[0];
         }
         s2.bs = a.alloc<float>(big);
         s2.pre = o.collect_taps ? a.alloc<float>((size_t)B * S_stride) : nullptr;
@@ -1056,21 +1058,32 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 const size_t nd = R.dil.size();
                 hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
                 TensorRef by = TR(s2.by[par ? j : 0], C, sts[st_out]), bt = TR(s2.bt[par ? j : 0], C, sts[st_out]);
+                // LeakyReLU is applied where a tensor is WRITTEN, not where it is read: the first conv of a pair stores
+                // leaky_relu(t) (t has no other reader), and for wide stages the second conv stores leaky_relu(y) beside y
+                // (y itself stays the residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the
+                // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
+                const bool lcopy = C >= lrelu_copy_minc_;
+                TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]);
                 for (size_t d = 0; d < nd; ++d) {
                     TensorRef resid = d == 0 ? bu : by;
                     ConvCall c1;
-                    c1.x = resid;
+                    c1.x = (d > 0 && lcopy) ? byl : resid;
                     c1.y = bt;
                     c1.len_in = c1.len_out = d_len[st_out];
                     c1.batch = B;
                     c1.t_in = c1.t_out = smax[st_out];
                     c1.dil = R.dil[d];
                     c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
-                    c1.pre_act = 1;
+                    c1.pre_act = (d > 0 && lcopy) ? 0 : 1;
                     c1.slope = hp.lrelu;
+                    c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
+                    c1.post_slope = hp.lrelu;
                     HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1, sj));
                     ConvCall c2 = c1;
                     c2.x = bt;
+                    c2.pre_act = 0;
+                    c2.post_act = 0;
+                    c2.y2 = (d + 1 < nd && lcopy) ? byl.p : nullptr;
                     c2.dil = 1;
                     c2.pad_l = (R.k - 1) / 2;
                     c2.res = resid;  // residual add (vits.cpp:578)

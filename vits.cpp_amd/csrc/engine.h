@@ -136,6 +136,7 @@ class Engine {
     hipStream_t side_[2] = {nullptr, nullptr};
     hipEvent_t ev_fork_ = nullptr, ev_done_[3] = {nullptr, nullptr, nullptr};
     int rb_streams_ = 3;
+    int lrelu_copy_minc_ = 128;  // stages at least this wide also store leaky_relu(y) (see the resblock loop)
     int halo_frames_ = 0;      // receptive field of the vocoder in frames, one side (computed at load)
     void* pinned_ = nullptr;   // grow-only pinned staging for streamed PCM
     size_t pinned_cap_ = 0;  // VITS_RB_STREAMS=1 serialises everything on the main stream

@@ -46,7 +46,9 @@ struct ConvCall {
     int dil = 1, pad_l = 0;
     int pre_act = 0;  // 1: leaky_relu(slope) on load
     float slope = 0.f;
-    int post_act = 0;  // 1: relu
+    int post_act = 0;  // 1: relu; 2: leaky_relu(post_slope) of the stored value (EPI_STD)
+    float post_slope = 0.f;
+    float* y2 = nullptr;  // EPI_STD, optional: also store leaky_relu(post_slope) of the output here (layout of y)
     float scale = 1.f;  // applied when acc.p: y = (acc + v) * scale, or / scale when scale_div
     int scale_div = 0;
     int ct_crop = 0;  // EPI_CONVT: output crop
