@@ -22,6 +22,9 @@ using namespace vits;
 #ifndef DIL_
 #define DIL_ 1
 #endif
+#ifndef PRE_
+#define PRE_ 1
+#endif
 #ifndef CIN_
 #define CIN_ 128
 #endif
@@ -48,7 +51,7 @@ int main() {
 #ifdef WITH_RES
     c.res = c.x;
 #endif
-    c.batch = B; c.t_in = c.t_out = T; c.dil = DIL_; c.pad_l = (K - 1) * DIL_ / 2; c.pre_act = 1; c.slope = 0.1f;
+    c.batch = B; c.t_in = c.t_out = T; c.dil = DIL_; c.pad_l = (K - 1) * DIL_ / 2; c.pre_act = PRE_; c.slope = 0.1f;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i) launch_conv(pc, c, nullptr);
     hipDeviceSynchronize();

@@ -21,6 +21,7 @@
 //   store side: + bias, relu (FFN, :397) | tanh*sigmoid gate (:442-450) | residual add (:578) |
 //               resblock accumulation and the 1/num_kernels scale (:630,635) | transposed-conv phase scatter.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
             constexpr int XW4 = XWP / 4;
             constexpr int G4 = XW4 % 64 == 0 ? 64 : (XW4 % 32 == 0 ? 32 : 16);  // gcd(XW4, 64); XWP is a multiple of 64
             constexpr int P4 = XW4 / G4, R4 = 64 / G4;
-            int64_t off4[P4];
+            unsigned off4[P4];  // BYTE offset from the chunk's first row: 32-bit, so the DMA can use the SGPR-base + VGPR-offset form
 #pragma unroll
             for (int j = 0; j < P4; ++j) {
                 const int g = j * 64 + lane;
@@ -177,20 +178,23 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                 int t = ts + 4 * c4;  // multiple of 4
                 const int tlast = (len_in - 1) & ~3;  // last float4 that starts inside the sequence (rows are padded to x4)
                 t = t < 0 ? 0 : (t > tlast ? tlast : t);
-                off4[j] = (int64_t)r * p.x_cs + t;
+                off4[j] = (unsigned)(r * p.x_cs + t) * 4u;
             }
+            const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
             auto fill = [&](int c) __attribute__((always_inline)) {
                 float* lbase = xs + (c & 1) * (CK * XWP);
                 // LDS-DMA of the whole 32 x XWP tile from clamped (always valid) addresses ...
                 if (x4 && (c + 1) * CK <= p.cin) {
-                    const float* src = xb + (int64_t)(c * CK) * p.x_cs;
+                    // buffer form: descriptor (SGPRs) + per-lane byte offset (loop-invariant VGPR) + scalar row offset — no
+                    // vector ALU work per DMA (the global_load_lds form needs a 64-bit VALU add for every address)
+                    unsigned soff = (unsigned)(c * CK) * (unsigned)p.x_cs * 4u;
 #pragma unroll 2
                     for (int i = 0; i < CK / R4; ++i) {
 #pragma unroll
                         for (int j = 0; j < P4; ++j)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off4[j]),
-                                                             (__attribute__((address_space(3))) void*)(lbase + (i * P4 + j) * 256), 16, 0, 0);
-                        src += (int64_t)R4 * p.x_cs;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(lbase + (i * P4 + j) * 256), 16, (int)off4[j],
+                                                                 (int)soff, 0, 0);
+                        soff += (unsigned)R4 * (unsigned)p.x_cs * 4u;
                     }
                 } else {
 #pragma unroll 4
@@ -272,7 +276,24 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     const int krow = lane >> 5;
     const float* xrow0 = xs + krow * xw + wn * (NR * 32) + (lane & 31) + lds_off + shift;  // B operand base of this lane
     const size_t tile4 = (size_t)p.nchunks * STEPS * 64;                           // float4 per 32-row tile
+    // A fragments come through a buffer descriptor: the address is (SGPR descriptor) + (per-lane byte offset, loop
+    // invariant VGPR) + (scalar step offset), so the K loop needs NO vector ALU work for addressing. VALU and MFMA share
+    // the issue port: every v_add / v_lshl_add_u64 in the loop is MFMA time (measured ~8 % of the k = 11 K loop).
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
+    int wvoff[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)(mt0 + mr) * tile4 + lane) * 16);
+    typedef float vfloat4 __attribute__((ext_vector_type(4)));
+    // (the small single-buffer kernels run 3-5 blocks per CU and are not MFMA-issue bound: plain loads measured 3-6 % faster there)
     const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.wp) + (size_t)mt0 * tile4 + lane;
+    auto load_a = [&](int mr, int step) __attribute__((always_inline)) -> float4 {
+        if constexpr (DB) {
+            const vfloat4 v = __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
+            return make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            return wq[(size_t)mr * tile4 + (size_t)step * 64];
+        }
+    };
     const int total_steps = p.nchunks * STEPS;
 
     // Software pipeline. A fragments (float4 = 4 MFMA k-steps per row tile) live in a ring of 4 register sets and
@@ -281,18 +302,23 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     float4 ring[4][MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        ring[0][mr] = wq[(size_t)mr * tile4];
-        ring[1][mr] = wq[(size_t)mr * tile4 + (size_t)(total_steps > 1 ? 1 : 0) * 64];
+        ring[0][mr] = load_a(mr, 0);
+        ring[1][mr] = load_a(mr, total_steps > 1 ? 1 : 0);
     }
     int gstep = 0;
     static_assert(CK / 8 == 4, "one tap must be 4 A-steps");
 
     // one chunk of MFMA work on the LDS tile whose lane base is `xrow`
-    auto compute_chunk = [&](const float* xrow) __attribute__((always_inline)) {
-        const float* xj = xrow;  // advances by `dil` floats per tap
+    // (lr: apply leaky_relu at the B-operand read — a compile-time flag so that convolutions whose input is already
+    // activated pay nothing for it)
+    auto compute_chunk = [&](const float* xrow, auto lr) __attribute__((always_inline)) {
+        constexpr bool LR = decltype(lr)::value;
+        typedef const __attribute__((address_space(3))) float* LdsF;
+        typedef std::conditional_t<DB, const volatile __attribute__((address_space(3))) float*, const __attribute__((address_space(3))) float*> LdsVF;
+        LdsF xj = (LdsF)xrow;  // advances by `dil` floats per tap
         float b_nxt[NR];
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xj[nr * 32];  // (tap 0, pair 0)
+        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = *(LdsVF)(xj + nr * 32);  // (tap 0, pair 0)
         // fully unrolled taps: a taken branch every 64 MFMAs costs ~240 cycles of MFMA issue (measured on k = 11: K-loop
         // efficiency 0.871 -> 0.915); VITS_TAP_ROLLED keeps the rolled loop for comparison
 #ifdef VITS_TAP_ROLLED
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     const int nstep = gstep + 2 < total_steps ? gstep + 2 : total_steps - 1;  // clamp: stays in bounds
 #ifndef VAR_NOA
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = wq[(size_t)mr * tile4 + (size_t)nstep * 64];
+                    for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = load_a(mr, nstep);
 #endif
                 }
                 // pin the prefetch at the top of the step: hipcc otherwise sinks the loads next to their first use
@@ -318,16 +344,18 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     float b_cur[NR];
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr) {
-                        b_cur[nr] = (DB && LRELU_AT_READ) ? fmaxf(b_nxt[nr], b_nxt[nr] * slope_eff) : b_nxt[nr];
+                        b_cur[nr] = LR ? fmaxf(b_nxt[nr], b_nxt[nr] * slope_eff) : b_nxt[nr];
                     }
                     {
                         // next k-step: next channel pair of this tap, or pair 0 of the next tap (after the last tap this
                         // reads a few floats past the row: still inside the tile, value unused)
                         const int pair = p4 * 4 + q;
-                        const float* nx = pair + 1 < CK / 2 ? xj + (2 * (pair + 1)) * xw : xj + dil;
+                        LdsF nx = pair + 1 < CK / 2 ? xj + (2 * (pair + 1)) * xw : xj + dil;
 #ifndef VAR_NOB
 #pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = nx[nr * 32];
+                        // (volatile: keeps one ds_read_b32 per value with a 16-bit immediate offset; merged into
+                        // ds_read2_b32 — 8-bit offsets — every read needs a v_add_u32 for its base)
+                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = *(LdsVF)(nx + nr * 32);
 #endif
                     }
 #ifndef VAR_NOBPIN
@@ -392,43 +420,28 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     };
     if constexpr (DB) {
         // compute waves of the wave-specialised path (see the producer above)
-#ifdef VITS_STAGGER
-        {
-            // the second block that lands on each CU in the first round of the grid starts half a K loop late, so that
-            // co-resident blocks are out of phase (one computes while the other runs its epilogue / prologue)
-            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            if (lin >= 256 && lin < 512) {
-                const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)p.nchunks * KT * 16 * MR * NR * 64 / 2;
-                while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
-            }
-        }
-#endif
         __syncthreads();
         VITS_STAMP(1);
-        for (int c = 0; c < p.nchunks; ++c) {
-#ifdef VITS_PRIO
-            // the further along a block is, the higher its priority on the shared SIMD: two co-resident blocks that start
-            // together would otherwise stay in lock-step (prologues and epilogues coincide, nothing overlaps them)
-            if (2 * c >= p.nchunks) __builtin_amdgcn_s_setprio(2);
-#endif
-            compute_chunk(xrow0 + (c & 1) * (CK * xw));
+        auto k_loop = [&](auto lr) __attribute__((always_inline)) {
+            for (int c = 0; c < p.nchunks; ++c) {
+                compute_chunk(xrow0 + (c & 1) * (CK * xw), lr);
 #ifdef VITS_PHASE_TIMING
-            if (tid == 0 && c < 4) {
-                const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-                if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
-            }
+                if (tid == 0 && c < 4) {
+                    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                    if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
+                }
 #endif
-            if (c + 1 < p.nchunks) __syncthreads();  // (see the producer: the last chunk needs no barrier)
+                if (c + 1 < p.nchunks) __syncthreads();  // (see the producer: the last chunk needs no barrier)
 #ifdef VITS_PHASE_TIMING
-            if (tid == 0 && c < 4) {
-                const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-                if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c + 1] = __builtin_amdgcn_s_memtime();
+                if (tid == 0 && c < 4) {
+                    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                    if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c + 1] = __builtin_amdgcn_s_memtime();
+                }
+#endif
             }
-#endif
-        }
-#ifdef VITS_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        };
+        if (LRELU_AT_READ && p.pre_act) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
         VITS_STAMP(2);
     } else {
         // single LDS buffer (few chunks: nothing to overlap inside the block; other resident blocks hide the latency)
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
             __syncthreads();
             if (c + 1 < p.nchunks) stage_load(c + 1);  // in flight during the MFMA work
             __builtin_amdgcn_sched_barrier(0);
-            compute_chunk(xrow0);
+            compute_chunk(xrow0, std::false_type{});
         }
         VITS_STAMP(2);
     }
