@@ -471,8 +471,8 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
         std::snprintf(full, sizeof(full), "%s|k%d|d%d|t%d|e%d|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, w.cin,
                       w.cout);
         const int64_t cols = (int64_t)c.batch * (w.epi == EPI_CONVT ? c.t_in : c.t_out);
-        // algorithmic bytes: input read once, output written once, residual/accumulator read once, weights once
-        double bytes = 4.0 * ((double)c.batch * w.cin * c.t_in + (double)c.batch * w.cout * c.t_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0))) +
+        // algorithmic bytes: input read once, output (and its activated copy, if any) written once, residual/accumulator read once, weights once
+        double bytes = 4.0 * ((double)c.batch * w.cin * c.t_in + (double)c.batch * w.cout * c.t_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0) + (c.y2 ? 1 : 0))) +
                        (double)w.bytes;
         prof.begin(full, conv_flops(w, c, cols), bytes, stream);
     }
