@@ -114,7 +114,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VITS_BENCH_FORCE_DIST=1: run the RCCL exchange even with one rank (exercises the N > 1 code path on a 1-GPU box)
+    dist_on = world > 1 or os.environ.get("VITS_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     pkg = load_package()
     pkg.set_device(local_rank)
@@ -137,7 +143,7 @@ def main():
         _, lengths, frames = model.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_seed, fixed_duration=args.pinned,
                                                  out_device=out.data_ptr(), out_device_stride=cap, skip_host_copy=True,
                                                  vocoder_chunk_frames=args.chunk_frames)
-        if world > 1:
+        if dist_on:
             # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
             lens_d = torch.from_numpy(lengths).cuda()
             mg.gather_pcm(mg.to_pcm16(pkg, out, lens_d) if args.pcm16 else out, lens_d)
@@ -145,7 +151,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +182,7 @@ def main():
             step()
         fence()
         elapsed_plain = time.perf_counter() - t1
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -258,7 +264,7 @@ def main():
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     model.close()

@@ -34,7 +34,7 @@ def to_pcm16(pkg, pcm, lengths=None):
 def gather_pcm(pcm, lengths):
     """pcm: [B, cap] fp32 (or int16, see to_pcm16) on this rank's device (rows valid up to lengths[b]); lengths: [B] int64 (same device).
     Returns (gathered [world*B, smax] fp32, all_lengths [world*B] int64) on every rank; world == 1 is a no-op view."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         smax = int(lengths.max().item())
         return pcm[:, :smax], lengths
     world = dist.get_world_size()
