@@ -872,8 +872,11 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
-    static const int db_min = getenv("VITS_DB_MIN") ? atoi(getenv("VITS_DB_MIN")) : 2;  // measured: 2 chunks (cin 64) gain, 1 chunk (cin 32) loses
-    const bool db = w.nchunks >= db_min;  // producer-wave path only when there is a next chunk worth prefetching
+    // producer-wave path for every compile-time-dilation conv: with dwordx4 LDS-DMA it also wins for single-chunk inputs
+    // (c_in = 32: 109 -> 120 TFLOP/s on the k = 11 layers; with dword DMA it lost 8 % there). VITS_DB_MIN=2 restores the
+    // register-staged kernels for them.
+    static const int db_min = getenv("VITS_DB_MIN") ? atoi(getenv("VITS_DB_MIN")) : 1;
+    const bool db = w.nchunks >= db_min;
 #define VITS_GO(K, D, E)                                                                     \
     do {                                                                                     \
         if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
