@@ -31,6 +31,13 @@
 
 #include "kernels.h"
 
+// The kernel template is instantiated for ~40 (taps, dilation, tile, epilogue) combinations; one translation unit takes
+// minutes, so the Makefile compiles this file four times: VITS_CONV_PART 0 = host code + taps 1/2/5, 1 = taps 3, 2 = taps 7,
+// 3 = taps 11 (each part defines launch_conv_k<taps>() for the dispatcher in part 0).
+#ifndef VITS_CONV_PART
+#define VITS_CONV_PART 0
+#endif
+
 namespace vits {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -702,6 +709,7 @@ static TileShape tile_shape(int tile) {
     }
 }
 
+#if VITS_CONV_PART == 0
 int choose_conv_tile(int rows, int epi, int t_hint) {
     // rows <= 64 (few MFMAs per staged tile): 128-column tiles -> twice as many independent blocks per CU keep more
     // loads in flight (measured 120.5 -> 116.4 ms per step); VITS_NARROW_TILES=0 restores 256-column tiles
@@ -766,6 +774,8 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
     return out;
 }
 
+#endif  // VITS_CONV_PART == 0
+
 template <int KT, int DIL, bool DB, int EPI>
 static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
     const TileShape ts = tile_shape(tile);
@@ -804,6 +814,42 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     return hipGetLastError();
 }
 
+// one launcher per tap count (see VITS_CONV_PART): picks the compile-time dilation and the producer-wave variant
+#define VITS_GO(K, D, E)                                                                     \
+    do {                                                                                     \
+        if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
+        return launch_tile<K, D, false, E>(w, tile, p, ncols_max, batch, s);                 \
+    } while (0)
+#define VITS_LAUNCHER(K) hipError_t launch_conv_k##K(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s, bool db)
+VITS_LAUNCHER(3);
+VITS_LAUNCHER(7);
+VITS_LAUNCHER(11);
+#if VITS_CONV_PART == 1
+VITS_LAUNCHER(3) {
+    if (p.dil == 1) VITS_GO(3, 1, EPI_STD);
+    if (p.dil == 3) VITS_GO(3, 3, EPI_STD);
+    if (p.dil == 5) VITS_GO(3, 5, EPI_STD);
+    VITS_GO(3, 0, EPI_STD);
+}
+#endif
+#if VITS_CONV_PART == 2
+VITS_LAUNCHER(7) {
+    if (p.dil == 1) VITS_GO(7, 1, EPI_STD);
+    if (p.dil == 3) VITS_GO(7, 3, EPI_STD);
+    if (p.dil == 5) VITS_GO(7, 5, EPI_STD);
+    VITS_GO(7, 0, EPI_STD);
+}
+#endif
+#if VITS_CONV_PART == 3
+VITS_LAUNCHER(11) {
+    if (p.dil == 1) VITS_GO(11, 1, EPI_STD);
+    if (p.dil == 3) VITS_GO(11, 3, EPI_STD);
+    if (p.dil == 5) VITS_GO(11, 5, EPI_STD);
+    VITS_GO(11, 0, EPI_STD);
+}
+#endif
+
+#if VITS_CONV_PART == 0
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     ConvParams p;
     p.x = c.x.p;
@@ -877,11 +923,6 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     // register-staged kernels for them.
     static const int db_min = getenv("VITS_DB_MIN") ? atoi(getenv("VITS_DB_MIN")) : 1;
     const bool db = w.nchunks >= db_min;
-#define VITS_GO(K, D, E)                                                                     \
-    do {                                                                                     \
-        if ((D) != 0 && db) return launch_tile<K, D, (D) != 0, E>(w, tile, p, ncols_max, batch, s); \
-        return launch_tile<K, D, false, E>(w, tile, p, ncols_max, batch, s);                 \
-    } while (0)
 #ifdef VITS_MICRO_KT  // developer microbenchmark (tools/conv_micro.hip): instantiate a single (taps, dilation) pair
     VITS_GO(VITS_MICRO_KT, VITS_MICRO_DIL, EPI_STD);
 #else
@@ -896,28 +937,15 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     }
     switch (w.kt) {
         case 1: VITS_GO(1, 1, EPI_STD);
-        case 3:
-            if (p.dil == 1) VITS_GO(3, 1, EPI_STD);
-            if (p.dil == 3) VITS_GO(3, 3, EPI_STD);
-            if (p.dil == 5) VITS_GO(3, 5, EPI_STD);
-            VITS_GO(3, 0, EPI_STD);
+        case 3: return launch_conv_k3(w, tile, p, ncols_max, batch, s, db);
         case 5:
             if (p.dil == 1) VITS_GO(5, 1, EPI_STD);
             VITS_GO(5, 0, EPI_STD);
-        case 7:
-            if (p.dil == 1) VITS_GO(7, 1, EPI_STD);
-            if (p.dil == 3) VITS_GO(7, 3, EPI_STD);
-            if (p.dil == 5) VITS_GO(7, 5, EPI_STD);
-            VITS_GO(7, 0, EPI_STD);
-        case 11:
-            if (p.dil == 1) VITS_GO(11, 1, EPI_STD);
-            if (p.dil == 3) VITS_GO(11, 3, EPI_STD);
-            if (p.dil == 5) VITS_GO(11, 5, EPI_STD);
-            VITS_GO(11, 0, EPI_STD);
+        case 7: return launch_conv_k7(w, tile, p, ncols_max, batch, s, db);
+        case 11: return launch_conv_k11(w, tile, p, ncols_max, batch, s, db);
         default: break;
     }
 #endif
-#undef VITS_GO
     return hipErrorInvalidValue;
 }
 
@@ -925,5 +953,8 @@ double conv_flops(const PackedConv& w, const ConvCall&, int64_t total_cols) {
     // algorithmic MACs: every (row, col) output sums cin*kt products
     return 2.0 * (double)w.rows * (double)w.cin * (double)w.kt * (double)total_cols;
 }
+#endif  // VITS_CONV_PART == 0
+#undef VITS_GO
+#undef VITS_LAUNCHER
 
 }  // namespace vits
