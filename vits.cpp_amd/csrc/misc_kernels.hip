@@ -172,12 +172,17 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
+// channel groups per block of the two LayerNorm kernels: 16 x 64 threads, every thread walks channels/16 rows. (4 groups
+// made each thread chain 48 dependent loads: 26-58 us per launch at batch 1, where these launches have 2 blocks.) The
+// partial sums are combined in a fixed order, so results do not depend on the batch.
+constexpr int LN_GROUPS = 16;
+
+__global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
                                                              const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs, float* addto,
                                                              int64_t a_bs, int a_cs, const int* lens, int channels, int tmax, float eps, int post_gelu) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* tile = sm;                    // [channels][64]
-    float* red = sm + channels * 64;     // [4][64] x2
+    float* red = sm + channels * 64;     // [LN_GROUPS][64] x2
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     const int len = lens ? lens[b] : tmax;
     if (t0 >= len) return;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, int
     const int t = t0 + tl;
     const bool ok = t < len;
     float s = 0.f;
-    for (int c = g; c < channels; c += 4) {
+    for (int c = g; c < channels; c += LN_GROUPS) {
         float v = 0.f;
         if (ok) {
             v = x[(int64_t)b * x_bs + (int64_t)c * x_cs + t];
@@ -196,18 +201,24 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, int
     }
     red[g * 64 + tl] = s;
     __syncthreads();
-    const float mean = (red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl]) / (float)channels;
+    float msum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * 64 + tl];
+    const float mean = msum / (float)channels;
     float vs = 0.f;
-    for (int c = g; c < channels; c += 4) {
+    for (int c = g; c < channels; c += LN_GROUPS) {
         const float d = tile[c * 64 + tl] - mean;
         vs += d * d;
     }
-    red[256 + g * 64 + tl] = vs;
+    red[(LN_GROUPS + g) * 64 + tl] = vs;
     __syncthreads();
-    const float var = (red[256 + tl] + red[320 + tl] + red[384 + tl] + red[448 + tl]) / (float)channels;
+    float vsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * 64 + tl];
+    const float var = vsum / (float)channels;
     const float inv = 1.0f / sqrtf(var + eps);
     if (!ok) return;
-    for (int c = g; c < channels; c += 4) {
+    for (int c = g; c < channels; c += LN_GROUPS) {
         float v = (tile[c * 64 + tl] - mean) * inv * gamma[c] + beta[c];
         if (post_gelu) v = gelu_erf(v);
         if (addto) {
@@ -220,14 +231,14 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, int
 
 hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
                                  int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s) {
-    const size_t lds = sizeof(float) * ((size_t)channels * 64 + 512);
+    const size_t lds = sizeof(float) * ((size_t)channels * 64 + 2 * 64 * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(add_layer_norm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     dim3 grid((tmax + 63) / 64, batch);
-    hipLaunchKernelGGL(add_layer_norm_kernel, grid, dim3(256), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
+    hipLaunchKernelGGL(add_layer_norm_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
                        add_to.cs, lens, channels, tmax, eps, post_gelu);
     return hipGetLastError();
 }
@@ -239,7 +250,7 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
 //   (vits.cpp:651-653 happens once before the layer loop; the engine passes g only for layer 0).
 // Block = 64 time steps x all channels, input tile with halo in LDS.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dds_depthwise_kernel(float* x, int64_t x_bs, int x_cs, const float* g, int64_t g_bs, int g_cs, const float* w,
+__global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x, int64_t x_bs, int x_cs, const float* g, int64_t g_bs, int g_cs, const float* w,
                                                             const float* bias, const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs,
                                                             const int* lens, int channels, int tmax, int k, int dil, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -247,12 +258,12 @@ __global__ __launch_bounds__(256) void dds_depthwise_kernel(float* x, int64_t x_
     const int xw = 64 + 2 * pad;
     float* xt = sm;                       // [channels][xw]
     float* ht = xt + channels * xw;       // [channels][64]
-    float* red = ht + channels * 64;      // [512]
+    float* red = ht + channels * 64;      // [2][LN_GROUPS][64]
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     const int len = lens ? lens[b] : tmax;
     if (t0 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int c = wid; c < channels; c += 4) {
+    for (int c = wid; c < channels; c += LN_GROUPS) {
         for (int i = lane; i < xw; i += 64) {
             const int t = t0 - pad + i;
             float v = 0.f;
@@ -267,14 +278,14 @@ __global__ __launch_bounds__(256) void dds_depthwise_kernel(float* x, int64_t x_
     }
     __syncthreads();
     if (g) {  // write back x + g for the centre columns (this block owns them)
-        for (int c = wid; c < channels; c += 4) {
+        for (int c = wid; c < channels; c += LN_GROUPS) {
             const int t = t0 + lane;
             if (t < len) x[(int64_t)b * x_bs + (int64_t)c * x_cs + t] = xt[c * xw + pad + lane];
         }
     }
     const int tl = lane, gq = wid;
     float s = 0.f;
-    for (int c = gq; c < channels; c += 4) {
+    for (int c = gq; c < channels; c += LN_GROUPS) {
         float a = bias[c];
         for (int j = 0; j < k; ++j) a += w[c * k + j] * xt[c * xw + tl + j * dil];
         ht[c * 64 + tl] = a;
@@ -282,32 +293,38 @@ __global__ __launch_bounds__(256) void dds_depthwise_kernel(float* x, int64_t x_
     }
     red[gq * 64 + tl] = s;
     __syncthreads();
-    const float mean = (red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl]) / (float)channels;
+    float msum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * 64 + tl];
+    const float mean = msum / (float)channels;
     float vs = 0.f;
-    for (int c = gq; c < channels; c += 4) {
+    for (int c = gq; c < channels; c += LN_GROUPS) {
         const float d = ht[c * 64 + tl] - mean;
         vs += d * d;
     }
-    red[256 + gq * 64 + tl] = vs;
+    red[(LN_GROUPS + gq) * 64 + tl] = vs;
     __syncthreads();
-    const float var = (red[256 + tl] + red[320 + tl] + red[384 + tl] + red[448 + tl]) / (float)channels;
+    float vsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * 64 + tl];
+    const float var = vsum / (float)channels;
     const float inv = 1.0f / sqrtf(var + eps);
     const int t = t0 + tl;
     if (t >= len) return;
-    for (int c = gq; c < channels; c += 4) y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = gelu_erf((ht[c * 64 + tl] - mean) * inv * gamma[c] + beta[c]);
+    for (int c = gq; c < channels; c += LN_GROUPS) y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = gelu_erf((ht[c * 64 + tl] - mean) * inv * gamma[c] + beta[c]);
 }
 
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
                                 const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s) {
     const int pad = (k * dil - dil) / 2;
-    const size_t lds = sizeof(float) * ((size_t)channels * (64 + 2 * pad) + (size_t)channels * 64 + 512);
+    const size_t lds = sizeof(float) * ((size_t)channels * (64 + 2 * pad) + (size_t)channels * 64 + 2 * 64 * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dds_depthwise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     dim3 grid((tmax + 63) / 64, batch);
-    hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(256), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
+    hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
                        k, dil, eps);
     return hipGetLastError();
 }
