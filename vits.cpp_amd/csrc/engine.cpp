@@ -82,7 +82,7 @@ hipEvent_t Profiler::get() {
     hipEventCreate(&e);
     return e;
 }
-void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s) {
+void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s, bool chain) {
     if (!on) return;
     auto it = ids.find(name);
     int id;
@@ -93,13 +93,18 @@ void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s)
         agg.emplace_back();
     } else
         id = it->second;
-    Rec r{id, get(), get(), flop, bytes};
-    hipEventRecord(r.a, s);
+    const bool share = chain && last_ok && last_s == s;
+    Rec r{id, share ? last_b : get(), get(), flop, bytes, share};
+    if (!share) hipEventRecord(r.a, s);
     recs.push_back(r);
+    last_ok = false;
 }
 void Profiler::end(hipStream_t s) {
     if (!on || recs.empty()) return;
     hipEventRecord(recs.back().b, s);
+    last_b = recs.back().b;
+    last_s = s;
+    last_ok = true;
 }
 void Profiler::collect() {
     for (auto& r : recs) {
@@ -111,10 +116,11 @@ void Profiler::collect() {
             a.flop += r.flop;
             a.bytes += r.bytes;
         }
-        pool.push_back(r.a);
+        if (!r.a_shared) pool.push_back(r.a);
         pool.push_back(r.b);
     }
     recs.clear();
+    last_ok = false;
 }
 void Profiler::reset() {
     collect();
@@ -474,7 +480,7 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
         // algorithmic bytes: input read once, output (and its activated copy, if any) written once, residual/accumulator read once, weights once
         double bytes = 4.0 * ((double)c.batch * w.cin * c.t_in + (double)c.batch * w.cout * c.t_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0) + (c.y2 ? 1 : 0))) +
                        (double)w.bytes;
-        prof.begin(full, conv_flops(w, c, cols), bytes, stream);
+        prof.begin(full, conv_flops(w, c, cols), bytes, stream, /*chain=*/true);
     }
     hipError_t e = launch_conv(w, c, stream);
     prof.end(stream);
@@ -518,6 +524,7 @@ void Engine::clear_taps() {
 }
 
 void Engine::snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens) {
+    prof.fence();
     Tap tp;
     tp.channels = channels;
     tp.stride = stride;
@@ -636,7 +643,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     };
     TensorRef none;
     HIP_OK(hipMemcpyAsync(s1.ids, ids, sizeof(int) * (size_t)B * id_stride, hipMemcpyHostToDevice, stream));
+    prof.fence();
     HIP_OK(hipMemcpyAsync(s1.lens, tlen.data(), sizeof(int) * B, hipMemcpyHostToDevice, stream));
+    prof.fence();
     // vocoder stage lengths as affine functions of the frame count L: len_i = L*mul_i + add_i (Q1: the reference
     // never crops the transposed conv, so every stage gains K - s samples; vits.cpp:187)
     std::vector<int> smul(n_up + 1), sadd(n_up + 1);
@@ -649,7 +658,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         sadd[i + 1] = sadd[i] * s + (K - s - 2 * crop);
     }
     HIP_OK(hipMemcpyAsync(s1.stage_mul, smul.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
+    prof.fence();
     HIP_OK(hipMemcpyAsync(s1.stage_add, sadd.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
+    prof.fence();
 
     const int* dl = s1.lens;
     TensorRef x = TR(s1.x, H, ts), qkv = TR(s1.qkv, 3 * H, ts), att = TR(s1.att, H, ts), tmp = TR(s1.tmp, H, ts), ffn = TR(s1.ffn, hp.ffn_dim, ts);
@@ -737,6 +748,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             }
         }
         HIP_OK(hipMemcpyAsync(s1.z, host_noise.data(), sizeof(float) * host_noise.size(), hipMemcpyHostToDevice, stream));
+        prof.fence();
         if (o.collect_taps) snapshot("noise_dur", z, 2, Tmax, B, tlen);
         HIP_OK(launch_scale_rows(z, 2, hp.noise_scale_dur, B, Tmax, stream));
     }
@@ -774,7 +786,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         for (int b = 0; b < B; ++b) frames[b] = std::max(1, o.fixed_duration * tlen[b]);
     } else {
         HIP_OK(hipMemcpyAsync(frames.data(), s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+        prof.fence();
         HIP_OK(hipStreamSynchronize(stream));
+        prof.fence();
     }
     int Lmax = 0;
     for (int b = 0; b < B; ++b) Lmax = std::max(Lmax, frames[b]);
@@ -884,6 +898,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             }
         }
         HIP_OK(hipMemcpyAsync(s2.noise, hn.data(), sizeof(float) * hn.size(), hipMemcpyHostToDevice, stream));
+        prof.fence();
         HIP_OK(hipStreamSynchronize(stream));  // hn goes out of scope
         if (o.collect_taps) snapshot("noise_prior", noise, F, Lmax, B, frames);
     }
@@ -975,6 +990,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     row[(size_t)(n_up + 1) * B + b] = frames[b] <= wn.f1 ? (frames[b] - wn.lo) * M + sadd[n_up] : (wn.f1 - wn.lo) * M;
             }
         HIP_OK(hipMemcpyAsync(s2.win_lens, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
+        prof.fence();
         HIP_OK(hipStreamSynchronize(stream));  // wl goes out of scope
         if (o.on_chunk) {
             const size_t need = (size_t)B * out_stride * sizeof(float);
@@ -1133,6 +1149,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             // final yet and travel again with the next window)
             const size_t g0 = (size_t)wn.f0 * M, g1 = std::min(out_stride, (size_t)wn.f1 * M + (size_t)sadd[n_up]);
             HIP_OK(hipMemcpy2DAsync(host_pcm + g0, out_stride * 4, wave_dst + g0, (size_t)wave_stride * 4, (g1 - g0) * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+            prof.fence();
             hipEvent_t ev;
             HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             chunk_ev.push_back(ev);
@@ -1172,10 +1189,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             if (o.on_chunk) std::memcpy(out->data, host_pcm, sizeof(float) * (size_t)B * out->stride);  // already streamed to the host
             else
                 HIP_OK(hipMemcpy2DAsync(out->data, out->stride * 4, wave_dst, (size_t)wave_stride * 4, out->stride * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+            prof.fence();
         }
     }
     if (!want_async) {
         HIP_OK(hipStreamSynchronize(stream));
+        prof.fence();
         if (prof.on) prof.collect();
     }
     return 0;

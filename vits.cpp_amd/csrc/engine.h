@@ -29,6 +29,7 @@ struct Profiler {
         int name_id;
         hipEvent_t a, b;
         double flop, bytes;
+        bool a_shared;  // a is the previous record's b (back-to-back launches share one event)
     };
     bool on = false;
     std::vector<std::string> names;
@@ -41,7 +42,13 @@ struct Profiler {
     };
     std::vector<Agg> agg;
     hipEvent_t get();
-    void begin(const char* name, double flop, double bytes, hipStream_t s);
+    // chain = true: if the previous timed launch ended on the same stream with nothing in between, its end event doubles as
+    // this launch's start (an event is a barrier packet on the queue: half as many of them in the timed region)
+    void begin(const char* name, double flop, double bytes, hipStream_t s, bool chain = false);
+    void fence() { last_ok = false; }  // something un-timed was queued (or the host waited): do not chain across it
+    hipEvent_t last_b = nullptr;
+    hipStream_t last_s = nullptr;
+    bool last_ok = false;
     void end(hipStream_t s);
     void collect();  // after a stream sync
     void reset();
