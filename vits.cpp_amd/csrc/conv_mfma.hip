@@ -716,7 +716,8 @@ int choose_conv_tile(int rows, int epi, int t_hint) {
     static const int narrow = getenv("VITS_NARROW_TILES") ? atoi(getenv("VITS_NARROW_TILES")) : 64;
     const bool small_t = t_hint <= 128 || (narrow && rows <= narrow);
     if (epi == EPI_GATE) return small_t ? TILE_64x64 : TILE_64x256;
-    if (rows % 128 == 0) return TILE_128x128;
+    static const int t128 = getenv("VITS_TILE128") ? atoi(getenv("VITS_TILE128")) : 1;
+    if (rows % 128 == 0 && t128) return TILE_128x128;
     if (rows % 64 == 0) return small_t ? TILE_64x64 : TILE_64x256;
     return small_t ? TILE_32x64 : TILE_32x256;
 }
