@@ -1195,7 +1195,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     if (!want_async) {
         HIP_OK(hipStreamSynchronize(stream));
         prof.fence();
-        if (prof.on) prof.collect();
+        // (event timings are read back lazily — vits_prof_report / vits_prof_reset — not here: ~1 ms of host work per call
+        // with the device idle would otherwise sit inside the caller's timed region; cap the backlog for long runs)
+        if (prof.on && prof.recs.size() > 50000) prof.collect();
     }
     return 0;
 }
