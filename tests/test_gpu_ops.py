@@ -18,6 +18,8 @@ def rnd(rng, *shape, scale=1.0):
     (32, 32, 3, 1, 300), (32, 32, 7, 3, 517), (32, 32, 11, 5, 1000), (64, 64, 3, 3, 256), (64, 64, 11, 1, 700),
     (128, 128, 7, 5, 400), (256, 256, 3, 1, 130), (256, 256, 11, 5, 260), (192, 768, 3, 1, 128), (768, 192, 3, 1, 128),
     (192, 512, 7, 1, 77), (192, 192, 1, 1, 128), (192, 29, 1, 1, 50), (96, 192, 1, 1, 33), (16, 32, 3, 1, 20), (5, 7, 5, 2, 19),
+    # 16-byte aligned rows (dwordx4 LDS-DMA path, tile origin shifted by 0..3) with lengths just past tile / float4 boundaries
+    (128, 128, 11, 5, 132), (64, 64, 7, 1, 1028), (256, 128, 3, 5, 516), (32, 64, 11, 3, 260), (128, 256, 3, 1, 4), (64, 32, 7, 3, 8),
 ])
 def test_conv1d_matches_oracle(pkg, oracle, cin, cout, k, dil, T):
     rng = np.random.default_rng(cin * 1000 + cout + k)
