@@ -648,12 +648,14 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
         }
     } else {  // EPI_CONVT: GEMM row rho = co*s + phase, column q; output sample n = s*q + phase - crop
         float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+        float* __restrict__ y2b = p.y2 ? p.y2 + (int64_t)b * p.y_bs : nullptr;  // leaky_relu(post_slope) copy for the resblocks' first convs
         const int s = p.ct_stride;
         const int out_len = p.len_out ? p.len_out[b] : p.t_out;
         // stride 8: the 4 registers of a group are phases 4h..4h+3 of ONE output channel at one input position, i.e. 4
         // consecutive output samples -> one dwordx4 store (interior tiles; crop is 0 or 4 so the address stays 16-B aligned)
         const bool wide8 = s == 8 && (p.ct_crop & 3) == 0 && (t0 + BN <= ncols - 1) && t0 > 0 && ((mt0 + MR) * 32 <= p.rows) &&
-                           ((p.y_cs & 3) == 0) && (((uintptr_t)yb & 15) == 0);
+                           ((p.y_cs & 3) == 0) && ((((uintptr_t)yb | (uintptr_t)y2b) & 15) == 0);
+        auto lr = [&](float v) __attribute__((always_inline)) { return fmaxf(v, v * p.post_slope); };
         if (wide8) {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
@@ -665,12 +667,19 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     for (int nr = 0; nr < NR; ++nr) {
                         const int q = colbase + nr * 32;
                         const int n = 8 * q + rowoff - p.ct_crop;
-                        if (n + 3 < out_len)
-                            *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + n) = make_float4(
-                                acc[mr][nr][4 * g] + bias, acc[mr][nr][4 * g + 1] + bias, acc[mr][nr][4 * g + 2] + bias, acc[mr][nr][4 * g + 3] + bias);
-                        else
+                        const float o0 = acc[mr][nr][4 * g] + bias, o1 = acc[mr][nr][4 * g + 1] + bias, o2 = acc[mr][nr][4 * g + 2] + bias,
+                                    o3 = acc[mr][nr][4 * g + 3] + bias;
+                        if (n + 3 < out_len) {
+                            *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + n) = make_float4(o0, o1, o2, o3);
+                            if (y2b) *reinterpret_cast<float4*>(y2b + (int64_t)co * p.y_cs + n) = make_float4(lr(o0), lr(o1), lr(o2), lr(o3));
+                        } else {
+                            const float o[4] = {o0, o1, o2, o3};
                             for (int e = 0; e < 4; ++e)
-                                if (n + e < out_len) yb[(int64_t)co * p.y_cs + n + e] = acc[mr][nr][4 * g + e] + bias;
+                                if (n + e < out_len) {
+                                    yb[(int64_t)co * p.y_cs + n + e] = o[e];
+                                    if (y2b) y2b[(int64_t)co * p.y_cs + n + e] = lr(o[e]);
+                                }
+                        }
                     }
                 }
         } else
@@ -687,7 +696,9 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     const int q = colbase + nr * 32;
                     const int n = s * q + ph - p.ct_crop;
                     if (q >= ncols || n < 0 || n >= out_len) continue;
-                    yb[(int64_t)co * p.y_cs + n] = acc[mr][nr][r] + bias;
+                    const float o = acc[mr][nr][r] + bias;
+                    yb[(int64_t)co * p.y_cs + n] = o;
+                    if (y2b) y2b[(int64_t)co * p.y_cs + n] = lr(o);
                 }
             }
         }

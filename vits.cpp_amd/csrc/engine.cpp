@@ -840,7 +840,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     for (int i = 0; i <= n_up; ++i) sts[i] = round_up(Lw_max * smul[i] + sadd[i], 32);
     for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
     struct S2 {
-        float *zp, *noise, *hout, *gate, *h0, *bu, *by[3], *bt[3], *byl[3], *bs, *pre, *wave;
+        float *zp, *noise, *hout, *gate, *h0, *bu, *bul, *by[3], *bt[3], *byl[3], *bs, *pre, *wave;
         int* win_lens;  // [window][n_up + 2][B]: stage lengths of each utterance inside the window, then its emit end
     } s2;
     const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
@@ -853,6 +853,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         s2.h0 = a.alloc<float>((size_t)B * hp.up_init * lws);
         s2.win_lens = windowed ? a.alloc<int>(wins.size() * (size_t)(n_up + 2) * B) : nullptr;
         s2.bu = a.alloc<float>(big);
+        s2.bul = a.alloc<float>(big);
         for (int j = 0; j < 3; ++j) {
             // one (y, t) pair per concurrently running resblock
             const bool own = j == 0 || (rb_streams_ > 1 && (size_t)j < hp.rb_k.size());
@@ -1059,6 +1060,10 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 c.pre_act = 1;  // leaky_relu before the upsampler (vits.cpp:613)
                 c.slope = hp.lrelu;
                 c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
+                if (C >= lrelu_copy_minc_) {  // activated copy for the first conv of each resblock (see below)
+                    c.y2 = s2.bul;
+                    c.post_slope = hp.lrelu;
+                }
                 HIP_OK(conv("hifigan_upsample_convT", U.up, c));
             }
             // resblock j runs on its own stream (engine.h); only the LAST convolution of each resblock touches the shared
@@ -1079,18 +1084,18 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 // (y itself stays the residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the
                 // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
                 const bool lcopy = C >= lrelu_copy_minc_;
-                TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]);
+                TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]), bul = TR(s2.bul, C, sts[st_out]);
                 for (size_t d = 0; d < nd; ++d) {
                     TensorRef resid = d == 0 ? bu : by;
                     ConvCall c1;
-                    c1.x = (d > 0 && lcopy) ? byl : resid;
+                    c1.x = lcopy ? (d > 0 ? byl : bul) : resid;
                     c1.y = bt;
                     c1.len_in = c1.len_out = d_len[st_out];
                     c1.batch = B;
                     c1.t_in = c1.t_out = smax[st_out];
                     c1.dil = R.dil[d];
                     c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
-                    c1.pre_act = (d > 0 && lcopy) ? 0 : 1;
+                    c1.pre_act = lcopy ? 0 : 1;
                     c1.slope = hp.lrelu;
                     c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
                     c1.post_slope = hp.lrelu;
