@@ -1040,6 +1040,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             c.batch = B;
             c.t_in = c.t_out = Lw;
             c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
+            c.post_act = 2;  // its only reader is the first upsampler, which takes leaky_relu(h0) (vits.cpp:613): activate at the writer
+            c.post_slope = hp.lrelu;
             HIP_OK(conv("hifigan_conv_pre", dec_pre_, c));
         }
         TensorRef cur = h0;
@@ -1057,7 +1059,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 c.batch = B;
                 c.t_in = smax[st_in];
                 c.t_out = smax[st_out];
-                c.pre_act = 1;  // leaky_relu before the upsampler (vits.cpp:613)
+                c.pre_act = 0;  // leaky_relu before the upsampler (vits.cpp:613) was applied by whoever wrote `cur`
                 c.slope = hp.lrelu;
                 c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
                 if (C >= lrelu_copy_minc_) {  // activated copy for the first conv of each resblock (see below)
@@ -1126,6 +1128,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         }
                         // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
                         // scale 1/1 is the identity, so no special case is needed)
+                        if (j + 1 == nk && i + 1 < n_up) {
+                            // the stage output feeds only the next upsampler, which wants leaky_relu of it (vits.cpp:613);
+                            // the last stage stays raw: conv_post applies its own slope (Q2)
+                            c2.post_act = 2;
+                            c2.post_slope = hp.lrelu;
+                        }
                     }
                     const bool last = d + 1 == nd;
                     if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
