@@ -64,6 +64,7 @@ struct ConvParams {
     int t_in, t_out;
     int cin, cout, rows, nchunks;
     int dil, pad_l, xw, lds_off;
+    int nbuf;  // LDS input buffers of the wave-specialised path: 2, or 3 when a chunk of MFMA work is shorter than the DMA latency
     int pre_act;
     float slope;
     int post_act;
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                 off4[j] = (unsigned)(r * p.x_cs + t) * 4u;
             }
             const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
-            auto fill = [&](int c) __attribute__((always_inline)) {
-                float* lbase = xs + (c & 1) * (CK * XWP);
+            constexpr int NI4 = CK / R4 * P4;  // DMA instructions of one dwordx4 fill
+            auto issue = [&](int c, int buf) __attribute__((always_inline)) {
+                float* lbase = xs + buf * (CK * XWP);
                 // LDS-DMA of the whole 32 x XWP tile from clamped (always valid) addresses ...
                 if (x4 && (c + 1) * CK <= p.cin) {
                     // buffer form: descriptor (SGPRs) + per-lane byte offset (loop-invariant VGPR) + scalar row offset — no
@@ -214,7 +216,9 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                                                              (__attribute__((address_space(3))) void*)(lbase + r * XWP + 64 * m), 4, 0, 0);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            };
+            auto finish = [&](int c, int buf) __attribute__((always_inline)) {
+                float* lbase = xs + buf * (CK * XWP);
                 // ... leaky_relu in place (the producer has slack; doing it at the B-operand read of the compute waves
                 // instead puts two VALU ops between every ds_read and its MFMAs: measured -9 % on the k=11 kernels) ...
                 if (!LRELU_AT_READ && p.pre_act) {
@@ -243,14 +247,44 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS writes of this wave done before the barrier
             };
-            fill(0);
-            __syncthreads();
             // (no barrier after the LAST chunk: nothing reuses its buffer. The producer therefore retires a whole chunk
             // before the block does, and with it the fifth wave that keeps a second block from being placed on this CU —
             // the next block's launch and prologue overlap this block's last chunk instead of following its K loop)
-            for (int c = 0; c + 1 < p.nchunks; ++c) {
-                fill(c + 1);
+            if (p.nbuf == 2) {
+                issue(0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                finish(0, 0);
                 __syncthreads();
+                for (int c = 0; c + 1 < p.nchunks; ++c) {
+                    issue(c + 1, (c + 1) & 1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    finish(c + 1, (c + 1) & 1);
+                    __syncthreads();
+                }
+            } else {
+                // three buffers: the DMA runs TWO chunks ahead. Used when a chunk is less MFMA work than one DMA round trip
+                // (1x1 convs, k = 3 on narrow tiles: 0.4-2.7 us against ~2.5 us), where one chunk of look-ahead leaves the
+                // compute waves waiting for every chunk. vmcnt retires in order: waiting until at most one fill's worth of
+                // instructions is outstanding means the OLDER fill has landed (a dword fill has more instructions than NI4,
+                // so the wait is then merely conservative).
+                const int n = p.nchunks;
+                issue(0, 0);
+                if (n > 1) issue(1, 1);
+                if (n > 1 && x4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                finish(0, 0);
+                __syncthreads();
+                int b1 = 1, b2 = 2;  // buffers of chunks c + 1 and c + 2
+                for (int c = 0; c + 1 < n; ++c) {
+                    const bool more = c + 2 < n;
+                    if (more) issue(c + 2, b2);  // last read during chunk c - 1, which every compute wave left before B(c)
+                    if (more && x4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    finish(c + 1, b1);
+                    __syncthreads();
+                    b1 = b2;
+                    b2 = b2 == 2 ? 0 : b2 + 1;
+                }
             }
             return;
         }
@@ -430,8 +464,10 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
         __syncthreads();
         VITS_STAMP(1);
         auto k_loop = [&](auto lr) __attribute__((always_inline)) {
+            int buf = 0;
             for (int c = 0; c < p.nchunks; ++c) {
-                compute_chunk(xrow0 + (c & 1) * (CK * xw), lr);
+                compute_chunk(xrow0 + buf * (CK * xw), lr);
+                buf = buf + 1 == p.nbuf ? 0 : buf + 1;
 #ifdef VITS_PHASE_TIMING
                 if (tid == 0 && c < 4) {
                     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -794,7 +830,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
-    const size_t lds = DB ? (size_t)2 * CK * ((p.xw + 3 + 63) / 64 * 64) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
+    const size_t lds = DB ? (size_t)p.nbuf * CK * ((p.xw + 3 + 63) / 64 * 64) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
 #define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
     do {                                                                                                                              \
         static bool big_lds_set = false;                                                                                              \
@@ -911,8 +947,9 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
             const int64_t mb = (w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
             return nb * mb * c.batch;
         };
-        if (blocks(tile) < 512 && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
-        if (blocks(tile) < 512 && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
+        static const int64_t min_blocks = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 512;
+        if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
+        if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
     }
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
@@ -927,6 +964,15 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.lds_off = span < 0 ? -span : 0;
     p.xw = bn + (span < 0 ? -span : span);
     if ((size_t)2 * CK * p.xw * 4 > 160 * 1024) return hipErrorInvalidValue;
+    {
+        // third LDS buffer (DMA two chunks ahead) where a chunk is less MFMA work than a DMA round trip (~2.5 us = 6k cycles):
+        // taps x (MFMAs per k-step) x 16 k-steps x 64 cycles
+        static const int nbuf_env = getenv("VITS_NBUF") ? atoi(getenv("VITS_NBUF")) : 0;
+        const TileShape t3 = tile_shape(tile);
+        const bool short_chunk = w.kt * t3.mr * t3.nr * 1024 < 8000 && w.nchunks >= 3 && bn == 128;
+        p.nbuf = nbuf_env == 2 || nbuf_env == 3 ? nbuf_env : (short_chunk ? 3 : 2);
+        if (w.nchunks < 2 || (size_t)p.nbuf * CK * ((p.xw + 3 + 63) / 64 * 64) * 4 > 150 * 1024) p.nbuf = 2;
+    }
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise
