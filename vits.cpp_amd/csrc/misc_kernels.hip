@@ -634,6 +634,54 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
     __syncthreads();
     const int pad = (k - 1) / 2;
     const float* xb = x + (int64_t)b * x_bs;
+    // fast path (k = 7, 16-byte aligned rows, away from the sequence ends): one thread = 4 consecutive samples; per channel
+    // three aligned float4 loads cover x[t-4 .. t+7] and feed all 28 products (the scalar path below loads every input 7x).
+    // Same order of accumulation per sample (channel-major, tap-minor), so both paths give identical values.
+    if (k == 7 && (x_cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0) && (t0 & 3) == 0) {
+        const int t = t0 + 4 * threadIdx.x;
+        if (t >= hi) return;
+        if (t >= 4 && t + 8 <= len && t + 4 <= hi) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int c = 0; c < cin; ++c) {
+                const float4* xr = reinterpret_cast<const float4*>(xb + (int64_t)c * x_cs + t - 4);
+                const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
+                float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};  // v[i] = x[t - 4 + i]
+#pragma unroll
+                for (int i = 1; i < 11; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+                const float* wc = sm + c * 7;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {  // sample t + e reads x[t + e + j - 3] = v[e + j + 1]
+                    const float wj = wc[j];
+                    a0 += wj * v[j + 1];
+                    a1 += wj * v[j + 2];
+                    a2 += wj * v[j + 3];
+                    a3 += wj * v[j + 4];
+                }
+            }
+            if (pre) *reinterpret_cast<float4*>(pre + (int64_t)b * p_bs + t) = make_float4(a0, a1, a2, a3);
+            float* wp = wave + (int64_t)b * w_bs + t;
+            wp[0] = tanhf(a0), wp[1] = tanhf(a1), wp[2] = tanhf(a2), wp[3] = tanhf(a3);
+            return;
+        }
+        // sequence ends / emit boundary: this thread's 4 samples through the scalar code
+        for (int e = 0; e < 4; ++e) {
+            const int te = t + e;
+            if (te >= hi) break;
+            float a = 0.f;
+            for (int c = 0; c < cin; ++c) {
+                const float* xr = xb + (int64_t)c * x_cs;
+                for (int j = 0; j < k; ++j) {
+                    const int tt = te + j - pad;
+                    float v = (tt >= 0 && tt < len) ? xr[tt] : 0.f;
+                    v = v > 0.f ? v : v * slope;
+                    a += sm[c * k + j] * v;
+                }
+            }
+            if (pre) pre[(int64_t)b * p_bs + te] = a;
+            wave[(int64_t)b * w_bs + te] = tanhf(a);
+        }
+        return;
+    }
     for (int u = 0; u < 4; ++u) {
         const int t = t0 + u * 256 + threadIdx.x;
         if (t >= hi) continue;
