@@ -170,3 +170,24 @@ def test_device_pcm16_matches_the_host_conversion(pkg):
     finally:
         for b in bufs:
             hip.hipFree(b)
+
+
+def test_tuning_knobs_do_not_change_a_single_bit():
+    """Tiling / scheduling knobs change which kernel instantiation, tile shape, LDS ring depth and
+    stream a convolution runs on — never the order in which an output's products are accumulated. One process per setting
+    (the knobs are read once per process); the PCM of a ragged two-mode batch must hash identically."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "knob_identity.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-1]
+
+    base = run({})
+    for extra in ({"VITS_RB_STREAMS": "1"}, {"VITS_DB_MIN": "2", "VITS_NBUF": "3"}, {"VITS_TILE128": "0", "VITS_NARROW_TILES": "0"},
+                  {"VITS_MIN_BLOCKS": "100000", "VITS_LRELU_COPY_MINC": "32"}):
+        assert run(extra) == base, extra

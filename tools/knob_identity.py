@@ -1,0 +1,15 @@
+"""Prints a hash of the PCM of a fixed ragged batch; run under different VITS_* knob settings: the hashes must be equal."""
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from conftest import load_package
+pkg = load_package()
+m = pkg.Model(pkg.synth_model_bytes(0x5EED, 0))
+ids = pkg.synth_ids(6, 48)
+lens = np.array([48, 7, 33, 48, 1, 20], np.int32)
+h = hashlib.sha256()
+for mode in (0, 1):
+    pcm, lengths, frames = m.process_batch(ids, id_lengths=lens, mode=mode, noise_seed=5)
+    for p in pcm:
+        h.update(p.tobytes())
+print(h.hexdigest()[:16])
