@@ -77,3 +77,35 @@ def test_pcm16_and_wav_writer_match_the_reference_driver(pkg, tmp_path):
     assert (fsz, afmt, ch, sr, br, align, bits, dbytes) == (16, 1, 1, 16000, 32000, 2, 16, 2 * x.size)
     assert size == 4 + (8 + 16) + (8 + dbytes)
     np.testing.assert_array_equal(np.frombuffer(raw[44:], np.int16), want)
+
+
+def test_header_is_plain_c_and_links_from_a_c_caller(pkg, tmp_path):
+    """include/vits.h must compile as C99 (the reference's consumers are C / Swift FFI, Makefile:21-24) and a C program
+    using the reference's five entry points must link against libvits_hip.so and get NULL + a message — not a crash — for a
+    missing file (the reference throws std::runtime_error across the boundary there, src/vits_model_data.cpp:102)."""
+    import subprocess
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "vits.h"
+static int sink(void* user, int32_t utt, size_t offset, const float* pcm, size_t n) { (void)user; (void)utt; (void)offset; (void)pcm; (void)n; return 0; }
+int main(void) {
+    vits_process_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.on_chunk = sink;
+    vits_model* m = vits_model_load_from_file("/nonexistent/model.ggml");
+    if (m) { vits_result r = vits_model_process(m, "hello"); vits_free_result(r); vits_free_model(m); return 2; }
+    printf("%s\n", vits_last_error());
+    return strstr(vits_last_error(), "failed to open file") ? 0 : 3;
+}
+''')
+    exe = tmp_path / "caller"
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lvits_hip",
+                         "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
