@@ -77,17 +77,18 @@ struct ConvParams {
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
 // immediates of the ds_read instructions (one base VGPR instead of one per tap). DIL == 0: run-time dilation (generic).
-// DB: wave-specialised double buffering (used when there are several chunks: cin >= 128). The block has FIVE waves:
-//     waves 0-3 only run MFMAs (their only global loads are the L2-resident weight fragments), wave 4 is a PRODUCER that
-//     streams the next 32-channel input tile from HBM straight into the other LDS buffer with LDS-DMA
-//     (global_load_lds_dword: no data VGPRs, no ds_write pass). Reason: vmcnt retires in order, so a compute wave that
-//     issues HBM tile loads itself makes every later weight load wait a full HBM latency (measured: k=3 72 -> 103
-//     TFLOP/s without those stalls). LeakyReLU moves to the B-operand read (max(x, slope*x)), zero padding at the
-//     sequence ends is done by a masked register path in the producer (boundary tiles only).
+// DB: wave-specialised, multi-buffered (every compile-time-dilation conv). The block has FIVE waves:
+//     waves 0-3 only run MFMAs (their only global loads are the L2-resident weight fragments, through a buffer
+//     descriptor), wave 4 is a PRODUCER that streams the next 32-channel input tile from HBM straight into another LDS
+//     buffer with LDS-DMA (buffer_load_dwordx4 ... lds: no data VGPRs, no ds_write pass). Reason: vmcnt retires in order, so
+//     a compute wave that issues HBM tile loads itself makes every later weight load wait a full HBM latency (measured:
+//     k=3 72 -> 103 TFLOP/s without those stalls). The K loop of the compute waves has no vector-ALU instruction at all
+//     (VALU and MFMA share the issue port); LeakyReLU is normally applied by whoever WROTE the input, otherwise by the
+//     producer in LDS (k >= 5) or at the B-operand read (k <= 3); zero padding at the sequence ends is a fix-up by the
+//     producer on boundary tiles only. DESIGN.md section 4.1 has the measurements behind each of these choices.
 #ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/conv_micro.hip): per-block phase timestamps, 100 MHz clock
-__device__ unsigned long long vits_phase_buf[8 * 65536];
-__device__ unsigned long long vits_chunk_buf[8 * 65536];
-__device__ unsigned long long vits_tap_buf[16 * 8192];  // [block < 8192][k-step group]: shader clock inside chunk 1  // shader-clock stamp at the end of chunk c < 8  // [block][0..3] 100 MHz stamps, [4..5] shader-clock stamps of the K loop
+__device__ unsigned long long vits_phase_buf[8 * 65536];  // [block][0..3] 100 MHz stamps, [4..5] shader clock around the K loop, [6..7] HW_ID / XCC_ID
+__device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]: shader clock at the end of chunk c < 4 and behind its barrier
 #define VITS_STAMP(k)                                                                                               \
     do {                                                                                                            \
         if (tid == 0) {                                                                                             \
