@@ -596,7 +596,11 @@ __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs
     __syncthreads();
     if (j >= L) return;
     const int a = tok[tid];
-    for (int c = 0; c < channels; ++c) {
+    // channels are split over blockIdx.z (every element is independent): one block per 256 frames walked all 192 channels
+    // serially through the counter-based normal, 100 us at batch 1
+    const int cpb = (channels + gridDim.z - 1) / gridDim.z;
+    const int c_end = min(channels, (int)(blockIdx.z + 1) * cpb);
+    for (int c = blockIdx.z * cpb; c < c_end; ++c) {
         const float mu = a >= 0 ? mean[(int64_t)b * m_bs + (int64_t)c * m_cs + a] : 0.f;
         const float lv = a >= 0 ? logvar[(int64_t)b * v_bs + (int64_t)c * v_cs + a] : 0.f;
         float e;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs
 
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
                      uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s) {
-    dim3 grid((lmax + 255) / 256, batch);
+    dim3 grid((lmax + 255) / 256, batch, 16);
     hipLaunchKernelGGL(zp_kernel, grid, dim3(256), 0, s, mean.p, mean.bs, mean.cs, logvar.p, logvar.bs, logvar.cs, cum, cum_stride, tok_lens, frames, noise.p,
                        noise.bs, noise.cs, noise_kind, seed, noise_scale, zp.p, zp.bs, zp.cs, channels, cum_stride);
     return hipGetLastError();
