@@ -236,18 +236,18 @@ def main():
                                "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
                                "hbm_frac_if_algorithmic": dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             # HBM bytes per launch of that kernel from the PMC passes (collected separately with rocprofv3 --pmc on this
-            # same command; PMC cannot be sampled from inside the run): profiles/round1_v11_pmc_traffic.json
+            # same command; PMC cannot be sampled from inside the run): profiles/round1_v12_pmc_traffic.json
             try:
                 tiles = {"t0": "2, 2, 2, 2", "t1": "1, 4, 2, 2", "t2": "1, 4, 1, 2", "t3": "1, 4, 2, 1", "t4": "1, 4, 1, 1"}
                 kk, dd, tt, ee = dom_key.split("|")
-                with open(os.path.join(ROOT, "profiles", "round1_v11_pmc_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "round1_v12_pmc_traffic.json")) as fh:
                     pmc = json.load(fh)["kernels"]
                 cands = [v for n, v in pmc.items() if n.startswith(f"void vits::conv_mfma_kernel<{kk[1:]}, {dd[1:]}, ")
                          and n.endswith(f"{tiles[tt]}, {ee[1:]}>(vits::ConvParams)")]
                 if cands:
                     best = max(cands, key=lambda v: v["launches_sampled"])
                     res["roofline"]["traffic"] = best["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE calibrated x1.143 + WRITE_SIZE, profiles/round1_v11_pmc_traffic.json)"
+                    res["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE calibrated x1.143 + WRITE_SIZE, profiles/round1_v12_pmc_traffic.json)"
                     res["roofline"]["traffic_over_algorithmic"] = best["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
             except Exception:
                 pass
