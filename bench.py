@@ -9,15 +9,21 @@ the counter-based synthetic streams of include/vits_synth_noise.h. Nothing is sk
 the model's own predictions (data-dependent shapes, one host read of B frame counts per step like the reference's
 vits.cpp:1133), unless --pinned is given.
 
-N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL), rank r synthesises its own 64 utterances
-(weak scaling, no data-path collective) and the PCM of all ranks is all-gathered over xGMI at the end of every step.
+N GPUs (`--gpus N`): one process per GPU (torch.distributed, backend nccl == RCCL), rank r synthesises its own 64
+utterances (weak scaling, no data-path collective) and the PCM of all ranks is all-gathered over xGMI at the end of every
+step. Started by torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) this process IS one rank; started plainly with
+--gpus N > 1 it is a LAUNCHER: it starts the N rank processes itself before touching the GPU, relays rank 0's JSON
+line, and fails if any rank fails or fewer than N devices are visible — it never falls back to fewer ranks.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,40 +53,109 @@ def algorithmic_flops(T, frames):
     return enc + dur + 14155776 * L + 614907904 * L
 
 
-def cpu_baseline(model_bytes, ids, seed, budget_s=15.0):
+def cpu_baseline(jobs, mode_name, with_one_thread=True, budget_s=9.0):
     """Times the CPU oracle (restatement of the reference ggml graph; the ggml fork itself is not vendored) on this host's
     cores with the reference's method (sequential batch-1 calls, wall clock; test/bench_e2e.cpp:79-89) on a bounded sample
-    of the same workload. Thread count: the reference would use max(hardware_concurrency, 6) (src/include/common.h:19-21),
-    which on a 256-thread host is far past the oracle's scaling knee, so a short sweep picks the FASTEST thread count and that
-    one is reported (`cores`); the figure at the reference's rule is kept alongside for transparency."""
+    of the same workload. Three SUSTAINED figures (each after one untimed warm-up call: the first call pages the model in):
+      * at the reference's thread rule max(hardware_concurrency, 6) (src/include/common.h:19-21),
+      * at the fastest thread count of a short sweep (on a 256-thread host the rule is far past the oracle's scaling knee) —
+        this one is `value` / `cores`,
+      * at 1 thread.
+    jobs: [(model_bytes, ids [n, T], noise_seed)]; utterances are taken round-robin from the jobs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    m = O.Model(model_bytes)
+    models = [O.Model(mb) for mb, _, _ in jobs]
+    omode = O.MODE_REFERENCE if mode_name == "reference" else O.MODE_HF
     hw = max(os.cpu_count() or 1, 6)
+    order = [(j, u) for u in range(max(len(i) for _, i, _ in jobs)) for j in range(len(jobs)) if u < len(jobs[j][1])]
 
-    def run(u, threads):
+    def run(k, threads):
+        j, u = order[k % len(order)]
         t = time.perf_counter()
-        r = m.process_ids(ids[u], mode=O.MODE_REFERENCE, noise_kind=O.NOISE_COUNTER, noise_seed=seed + u, threads=threads, taps=["waveform"])
+        r = models[j].process_ids(jobs[j][1][u], mode=omode, noise_kind=O.NOISE_COUNTER, noise_seed=jobs[j][2] + u, threads=threads, taps=["waveform"])
         return r["waveform"].size, time.perf_counter() - t
 
+    def sustained(threads, budget, max_n):
+        t0 = time.perf_counter()
+        samples = n = 0
+        while n < max_n:
+            sz, _ = run(n, threads)
+            samples += sz
+            n += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        return {"value": samples / dt, "threads": threads, "utterances": n, "wall_s": dt, "rtf_16k": dt / (samples / 16000.0)}
+
+    run(0, min(hw, 32))  # warm-up (untimed)
     sweep = {}
-    for th in sorted({min(hw, c) for c in (8, 16, 32, 64)} | {hw}):
+    for th in sorted({min(hw, c) for c in (8, 16, 32, 64)}):
         n, dt = run(0, th)
         sweep[th] = n / dt
     best = max(sweep, key=sweep.get)
-    t0 = time.perf_counter()
-    samples, n = 0, 0
-    for u in range(ids.shape[0]):
-        sz, _ = run(u, best)
-        samples += sz
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": samples / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "sample": f"{n} utterance(s) of the same workload ({ids.shape[1]} ids each, reference mode), {dt:.1f} s wall, "
-                      f"CPU restatement of the reference ggml graph (ggml fork not vendored); thread count = fastest of a sweep",
-            "rtf_16k": dt / (samples / 16000.0), "host_threads": hw, "thread_sweep_samples_per_s": {str(k): v for k, v in sweep.items()}}
+    fastest = sustained(best, budget_s, len(order))
+    at_rule = fastest if hw == best else sustained(hw, 4.0, 4)
+    one = sustained(1, 0.0, 1) if with_one_thread else None  # one utterance (several seconds)
+    T = jobs[0][1].shape[1]
+    res = {"value": fastest["value"], "unit": "samples/s", "cores": best, "kind": "port",
+           "sample": f"{fastest['utterances']} utterance(s) of the same workload ({T} ids each, {mode_name} mode), {fastest['wall_s']:.1f} s wall, sequential "
+                     f"batch-1 calls (method of test/bench_e2e.cpp:79-89), CPU restatement of the reference ggml graph (ggml fork not vendored); "
+                     f"thread count = fastest of the sweep {sorted(sweep)}",
+           "rtf_16k": fastest["rtf_16k"], "host_threads": os.cpu_count(),
+           "at_reference_thread_rule": at_rule, "thread_sweep_samples_per_s": {str(k): v for k, v in sweep.items()}}
+    if one:
+        res["one_thread"] = one
+    return res
+
+
+def find_profile_artifact(pkg, suffix):
+    """Newest profiles/*<suffix> whose recorded source hash equals the library sources of THIS run (the PMC passes are
+    separate rocprofv3 runs over this same command; a file collected for another build would be stale, so it is ignored)."""
+    want = pkg.source_sha16()
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        if d.get("source_sha16") == want and (best is None or os.path.getmtime(path) > os.path.getmtime(best[0])):
+            best = (path, d)
+    return best
+
+
+def launcher(args):
+    """--gpus N without torchrun: start the N ranks as fresh child processes. Nothing here touches the GPU
+    (torch.cuda.device_count() does not initialise it on this image), and no process that did is ever re-exec'd."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} device(s) visible; refusing to run fewer ranks\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    line = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no result\n")
+        return 1
+    print(line[-1])
+    return 0
 
 
 def main():
@@ -88,31 +163,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
-    ap.add_argument("--ids-per-utt", type=int, default=128, help="encoder input ids per utterance (after blank interspersing)")
+    ap.add_argument("--workload", choices=["c3", "c5"], default="c3",
+                    help="c3 (BASELINE.json metric): one model, batch 64 x 128 ids. c5: two resident models with bf16-stored weights, "
+                         "1024-id utterances, calls interleaved (BASELINE.json configs[4])")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (per model); default 64 (c3) / 8 (c5)")
+    ap.add_argument("--ids-per-utt", type=int, default=0, help="encoder input ids per utterance (after blank interspersing); default 128 (c3) / 1024 (c5)")
     ap.add_argument("--pinned", type=int, default=0, help=">0: pin every id to this many frames (SURVEY §8d run ii)")
     ap.add_argument("--mode", choices=["reference", "hf"], default="reference")
+    ap.add_argument("--arith", choices=["f32", "bf16", "f16"], default="f32",
+                    help="conv operand precision: f32 (exact, default), or 16-bit MFMA operands with fp32 accumulation (vits_model_set_arith)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the pinned-duration and host-PCM passes reported beside the headline")
     ap.add_argument("--pcm16", action="store_true", help="multi-GPU: convert to int16 on the device and gather that (half the bytes)")
+    ap.add_argument("--balance", choices=["none", "frames"], default="none",
+                    help="multi-GPU: 'frames' = every step first predicts frames (frames_only pre-pass on the own block), all-gathers "
+                         "them, and re-shards the global batch so that the per-rank frame sums are equal (SURVEY §8e)")
     ap.add_argument("--chunk-frames", type=int, default=0,
                     help="run the vocoder in windows of this many frames (vits_process_opts.vocoder_chunk_frames); 0 = whole utterance")
     ap.add_argument("--single-pass", action="store_true",
-                    help="instrumented (serialised) warmup + timed region only, no second pass: every launch of the run is then one "
+                    help="instrumented (serialised) warmup + timed region only, no further passes: every launch of the run is then one "
                          "the HIP events timed, which is what a rocprofv3 --kernel-trace of this command is compared against")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launcher(args))
+    world = int(env_world or "1")
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}\n")
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank}")
     torch.cuda.set_device(local_rank)
     # VITS_BENCH_FORCE_DIST=1: run the RCCL exchange even with one rank (exercises the N > 1 code path on a 1-GPU box)
     dist_on = world > 1 or os.environ.get("VITS_BENCH_FORCE_DIST") == "1"
@@ -128,26 +219,53 @@ def main():
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
 
-    B, T = args.batch, args.ids_per_utt
+    c5 = args.workload == "c5"
+    B = args.batch or (8 if c5 else 64)
+    T = args.ids_per_utt or (1024 if c5 else 128)
     mode = pkg.MODE_REFERENCE if args.mode == "reference" else pkg.MODE_HF
-    model_bytes = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL)
-    model = pkg.Model(model_bytes)
-    model.set_mode(mode)
-    # rank r owns utterances [r*B, (r+1)*B): ids seed 1234+utt, noise seed 4321+utt
-    ids = pkg.synth_ids(B * world, T)[rank * B:(rank + 1) * B]
-    noise_seed = 4321 + rank * B
+    # c3: "vits-english"; c5: "vits-spanish + english": two synthetic weight sets resident at once, conv weights stored as bf16
+    model_specs = [(0x5EED, pkg.SYNTH_FULL | pkg.SYNTH_BF16, 1234), (0xBEEF, pkg.SYNTH_FULL | pkg.SYNTH_BF16, 91234)] if c5 else [(0x5EED, pkg.SYNTH_FULL, 1234)]
+    arith = {"f32": pkg.ARITH_F32, "bf16": pkg.ARITH_BF16, "f16": pkg.ARITH_F16}[args.arith]
     cap = 256 * 8 * T + 294  # PCM row capacity: up to 8 frames per id
-    out = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+    jobs = []
+    for seed, arch, ids_seed in model_specs:
+        mb = pkg.synth_model_bytes(seed, arch)
+        m = pkg.Model(mb)
+        m.set_mode(mode)
+        if arith != pkg.ARITH_F32:
+            m.set_arith(arith)
+        ids_all = pkg.synth_ids(B * world, T, ids_seed=ids_seed)  # global batch; rank r owns [r*B, (r+1)*B) unless --balance
+        jobs.append({"model": m, "bytes": mb, "ids_all": ids_all, "ids": ids_all[rank * B:(rank + 1) * B], "offsets": None,
+                     "out": torch.empty((B, cap), dtype=torch.float32, device="cuda")})
+    noise_base = 4321  # global utterance u draws from the counter stream with seed 4321 + u, wherever it runs
 
-    def step(profile=False):
-        _, lengths, frames = model.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_seed, fixed_duration=args.pinned,
-                                                 out_device=out.data_ptr(), out_device_stride=cap, skip_host_copy=True,
-                                                 vocoder_chunk_frames=args.chunk_frames)
-        if dist_on:
-            # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
-            lens_d = torch.from_numpy(lengths).cuda()
-            mg.gather_pcm(mg.to_pcm16(pkg, out, lens_d) if args.pcm16 else out, lens_d)
-        return lengths, frames
+    def step(host_pcm=False, pinned=0, collect=None):
+        pinned = pinned or args.pinned
+        tot_len, tot_frames = [], []
+        for j in jobs:
+            m, ids, offs = j["model"], j["ids"], j["offsets"]
+            if dist_on and args.balance == "frames" and world > 1:
+                # dispatcher pre-pass: predicted frames of the own block -> all ranks -> identical balanced assignment
+                _, _, fr = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_base + rank * B, fixed_duration=pinned, frames_only=True)
+                all_fr = mg.gather_frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+                mine = mg.balanced_shards(all_fr, world)[rank]
+                ids, offs = j["ids_all"][mine], np.asarray(mine, np.int32)
+            if offs is None:
+                kw = {"noise_seed": noise_base + rank * B}
+            else:
+                kw = {"noise_seed": noise_base, "noise_seed_offsets": offs}
+            _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, fixed_duration=pinned, out_device=j["out"].data_ptr(),
+                                                 out_device_stride=cap, skip_host_copy=not host_pcm, keep_pcm=False,
+                                                 vocoder_chunk_frames=args.chunk_frames, **kw)
+            if dist_on:
+                # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
+                lens_d = torch.from_numpy(lengths).cuda()
+                g, gl = mg.gather_pcm(mg.to_pcm16(pkg, j["out"], lens_d) if args.pcm16 else j["out"], lens_d)
+                if collect is not None:
+                    collect.append((g, gl))
+            tot_len.append(lengths)
+            tot_frames.append(frames)
+        return np.concatenate(tot_len), np.concatenate(tot_frames)
 
     def fence():
         torch.cuda.synchronize()
@@ -155,33 +273,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        fence()
+        t = time.perf_counter()
+        samples = 0
+        for _ in range(n):
+            lengths, frames = step(**kw)
+            samples += int(lengths.sum())
+        fence()
+        return time.perf_counter() - t, samples, frames
+
+    models = [j["model"] for j in jobs]
     if args.single_pass and not args.no_prof:
-        model.prof_enable(True)
+        for m in models:
+            m.prof_enable(True)
     for _ in range(args.warmup):
         step()
     fence()
     if not args.no_prof:
-        model.prof_reset()
-        model.prof_enable(True)
-    t0 = time.perf_counter()
-    total_samples = 0
-    for _ in range(args.steps):
-        lengths, frames = step()
-        total_samples += int(lengths.sum())
-    fence()
-    elapsed = time.perf_counter() - t0
-    model.prof_enable(False)
-    # second pass of the same K steps in the library's default configuration: no per-kernel events, and therefore the three
-    # resblocks of every vocoder stage on concurrent streams (the profiler serialises them so that kernel durations are
-    # meaningful). Reported beside the headline, which stays the instrumented region the roofline is measured in.
-    elapsed_plain = None
-    if not args.no_prof and not args.single_pass:
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed_plain = time.perf_counter() - t1
+        for m in models:
+            m.prof_reset()
+            m.prof_enable(True)
+    elapsed, total_samples, frames = timed(args.steps)
+    for m in models:
+        m.prof_enable(False)
+    # further passes of the same K steps, reported BESIDE the headline (which stays the instrumented region the roofline is
+    # measured in): (a) the library's default configuration: no per-kernel events, and therefore the three resblocks of every
+    # vocoder stage on concurrent streams (the profiler serialises them so that kernel durations are meaningful);
+    # (b) durations pinned to 2 frames per id (SURVEY §8d run ii: equal lengths, L = 2T); (c) the PCM also copied to host
+    # memory (what the drop-in vits_model_process returns) — PCIe-inclusive, never `value`.
+    extra = {}
+    if not args.single_pass and world == 1:
+        if not args.no_prof:
+            e, s, _ = timed(args.steps)
+            extra["plain"] = (e, s)
+        if not args.no_extra_passes:
+            step(pinned=2)
+            e, s, fr = timed(args.steps, pinned=2)
+            extra["pinned"] = (e, s, fr)
+            step(host_pcm=True)
+            e, s, _ = timed(args.steps, host_pcm=True)
+            extra["host"] = (e, s)
     if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -191,30 +323,50 @@ def main():
         total_samples = int(ts.item())
 
     if rank == 0:
-        sr = model.sampling_rate
+        sr = models[0].sampling_rate
         value = total_samples / elapsed
         flops_step = sum(algorithmic_flops(T, int(f)) for f in frames) * world
+        dur_txt = "predicted" if not args.pinned else "pinned %d frames/id" % args.pinned
+        if c5:
+            workload = (f"vits-spanish + english stand-ins: TWO resident MMS-TTS-architecture models (synthetic weights, seeds 0x5EED / 0xBEEF, conv weights "
+                        f"stored as bf16), {B} utterances x {T} ids per model per step, calls interleaved, {dur_txt} durations, mode={args.mode}, conv arithmetic {args.arith}")
+        else:
+            workload = (f"vits-english (MMS-TTS architecture, synthetic weights), batch={B} per GPU, {T} ids per utterance, {dur_txt} durations, "
+                        f"mode={args.mode}, conv arithmetic {args.arith}")
         res = {
-            "metric": "audio samples/sec end-to-end (ids -> fp32 PCM in HBM), vits-english architecture, batch=64 x 128 ids",
+            "metric": "audio samples/sec end-to-end (ids -> fp32 PCM in HBM), vits-english architecture, batch=64 x 128 ids" if not c5 else
+                      "audio samples/sec end-to-end (ids -> fp32 PCM in HBM), two resident bf16-stored models, 1024-id utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"vits-english (MMS-TTS architecture, synthetic weights), batch={B} per GPU, {T} ids per utterance, "
-                                   f"{'predicted' if not args.pinned else 'pinned %d frames/id' % args.pinned} durations, mode={args.mode}",
-                       "batch_per_gpu": B, "ids_per_utterance": T, "frames_per_utterance_mean": float(np.mean(frames)),
+            "dtype": args.arith, "data": "synthetic",
+            "config": {"workload": workload, "batch_per_gpu": B * len(jobs), "ids_per_utterance": T, "frames_per_utterance_mean": float(np.mean(frames)),
                        "samples_per_step": total_samples // args.steps, "sampling_rate": sr, "parallelism": f"utterance-sharded x{world}",
-                       "pcm_destination": "device (HBM)", "vocoder_chunk_frames": args.chunk_frames},
+                       "shard_balance": args.balance, "pcm_destination": "device (HBM)", "vocoder_chunk_frames": args.chunk_frames,
+                       "source_sha16": pkg.source_sha16()},
             "rtf": elapsed / (total_samples / float(sr)), "rtf_22050": elapsed / (total_samples / 22050.0),
             "algorithmic_tflops": flops_step * args.steps / elapsed / 1e12,
             "frac_fp32_peak_whole_path": flops_step * args.steps / elapsed / 1e12 / (PEAK_F32_TFLOPS * world),
         }
-        if elapsed_plain is not None and world == 1:
-            res["value_without_kernel_events"] = total_samples / elapsed_plain
-            res["ms_per_step_without_kernel_events"] = 1000.0 * elapsed_plain / args.steps
-            res["without_kernel_events_note"] = "library default: no per-kernel HIP events, resblocks of a stage on 3 concurrent streams" 
+        if "plain" in extra:
+            e, s = extra["plain"]
+            res["value_without_kernel_events"] = s / e
+            res["ms_per_step_without_kernel_events"] = 1000.0 * e / args.steps
+            res["without_kernel_events_note"] = "library default: no per-kernel HIP events, resblocks of a stage on 3 concurrent streams"
+        if "pinned" in extra:
+            e, s, fr = extra["pinned"]
+            fl = sum(algorithmic_flops(T, int(f)) for f in fr)
+            res["pinned_durations"] = {"value": s / e, "ms_per_step": 1000.0 * e / args.steps, "samples_per_step": s // args.steps, "frames_per_id": 2,
+                                       "algorithmic_tflops": fl * args.steps / e / 1e12, "frac_fp32_peak_whole_path": fl * args.steps / e / 1e12 / PEAK_F32_TFLOPS,
+                                       "note": "SURVEY 8d run (ii): every id lasts 2 frames (equal lengths), library default configuration"}
+        if "host" in extra:
+            e, s = extra["host"]
+            res["host_pcm"] = {"value": s / e, "ms_per_step": 1000.0 * e / args.steps,
+                               "note": "PCM also copied to pageable host memory (what the drop-in vits_model_process returns): PCIe-inclusive, never the headline"}
         if not args.no_prof:
-            rep = model.prof_report()["kernels"]
-            # group by kernel instantiation (taps, tile, epilogue) == one rocprofv3 kernel name
+            rep = []
+            for m in models:
+                rep += m.prof_report()["kernels"]
+            # group by kernel instantiation (taps, dilation, tile, epilogue) == one rocprofv3 kernel name
             groups = {}
             for k in rep:
                 parts = k["name"].split("|")
@@ -230,44 +382,50 @@ def main():
             avg_ms = dom["ms"] / dom["calls"]
             achieved = dom["flop"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
             all_ms = sum(g["ms"] for g in groups.values())
-            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                               "traffic": None, "kernel": "conv_mfma_kernel<" + dom_key + ">", "avg_launch_ms": avg_ms, "launches": dom["calls"],
+            peak = PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0
+            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                               "traffic": None, "kernel": dom_key, "avg_launch_ms": avg_ms, "launches": dom["calls"],
                                "share_of_gpu_time": dom["ms"] / all_ms,
+                               "flop_accounting": "algorithmic: 2 * rows * c_in * taps * (sum over utterances of the real output length), not the padded grid",
                                "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
                                "hbm_frac_if_algorithmic": dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
-            # HBM bytes per launch of that kernel from the PMC passes (collected separately with rocprofv3 --pmc on this
-            # same command; PMC cannot be sampled from inside the run): profiles/round1_v12_pmc_traffic.json
-            try:
-                tiles = {"t0": "2, 2, 2, 2", "t1": "1, 4, 2, 2", "t2": "1, 4, 1, 2", "t3": "1, 4, 2, 1", "t4": "1, 4, 1, 1"}
-                kk, dd, tt, ee = dom_key.split("|")
-                with open(os.path.join(ROOT, "profiles", "round1_v12_pmc_traffic.json")) as fh:
-                    pmc = json.load(fh)["kernels"]
-                cands = [v for n, v in pmc.items() if n.startswith(f"void vits::conv_mfma_kernel<{kk[1:]}, {dd[1:]}, ")
-                         and n.endswith(f"{tiles[tt]}, {ee[1:]}>(vits::ConvParams)")]
-                if cands:
-                    best = max(cands, key=lambda v: v["launches_sampled"])
-                    res["roofline"]["traffic"] = best["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE calibrated x1.143 + WRITE_SIZE, profiles/round1_v12_pmc_traffic.json)"
-                    res["roofline"]["traffic_over_algorithmic"] = best["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
-            except Exception:
-                pass
+            # HBM bytes per launch of that kernel and MFMA-busy fraction from the PMC passes (separate rocprofv3 --pmc runs over
+            # this same command, reduced by tools/pmc_traffic.py / tools/pmc_summary.py): only a file collected for THIS
+            # build (same source hash) is used, otherwise the fields stay null
+            art = find_profile_artifact(pkg, "_pmc_traffic.json")
+            if art:
+                ent = art[1].get("by_bench_key", {}).get(dom_key)
+                if ent:
+                    res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_unit"] = "bytes per launch (" + art[1].get("calibration", "PMC") + "; " + os.path.relpath(art[0], ROOT) + ")"
+                    res["roofline"]["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
+            art = find_profile_artifact(pkg, "_pmc_mfma.json")
+            if art:
+                ent = art[1].get("by_bench_key", {}).get(dom_key)
+                if ent:
+                    res["roofline"]["mfma_busy_frac"] = ent.get("mfma_busy_frac")
+                    res["roofline"]["lds_bank_conflict_frac"] = ent.get("lds_bank_conflict_frac")
+                    res["roofline"]["pmc_source"] = os.path.relpath(art[0], ROOT)
             conv_ms = sum(g["ms"] for kk, g in groups.items() if kk.startswith("k"))
             conv_flop = sum(g["flop"] for kk, g in groups.items() if kk.startswith("k"))
             res["kernel_time_ms_per_step"] = all_ms / args.steps
-            res["all_conv_kernels"] = {"tflops": conv_flop / (conv_ms * 1e-3) / 1e12, "frac_of_peak": conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+            res["all_conv_kernels"] = {"tflops": conv_flop / (conv_ms * 1e-3) / 1e12, "frac_of_peak": conv_flop / (conv_ms * 1e-3) / 1e12 / peak,
                                        "share_of_gpu_time": conv_ms / all_ms}
-            top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]
+            top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:10]
             res["top_kernels"] = [{"kernel": kk, "ms_per_step": g["ms"] / args.steps, "calls_per_step": g["calls"] / args.steps,
-                                   "tflops": (g["flop"] / (g["ms"] * 1e-3) / 1e12) if g["flop"] else None} for kk, g in top]
+                                   "tflops": (g["flop"] / (g["ms"] * 1e-3) / 1e12) if g["flop"] else None,
+                                   "algorithmic_gbs": (g["bytes"] / (g["ms"] * 1e-3) / 1e9) if g["bytes"] else None} for kk, g in top]
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(model_bytes, ids, noise_seed)
+            n_cpu = 24 if not c5 else 1
+            cb = cpu_baseline([(j["bytes"], j["ids"][:n_cpu], noise_base) for j in jobs], args.mode, with_one_thread=not c5)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(res))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    model.close()
+    for m in models:
+        m.close()
 
 
 if __name__ == "__main__":

@@ -70,6 +70,22 @@ VITS_API const char* vits_last_error(void);
 VITS_API int vits_model_set_mode(vits_model* model, int mode);
 VITS_API int vits_model_get_mode(const vits_model* model);
 
+/* Conv arithmetic. The reference's conv is fp16 x fp16 -> fp32: weights are cast to fp16 by the exporter
+ * (scripts/export_vits.py:87) and the activations are rounded to fp16 by the im2col in front of every conv
+ * (src/include/custom-ops.h:684-690).
+ *   VITS_ARITH_F32 (default): activations stay fp32, weights are the stored 16-bit values widened exactly, fp32 MFMA
+ *     (v_mfma_f32_32x32x2_f32) — the exact-arithmetic parity mode the headline is measured in.
+ *   VITS_ARITH_F16: the literal Q7 arithmetic: conv inputs rounded to fp16 (round-to-nearest-even) where the tile is staged,
+ *     fp16 weights, fp32 accumulation on v_mfma_f32_32x32x16_f16.
+ *   VITS_ARITH_BF16: the same with bf16 operands (BASELINE.json configs[4]: bf16 weights) on v_mfma_f32_32x32x16_bf16.
+ * 16-bit modes apply to every Conv1d / ConvTranspose1d / Linear of the path; everything else (layer norms, attention
+ * softmax, splines, gates, residual adds, accumulators) stays fp32. Set between calls, not during one. */
+#define VITS_ARITH_F32 0
+#define VITS_ARITH_BF16 1
+#define VITS_ARITH_F16 2
+VITS_API int vits_model_set_arith(vits_model* model, int arith);
+VITS_API int vits_model_get_arith(const vits_model* model);
+
 /* Noise source for the two N(0,1) draws (vits.cpp:948 [T,2] and :1059 [L,192]). */
 #define VITS_NOISE_REFERENCE 0 /* libstdc++ minstd_rand0 + normal_distribution<float>, global, host-serial */
 #define VITS_NOISE_COUNTER 1   /* include/vits_synth_noise.h, evaluated on the device                       */
@@ -103,11 +119,18 @@ typedef struct vits_process_opts {
                                      field halo on both sides) instead of the whole utterance: activation memory is
                                      bounded by the window, and the PCM is BIT-IDENTICAL to the unchunked result.
                                      Ignored with collect_taps. 0 = whole utterance. */
-    int32_t reserved0;
+    int32_t frames_only;          /* 1: run the text encoder and the duration predictor only: the result carries frames[] and
+                                     lengths[] (samples) per utterance and no audio. For dispatchers: sizing out_device,
+                                     balancing utterance shards by predicted frames. Same noise -> same durations
+                                     as the full call. */
     vits_chunk_callback on_chunk; /* optional: called on the calling thread as each window's PCM reaches the host,
                                      while the device already works on the next windows (needs vocoder_chunk_frames>0
                                      and a host copy, i.e. skip_host_copy=0). Non-zero return aborts the call. */
     void* on_chunk_user;
+    const int32_t* noise_seed_offsets; /* VITS_NOISE_COUNTER, optional host [B]: utterance b draws from the stream with seed
+                                          noise_seed + noise_seed_offsets[b] instead of noise_seed + b. Lets a dispatcher
+                                          re-order or re-shard utterances (e.g. balance ranks by frames) without changing
+                                          any utterance's audio. */
 } vits_process_opts;
 
 typedef struct vits_batch_result {
@@ -157,6 +180,9 @@ VITS_API void vits_free_bytes(char* bytes);
 /* Parse a model file and write it back (host only): byte-exact round trip of the reference's format
  * (reader src/vits_model_data.cpp:29-97 + src/vits_tokenizer.cpp:22-55, writer scripts/export_vits.py:5-70). */
 VITS_API int vits_model_file_reserialize(const char* in, size_t in_size, char** out, size_t* out_size);
+/* Everything vits_model_load_from_bytes checks before it uploads (container format, hyper-parameters, the shape of every
+ * tensor against them), on the host only. 0 = loadable; -1 = rejected (vits_last_error says which tensor and why). */
+VITS_API int vits_model_file_validate(const char* bytes, size_t size);
 /* Tokenize with the vocabulary stored in a model file, without loading the model onto a device. */
 VITS_API int64_t vits_model_file_tokenize(const char* model_bytes, size_t size, const char* text, int32_t* ids, size_t cap);
 

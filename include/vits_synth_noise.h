@@ -19,7 +19,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__) /* compiled by hipcc: usable from gfx950 device code; plain host C/C++ otherwise (oracle, tests) */
 #define VITS_HD __host__ __device__ static inline
 #else
 #define VITS_HD static inline

@@ -47,7 +47,7 @@ class Pool {
     void run(int threads, int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
         std::unique_lock<std::mutex> run_lock(run_mu_);  // one parallel region at a time
         const int nt = (int)std::min<int64_t>(threads, n);
-        ensure(nt - 1);
+        resize(std::max(threads, 1) - 1);
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = &fn;
@@ -73,6 +73,9 @@ class Pool {
     int64_t n_ = 0, chunk_ = 1;
     std::atomic<int64_t> next_{0};
     int active_ = 0, pending_ = 0;
+    int limit_ = 1 << 30;  // workers with id >= limit_ retire (the pool follows the requested thread count DOWN as well:
+                           // every region wakes all parked workers, so 255 idle ones left over from a 256-thread run make a
+                           // 32-thread run 1.8x slower — the sweep-vs-sustained gap of round 1's cpu_baseline)
     uint64_t epoch_ = 0;
     bool stop_ = false;
     void work() {
@@ -82,15 +85,28 @@ class Pool {
             (*fn_)(b, std::min(n_, b + chunk_));
         }
     }
-    void ensure(int count) {
+    void resize(int count) {
+        if ((int)workers_.size() > count) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                limit_ = count;
+            }
+            cv_.notify_all();
+            while ((int)workers_.size() > count) {
+                workers_.back().join();
+                workers_.pop_back();
+            }
+            std::lock_guard<std::mutex> lk(mu_);
+            limit_ = 1 << 30;
+        }
         while ((int)workers_.size() < count) {
             const int id = (int)workers_.size();
             workers_.emplace_back([this, id] {
                 uint64_t seen = 0;
                 for (;;) {
                     std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && id < active_); });
-                    if (stop_) return;
+                    cv_.wait(lk, [&] { return stop_ || id >= limit_ || (epoch_ != seen && id < active_); });
+                    if (stop_ || id >= limit_) return;
                     seen = epoch_;
                     lk.unlock();
                     work();

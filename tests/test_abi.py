@@ -109,3 +109,106 @@ int main(void) {
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+
+
+# ---- model files whose tensor shapes disagree with the hyper-parameters must be rejected at load ------------------------
+def _tensor_headers(data):
+    """(name, header offset of `rank`, rank, ne list, nbytes) for every tensor record of a model file."""
+    import struct
+    off = 0
+
+    def u32():
+        nonlocal off
+        (v,) = struct.unpack_from("<I", data, off)
+        off += 4
+        return v
+
+    def skip_str():
+        nonlocal off
+        n = u32()
+        s = data[off:off + n]
+        off += n
+        return s
+
+    for _ in range(u32()):
+        skip_str()
+        u32()
+    u32(), u32()
+    skip_str(), skip_str()
+    for _ in range(u32()):
+        skip_str(), skip_str()
+    out = []
+    for _ in range(u32()):
+        name = skip_str().decode()
+        u32()  # dtype
+        rank_off = off
+        rank = u32()
+        ne = [u32() for _ in range(rank)]
+        nb = u32()
+        out.append((name, rank_off, rank, ne, nb))
+        off += nb
+    return out
+
+
+def _reshape_tensor(data, name, new_ne):
+    """Same payload, different declared shape (same rank so that the record keeps its size)."""
+    import struct
+    for n, rank_off, rank, ne, nb in _tensor_headers(data):
+        if n == name:
+            assert len(new_ne) == rank, (ne, new_ne)
+            b = bytearray(data)
+            struct.pack_into("<" + "I" * rank, b, rank_off + 4, *new_ne)
+            return bytes(b), ne
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,reshape", [
+    ("text_encoder.encoder.layers.0.attention.q_proj.weight", lambda ne: [ne[0] // 2, ne[1] * 2]),
+    ("text_encoder.embed_tokens.weight", lambda ne: [ne[1], ne[0]]),
+    ("text_encoder.encoder.layers.1.attention.emb_rel_k", lambda ne: [ne[1], ne[0], ne[2]]),
+    ("text_encoder.encoder.layers.0.feed_forward.conv_1.weight", lambda ne: [ne[1], ne[0], ne[2]]),
+    ("duration_predictor.conv_dds.convs_dilated.0.weight", lambda ne: [ne[2], ne[1], ne[0]]),
+    ("duration_predictor.flows.2.conv_proj.weight", lambda ne: [ne[0], ne[2], ne[1]]),
+    ("flow.flows.0.wavenet.in_layers.0.weight", lambda ne: [ne[0], ne[2], ne[1]]),
+    ("decoder.upsampler.0.weight", lambda ne: [ne[0] * 2, ne[1] // 2, ne[2]]),
+    ("decoder.resblocks.0.convs1.0.weight", lambda ne: [ne[1], ne[0], ne[2]]),
+    ("decoder.conv_post.weight", lambda ne: [ne[1], ne[0], ne[2]]),
+    ("decoder.conv_pre.bias", lambda ne: [ne[0] // 2]),
+])
+def test_tensor_shapes_are_checked_against_the_hyper_parameters(pkg, tiny_bytes, name, reshape):
+    """shapes from the file were trusted (host over-read in the q/k/v memcpy, device out-of-bounds reads for
+    embeddings / depthwise / rel_k). Every tensor is now checked at load; vits_model_file_validate runs the same checks
+    without a device. The payload size still matches the declared shape here, so only the shape check can catch it."""
+    import struct
+    pkg.validate(tiny_bytes)  # the unmodified file passes
+    if name.endswith(".bias"):
+        # a bias with half the elements: shrink the record (rank 1)
+        for n, rank_off, rank, ne, nb in _tensor_headers(tiny_bytes):
+            if n == name:
+                new_n = reshape(ne)[0]
+                esz = nb // ne[0]
+                b = bytearray(tiny_bytes[:rank_off + 4]) + struct.pack("<II", new_n, new_n * esz) + tiny_bytes[rank_off + 12:rank_off + 12 + new_n * esz] + \
+                    tiny_bytes[rank_off + 12 + nb:]
+                bad = bytes(b)
+                break
+    else:
+        ne0 = next(h[3] for h in _tensor_headers(tiny_bytes) if h[0] == name)
+        bad, _ = _reshape_tensor(tiny_bytes, name, reshape(ne0))
+    with pytest.raises(pkg.VitsError) as ei:
+        pkg.validate(bad)
+    assert name.rsplit(".", 1)[0] in str(ei.value), str(ei.value)  # the message names the offending tensor
+    assert not pkg.lib().vits_model_load_from_bytes(bad, len(bad))  # the loader refuses it too (with or without a GPU)
+
+
+def test_tensor_dimension_product_overflow_is_rejected(pkg, tiny_bytes):
+    """Four u32 dimensions can wrap a 64-bit product back to the payload size; the parser counts with an overflow guard."""
+    import struct
+    name, rank_off, rank, ne, nb = _tensor_headers(tiny_bytes)[0]
+    # rebuild the record with rank 4 and dims whose 64-bit product wraps to the true element count
+    esz = nb // int(__import__("numpy").prod(ne))
+    count = nb // esz
+    dims = [1 << 31, 1 << 31, 4, count]  # 2^64 * count == count (mod 2^64) for the product of the first three = 2^64
+    rec = struct.pack("<I", 4) + struct.pack("<IIII", *dims) + struct.pack("<I", nb)
+    bad = tiny_bytes[:rank_off] + rec + tiny_bytes[rank_off + 4 + 4 * rank + 4:]
+    with pytest.raises(pkg.VitsError, match="overflows|byte length"):
+        pkg.validate(bad)

@@ -74,8 +74,9 @@ def test_two_models_resident_and_interleaved(pkg, oracle, full_bytes):
 
 
 def test_full_benchmark_size_properties(pkg, full_model):
-    """BASELINE.json config 3 shape (batch 64 x 128 ids). Too big for the oracle, so: exact determinism, exact sample
-    counts, bounded output, and batch invariance (utterance b of the batch == the same utterance alone)."""
+    """BASELINE.json config 3 shape (batch 64 x 128 ids): size-independent properties over the whole batch — exact determinism,
+    exact sample counts, bounded output, batch invariance (utterance b of the batch == the same utterance alone). Utterances of
+    this very batch are compared with the oracle in test_gpu_round2.py::test_benchmark_batch_utterances_match_the_oracle."""
     ids = pkg.synth_ids(64, 128)
     pcm1, len1, fr1 = full_model.process_batch(ids, noise_seed=4321)
     pcm2, len2, fr2 = full_model.process_batch(ids, noise_seed=4321)

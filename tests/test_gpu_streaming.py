@@ -95,8 +95,10 @@ def test_callback_abort_and_misuse(pkg, full_model):
 
     with pytest.raises(KeyError):
         full_model.process_batch(ids, vocoder_chunk_frames=16, on_chunk=boom)
-    with pytest.raises(pkg.VitsError, match="on_chunk needs"):
-        full_model.process_batch(ids, on_chunk=stop)  # no chunking requested
+    calls.clear()
+    with pytest.raises(pkg.VitsError, match="aborted"):
+        full_model.process_batch(ids, on_chunk=stop)  # no chunking requested: one window, the sink still gets (and may abort) it
+    assert calls == [0]
     # the model is still usable afterwards
     pcm, _, _ = full_model.process_batch(ids, vocoder_chunk_frames=16)
     assert np.isfinite(pcm[0]).all()

@@ -55,6 +55,84 @@ def test_shard_range_partitions_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_balanced_shards_equalise_the_frame_sums():
+    """SURVEY 8e "balance by sum of predicted frames": same counts per rank as the contiguous split, smaller spread of the
+    per-rank sums, every utterance assigned exactly once, identical on every rank (pure function of the weights)."""
+    import numpy as np
+    mg = _load_multi_gpu()
+    rng = np.random.default_rng(3)
+    for world, total in ((8, 512), (2, 7), (3, 10), (4, 64)):
+        frames = rng.integers(150, 320, size=total)
+        frames[:: max(total // 5, 1)] *= 3  # a few long outliers
+        shards = mg.balanced_shards(frames, world)
+        assert sorted(i for s in shards for i in s) == list(range(total))
+        assert [len(s) for s in shards] == [mg.shard_range(total, world, r)[1] - mg.shard_range(total, world, r)[0] for r in range(world)]
+        contiguous = [list(range(*mg.shard_range(total, world, r))) for r in range(world)]
+        assert mg.imbalance(frames, shards) <= mg.imbalance(frames, contiguous) + 1e-12
+        assert shards == mg.balanced_shards(list(frames), world)
+    # the benchmark's own situation: 8 ranks x 64 utterances of ~225 +- 25 frames
+    frames = rng.normal(225, 25, size=512).astype(int)
+    assert mg.imbalance(frames, mg.balanced_shards(frames, 8)) < 1.001
+
+
+def _worker_uneven(rank, world, port, total, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = _load_multi_gpu()
+    lo, hi = mg.shard_range(total, world, rank)
+    lengths = torch.tensor([100 + 37 * u for u in range(lo, hi)], dtype=torch.int64)
+    pcm = torch.stack([_fake_pcm(u, int(lengths[i]), cap) for i, u in enumerate(range(lo, hi))])
+    out, all_len = mg.gather_pcm(pcm, lengths)
+    frames_all = mg.gather_frames(lengths // 10)
+    q.put((rank, out.numpy().copy(), all_len.numpy().copy(), frames_all.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_uneven_shards_all_gather_world2():
+    """shard_range hands out blocks that differ by one when total % world != 0; the fixed-size collective then
+    needs the short block padded (and the padding dropped again). 7 utterances over 2 ranks: 4 + 3."""
+    world, total, cap = 2, 7, 512
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, total, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    want_len = torch.tensor([100 + 37 * u for u in range(total)], dtype=torch.int64)
+    for rank, out, all_len, frames_all in results:
+        out, all_len = torch.from_numpy(out), torch.from_numpy(all_len)
+        assert torch.equal(all_len, want_len) and out.shape == (total, int(want_len.max()))
+        assert torch.equal(torch.from_numpy(frames_all), want_len // 10)
+        for u in range(total):
+            assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap)[: want_len[u]])
+
+
+def test_bench_launcher_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus 8` without torchrun starts the ranks itself, and fails (exit 2, message) when fewer devices
+    are visible — it must never fall back to one rank and print an n_gpus=1 line labelled as a scaling run.
+    Here (no GPU) 0 devices are visible."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=110)
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 devices are visible here")
+    assert r.returncode == 2 and "refusing to run fewer ranks" in r.stderr and not r.stdout.strip()
+    # a rank process whose --gpus disagrees with the launcher's world size is an error as well
+    env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 2 and "does not match WORLD_SIZE" in r.stderr
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("dtype", ["float32", "int16"])
 def test_ragged_pcm_all_gather_world2(dtype):

@@ -1,0 +1,82 @@
+"""One rank of the multi-GPU parity check (tests/test_gpu_round2.py::test_rccl_gather_*): every rank synthesises its shard of
+a small global batch on its own GPU, the PCM is all-gathered over RCCL (torch.distributed backend "nccl"), and every rank
+verifies the gathered tensor row by row: its own rows bit-equal to what it computed, and every OTHER rank's rows bit-equal
+to a local recomputation of those utterances (utterances are deterministic functions of (ids, seed), wherever they run).
+Also exercises the frames-balanced dispatch (frames_only pre-pass -> gather_frames -> balanced_shards -> noise_seed_offsets).
+Started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; prints `rank R ok`."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pkg = load("vits_cpp_amd", os.path.join(ROOT, "vits.cpp_amd", "__init__.py"))
+    mg = load("vits_multi_gpu", os.path.join(ROOT, "vits.cpp_amd", "multi_gpu.py"))
+    pkg.set_device(local)
+    total, T, base = 5 * world + (1 if world > 1 else 0), 24, 777  # uneven blocks when world > 1
+    ids_all = pkg.synth_ids(total, T)
+    ids_all[1::2, 12:] = 0  # (all lengths equal; content differs per utterance)
+    m = pkg.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL))
+    cap = 256 * 8 * T + 294
+
+    def run(indices):
+        out = torch.zeros((len(indices), cap), dtype=torch.float32, device="cuda")
+        _, lengths, frames = m.process_batch(ids_all[indices], noise_seed=base, noise_seed_offsets=np.asarray(indices, np.int32), out_device=out.data_ptr(),
+                                             out_device_stride=cap, skip_host_copy=True)
+        return out, torch.from_numpy(lengths).cuda(), frames
+
+    # 1) contiguous shards -------------------------------------------------------------------------------------------
+    lo, hi = mg.shard_range(total, world, rank)
+    mine = list(range(lo, hi))
+    out, lens, frames = run(mine)
+    for pcm16 in (False, True):
+        g, gl = mg.gather_pcm(mg.to_pcm16(pkg, out, lens) if pcm16 else out, lens)
+        assert g.shape[0] == total and gl.shape[0] == total, (g.shape, gl.shape)
+        ref_all, ref_len, _ = run(list(range(total)))  # every utterance recomputed locally
+        if pcm16:
+            ref_all = mg.to_pcm16(pkg, ref_all, ref_len)
+        assert torch.equal(gl, ref_len)
+        for u in range(total):
+            n = int(ref_len[u])
+            assert torch.equal(g[u, :n], ref_all[u, :n]), f"rank {rank}: utterance {u} differs after the gather (pcm16={pcm16})"
+            assert not bool(g[u, n:].any())
+    # 2) frames-balanced shards -----------------------------------------------------------------------------------------
+    _, _, fr = m.process_batch(ids_all[mine], noise_seed=base, noise_seed_offsets=np.asarray(mine, np.int32), frames_only=True)
+    assert np.array_equal(fr, frames)  # the pre-pass predicts exactly the frames the full call produces
+    all_fr = mg.gather_frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert all_fr.size == total
+    shards = mg.balanced_shards(all_fr, world)
+    out_b, lens_b, _ = run(shards[rank])
+    g, gl = mg.gather_pcm(out_b, lens_b)
+    order = [u for s in shards for u in s]
+    ref_all, ref_len, _ = run(list(range(total)))
+    for row, u in enumerate(order):
+        n = int(ref_len[u])
+        assert int(gl[row]) == n and torch.equal(g[row, :n], ref_all[u, :n]), f"rank {rank}: balanced row {row} (utterance {u}) differs"
+    dist.barrier()
+    dist.destroy_process_group()
+    m.close()
+    print(f"rank {rank} ok world {world} imbalance contiguous {mg.imbalance(all_fr, [list(range(*mg.shard_range(total, world, r))) for r in range(world)]):.4f} "
+          f"balanced {mg.imbalance(all_fr, shards):.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

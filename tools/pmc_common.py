@@ -1,0 +1,35 @@
+"""Shared helpers of the PMC reducers (tools/pmc_traffic.py, tools/pmc_mfma.py): rocprofv3 kernel names -> the kernel keys
+bench.py prints (`k<taps>|d<dilation>|t<tile>|e<epilogue>`), and the source hash that ties a profile artefact to a build."""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (WM, WN, MR, NR) of conv_mfma_kernel -> ConvTile index (kernels.h)
+TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4}
+_CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
+_CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
+
+
+def bench_key(kernel_name):
+    """`void vits::conv_mfma_kernel<11, 1, true, 2, 2, 2, 2, 0>(vits::ConvParams)` -> `k11|d1|t0|e0` (None for other kernels)"""
+    m = _CONV.search(kernel_name)
+    if not m:
+        return None
+    kt, dil, _, wm, wn, mr, nr, epi = m.groups()
+    tile = TILES.get((int(wm), int(wn), int(mr), int(nr)))
+    if tile is None:
+        return None
+    return f"k{kt}|d{dil}|t{tile}|e{epi}"
+
+
+def short_name(kernel_name):
+    s = kernel_name.replace("void vits::", "").replace("(vits::ConvParams)", "")
+    return s if "<" in s else s.split("(")[0]
+
+
+def source_sha16():
+    spec = importlib.util.spec_from_file_location("vits_cpp_amd", os.path.join(ROOT, "vits.cpp_amd", "__init__.py"))
+    pkg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pkg)
+    return pkg.source_sha16()

@@ -1,0 +1,64 @@
+"""MFMA-busy and LDS-bank-conflict summary per kernel from rocprofv3 --pmc passes (counter_collection CSVs) joined with the
+kernel trace of the same run (kernel durations).
+
+  pass A: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE ...
+  pass B: rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS ...
+
+mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)  — the counter ticks once per cycle a SIMD's matrix
+pipe is busy (MI355X_MICROARCH.md: 64 cycles per v_mfma_f32_32x32x2_f32, 32 per 32x32x16 bf16), SQ_BUSY_CU_CYCLES once per
+cycle a CU has a wave: the fraction of the time CUs are occupied that their four matrix pipes are issuing. A second figure
+normalises by the whole launch instead: busy / (1024 SIMDs x launch duration x 2.4 GHz) (lower bound: the clock under load is
+2.15-2.35 GHz). lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles lost to conflicts over LDS-busy cycles).
+
+usage: pmc_mfma.py OUT.json DIR_OR_CSV_GLOB..."""
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_common import bench_key, source_sha16
+
+out = sys.argv[1]
+ctr = collections.defaultdict(lambda: collections.defaultdict(float))   # kernel -> counter -> sum
+ndisp = collections.defaultdict(lambda: collections.defaultdict(set))   # kernel -> counter -> dispatch ids
+dur_ns = collections.defaultdict(float)
+dur_n = collections.Counter()
+files = []
+for pattern in sys.argv[2:]:
+    if os.path.isdir(pattern):
+        files += glob.glob(os.path.join(pattern, "**", "*.csv"), recursive=True)
+    else:
+        files += glob.glob(pattern, recursive=True)
+for f in files:
+    rd = csv.DictReader(open(f))
+    cols = rd.fieldnames or []
+    if "Counter_Name" in cols:
+        for row in rd:
+            ctr[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+            ndisp[row["Kernel_Name"]][row["Counter_Name"]].add((f, row["Dispatch_Id"]))
+    elif "Start_Timestamp" in cols and "Kernel_Name" in cols:
+        for row in rd:
+            dur_ns[row["Kernel_Name"]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            dur_n[row["Kernel_Name"]] += 1
+res, by_key = {}, {}
+for name, c in ctr.items():
+    n = {k: max(len(v), 1) for k, v in ndisp[name].items()}
+    per = {k: v / n[k] for k, v in c.items()}
+    e = {"counters_per_launch": per, "launches_sampled": max(n.values())}
+    if dur_n[name]:
+        e["avg_duration_us"] = dur_ns[name] / dur_n[name] / 1e3
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
+        if per.get("SQ_BUSY_CU_CYCLES"):
+            e["mfma_busy_frac"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * per["SQ_BUSY_CU_CYCLES"])
+        if dur_n[name]:
+            e["mfma_busy_frac_of_launch_at_2p4ghz"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * (dur_ns[name] / dur_n[name]) * 2.4)
+    if per.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_bank_conflict_frac"] = per.get("SQ_LDS_BANK_CONFLICT", 0.0) / per["SQ_LDS_IDX_ACTIVE"]
+    res[name] = e
+    key = bench_key(name)
+    if key and (key not in by_key or e["launches_sampled"] > by_key[key]["launches_sampled"]):
+        by_key[key] = dict(e, kernel_name=name)
+json.dump({"note": "rocprofv3 --kernel-trace --pmc passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-pass`; formulas in tools/pmc_mfma.py",
+           "source_sha16": source_sha16(), "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+top = sorted(by_key.items(), key=lambda kv: -kv[1]["counters_per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["launches_sampled"])[:12]
+for k, e in top:
+    print(f"{k:18s} mfma_busy {e.get('mfma_busy_frac', float('nan')):.3f}  of-launch@2.4GHz {e.get('mfma_busy_frac_of_launch_at_2p4ghz', float('nan')):.3f}  "
+          f"lds_conflict {e.get('lds_bank_conflict_frac', float('nan')):.4f}")
+print(len(res), "kernels ->", out)

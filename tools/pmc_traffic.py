@@ -1,28 +1,45 @@
 """Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (separate passes) into a JSON of HBM bytes per
 launch for every kernel name, following /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE on
-gfx950 under-reports and must be CALIBRATED on a known byte count in the kernel's own access pattern (the guide's exact x2
-holds for 16 B/lane streams; these kernels stage with 4 B/lane loads). Calibration used here: launches whose read volume is
-known exactly (conv_mfma_kernel<3, 3, false, 1, 4, 1, 1, 0>: one 474.1 MB input tensor, no residual, negligible weights)
-report 415 MB raw -> factor 1/0.875 = 1.143 on FETCH_SIZE; WRITE_SIZE matches the known output bytes to <1 % (factor 1)."""
+gfx950 under-reports and must be CALIBRATED on a known byte count in the kernel's own access pattern. The calibration
+factors come from tools/fetch_calib.hip (pure streaming kernels over a 1 GiB buffer, well past the 256 MiB Infinity Cache):
+pass them as --fetch-cal / --write-cal (defaults: the values measured in profiles/round2_fetch_calibration.json).
+
+usage: pmc_traffic.py OUT.json [--fetch-cal F] [--write-cal W] CSV_GLOB..."""
 import collections, csv, glob, json, sys
-out = sys.argv[1]
-FETCH_CAL = 1.0 / 0.875
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from pmc_common import bench_key, source_sha16
+
+argv = sys.argv[1:]
+out = argv.pop(0)
+FETCH_CAL, WRITE_CAL = 2.0, 1.0
+while argv and argv[0].startswith("--"):
+    flag = argv.pop(0)
+    val = float(argv.pop(0))
+    if flag == "--fetch-cal":
+        FETCH_CAL = val
+    elif flag == "--write-cal":
+        WRITE_CAL = val
 fetch, write, calls_f, calls_w = collections.Counter(), collections.Counter(), collections.Counter(), collections.Counter()
-for pattern in sys.argv[2:]:
-    for f in glob.glob(pattern):
+for pattern in argv:
+    for f in glob.glob(pattern, recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
             if row["Counter_Name"] == "FETCH_SIZE":
                 fetch[name] += float(row["Counter_Value"]); calls_f[name] += 1
             elif row["Counter_Name"] == "WRITE_SIZE":
                 write[name] += float(row["Counter_Value"]); calls_w[name] += 1
-res = {}
+res, by_key = {}, {}
 for name in set(fetch) | set(write):
     raw = 1024.0 * fetch[name] / max(calls_f[name], 1)
     fb = FETCH_CAL * raw
-    wb = 1024.0 * write[name] / max(calls_w[name], 1)
-    res[name] = {"fetch_raw_bytes_per_launch": raw, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
-                 "launches_sampled": max(calls_f[name], calls_w[name])}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1`; KiB -> bytes, FETCH_SIZE x 1.143 (calibrated on a launch with known read volume), WRITE_SIZE x 1",
-           "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    wraw = 1024.0 * write[name] / max(calls_w[name], 1)
+    wb = WRITE_CAL * wraw
+    res[name] = {"fetch_raw_bytes_per_launch": raw, "fetch_bytes_per_launch": fb, "write_raw_bytes_per_launch": wraw, "write_bytes_per_launch": wb,
+                 "hbm_bytes_per_launch": fb + wb, "launches_sampled": max(calls_f[name], calls_w[name])}
+    key = bench_key(name)
+    if key and (key not in by_key or res[name]["launches_sampled"] > by_key[key]["launches_sampled"]):
+        by_key[key] = dict(res[name], kernel_name=name)
+cal = f"rocprofv3 --pmc FETCH_SIZE x {FETCH_CAL:g} + WRITE_SIZE x {WRITE_CAL:g} (KiB -> bytes; factors calibrated with tools/fetch_calib.hip)"
+json.dump({"note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-pass`",
+           "calibration": cal, "source_sha16": source_sha16(), "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 print(len(res), "kernels ->", out)

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("VITS_HIP_LIB", os.path.join(_HERE, "csrc", "libvits_h
 MODE_DEFAULT, MODE_REFERENCE, MODE_HF = -1, 0, 1
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
 SYNTH_FULL, SYNTH_TINY, SYNTH_BF16 = 0, 1, 0x100
+ARITH_F32, ARITH_BF16, ARITH_F16 = 0, 1, 2
 
 #: every symbol include/vits.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
@@ -32,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
     "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
+    "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate",
 ]
 
 
@@ -49,7 +51,8 @@ class ProcessOpts(C.Structure):
         ("noise_dur", C.c_void_p), ("noise_prior", C.c_void_p), ("noise_prior_stride", C.c_int64),
         ("fixed_duration", C.c_int32), ("collect_taps", C.c_int32), ("out_device", C.c_void_p),
         ("out_device_stride", C.c_int64), ("skip_host_copy", C.c_int32), ("async_", C.c_int32),
-        ("vocoder_chunk_frames", C.c_int32), ("reserved0", C.c_int32), ("on_chunk", ChunkCallback), ("on_chunk_user", C.c_void_p),
+        ("vocoder_chunk_frames", C.c_int32), ("frames_only", C.c_int32), ("on_chunk", ChunkCallback), ("on_chunk_user", C.c_void_p),
+        ("noise_seed_offsets", C.c_void_p),
     ]
 
 
@@ -71,6 +74,23 @@ class ConvT1dDesc(C.Structure):
 
 
 _lib = None
+
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the library's sources (csrc/*.hip|cpp|h, include/*.h): identifies the kernel build
+    that a profile artefact (profiles/*_pmc_*.json) was collected with. The GPU box has no .git, so a commit hash is not
+    available there; this changes exactly when the code that runs changes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(root, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def lib():
@@ -98,6 +118,10 @@ def lib():
     L.vits_model_set_mode.argtypes = [vp, i32]
     L.vits_model_get_mode.restype = i32
     L.vits_model_get_mode.argtypes = [vp]
+    L.vits_model_set_arith.restype = i32
+    L.vits_model_set_arith.argtypes = [vp, i32]
+    L.vits_model_get_arith.restype = i32
+    L.vits_model_get_arith.argtypes = [vp]
     L.vits_reference_noise_seed.restype = None
     L.vits_reference_noise_seed.argtypes = [C.c_uint32]
     L.vits_model_process_ids.restype = VitsResult
@@ -190,6 +214,14 @@ def reserialize(data):
         lib().vits_free_bytes(p)
 
 
+def validate(data):
+    """Host-only load check of a model file (vits_model_file_validate); raises VitsError with the reason."""
+    f = lib().vits_model_file_validate
+    f.restype, f.argtypes = C.c_int32, [C.c_char_p, C.c_size_t]
+    if f(data, len(data)) != 0:
+        raise VitsError(last_error())
+
+
 def file_tokenize(data, text):
     buf = np.zeros(4 * len(text.encode("utf-8")) + 8, np.int32)
     n = lib().vits_model_file_tokenize(data, len(data), text.encode("utf-8"), _ptr(buf), buf.size)
@@ -270,6 +302,15 @@ class Model:
         if lib().vits_model_set_mode(self._h, mode) != 0:
             raise VitsError(last_error())
 
+    def set_arith(self, arith):
+        """ARITH_F32 (exact, default) | ARITH_BF16 | ARITH_F16: conv operand precision (include/vits.h VITS_ARITH_*)"""
+        if lib().vits_model_set_arith(self._h, arith) != 0:
+            raise VitsError(last_error())
+
+    @property
+    def arith(self):
+        return lib().vits_model_get_arith(self._h)
+
     @property
     def mode(self):
         return lib().vits_model_get_mode(self._h)
@@ -295,7 +336,7 @@ class Model:
 
     def process_batch(self, ids, id_lengths=None, mode=MODE_DEFAULT, noise_kind=NOISE_COUNTER, noise_seed=4321,
                       noise_dur=None, noise_prior=None, fixed_duration=0, collect_taps=False, out_device=None,
-                      out_device_stride=0, skip_host_copy=False, async_=False, vocoder_chunk_frames=0, on_chunk=None):
+                      out_device_stride=0, skip_host_copy=False, async_=False, vocoder_chunk_frames=0, on_chunk=None, frames_only=False, noise_seed_offsets=None, keep_pcm=True):
         """ids: int32 [B, id_stride]. Returns (list of per-utterance PCM arrays or None, lengths, frames).
         vocoder_chunk_frames > 0 runs the vocoder window by window (bit-identical PCM, bounded activations);
         on_chunk(utt, offset, pcm ndarray) is then called as each window's samples reach the host (return True to abort)."""
@@ -315,6 +356,11 @@ class Model:
         o.out_device_stride = out_device_stride
         o.skip_host_copy, o.async_ = int(skip_host_copy), int(async_)
         o.vocoder_chunk_frames = int(vocoder_chunk_frames)
+        o.frames_only = int(frames_only)
+        nso = None if noise_seed_offsets is None else np.ascontiguousarray(noise_seed_offsets, dtype=np.int32)
+        if nso is not None and nso.size != B:
+            raise ValueError("noise_seed_offsets needs one entry per utterance")
+        o.noise_seed_offsets = _ptr(nso)
         cb_error = []
         if on_chunk is not None:
             def _cb(_user, utt, offset, pcm, n):
@@ -333,7 +379,7 @@ class Model:
             lengths = np.ctypeslib.as_array(res.lengths, shape=(B,)).copy()
             frames = np.ctypeslib.as_array(res.frames, shape=(B,)).copy()
             pcm = None
-            if res.data:
+            if res.data and keep_pcm:
                 full = np.ctypeslib.as_array(res.data, shape=(B, res.stride))
                 pcm = [full[b, : lengths[b]].copy() for b in range(B)]
             return pcm, lengths, frames

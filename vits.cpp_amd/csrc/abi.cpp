@@ -137,6 +137,21 @@ VITS_API int vits_model_set_mode(vits_model* model, int mode) {
 }
 VITS_API int vits_model_get_mode(const vits_model* model) { return model ? model->eng.mode : -1; }
 VITS_API void vits_reference_noise_seed(uint32_t seed) { vits::reference_noise_seed(seed); }
+VITS_API int vits_model_set_arith(vits_model* model, int arith) {
+    VITS_TRY
+    if (!model || (arith != VITS_ARITH_F32 && arith != VITS_ARITH_BF16 && arith != VITS_ARITH_F16)) {
+        set_err("bad arithmetic mode");
+        return -1;
+    }
+    std::string err;
+    if (model->eng.set_arith(arith, err) != 0) {
+        set_err(err);
+        return -1;
+    }
+    return 0;
+    VITS_CATCH(-1)
+}
+VITS_API int vits_model_get_arith(const vits_model* model) { return model ? model->eng.arith : -1; }
 
 VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
                                       const vits_process_opts* opts, vits_batch_result* out) {
@@ -225,6 +240,22 @@ VITS_API int vits_model_file_reserialize(const char* in, size_t in_size, char** 
     *out = new char[v.size()];
     std::memcpy(*out, v.data(), v.size());
     *out_size = v.size();
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_model_file_validate(const char* bytes, size_t size) {
+    VITS_TRY
+    if (!bytes) {
+        set_err("null argument");
+        return -1;
+    }
+    vits::Engine e;
+    std::string err;
+    if (!e.validate(reinterpret_cast<const uint8_t*>(bytes), size, err)) {
+        set_err(err);
+        return -1;
+    }
     return 0;
     VITS_CATCH(-1)
 }

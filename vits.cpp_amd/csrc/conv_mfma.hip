@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -840,12 +841,12 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     const size_t lds = DB ? (size_t)p.nbuf * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
 #define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
     do {                                                                                                                              \
-        static bool big_lds_set = false;                                                                                              \
-        if (lds > 64 * 1024 && !big_lds_set) {                                                                                        \
+        static std::atomic<bool> big_lds_set{false}; /* (atomic: distinct model handles may launch from distinct threads) */         \
+        if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {                                                                                        \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>),       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
             if (ea != hipSuccess) return ea;                                                                                          \
-            big_lds_set = true;                                                                                                       \
+            big_lds_set.store(true, std::memory_order_release);                                                                                                 \
         }                                                                                                                             \
         hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(DB ? 320 : 256), lds, s, p);                             \
     } while (0)

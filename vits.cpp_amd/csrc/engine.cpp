@@ -168,8 +168,13 @@ Engine::~Engine() {
     for (hipStream_t s : side_)
         if (s) hipStreamSynchronize(s);
     clear_taps();
-    for (void* p : owned_) hipFree(p);
+    if (!dry_run_)
+        for (void* p : owned_) hipFree(p);
     if (pinned_) hipHostFree(pinned_);
+    for (HStage& hs : hstage_) {
+        if (hs.p) hipHostFree(hs.p);
+        if (hs.ev) hipEventDestroy(hs.ev);
+    }
     if (ev_fork_) hipEventDestroy(ev_fork_);
     for (hipEvent_t e : ev_done_)
         if (e) hipEventDestroy(e);
@@ -179,6 +184,7 @@ Engine::~Engine() {
 }
 
 float* Engine::upload(const std::vector<float>& v) {
+    if (dry_run_) return reinterpret_cast<float*>(16);  // validation only (vits_model_file_validate): nothing is allocated
     float* d = nullptr;
     if (hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * sizeof(float)) != hipSuccess) return nullptr;
     hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -187,10 +193,42 @@ float* Engine::upload(const std::vector<float>& v) {
     return d;
 }
 
-float* Engine::upload_tensor(const ModelFile& f, const std::string& name, std::string& err) {
+// Shape check against the hyper-parameters (file order: fastest dimension first; missing trailing dimensions count as 1;
+// -1 = any). The reference trusts the file (ggml asserts or reads out of bounds, vits_model_data.cpp:56-89); here a tensor
+// whose shape does not match what the kernels will index with is a load error, never a device out-of-bounds access.
+static bool shape_is(const TensorEntry& t, std::initializer_list<int64_t> want) {
+    if (want.size() < t.rank) {
+        for (uint32_t j = (uint32_t)want.size(); j < t.rank; ++j)
+            if (t.ne[j] != 1) return false;
+    }
+    size_t j = 0;
+    for (int64_t w : want) {
+        const int64_t have = j < t.rank ? t.ne[j] : 1;
+        if (w >= 0 && have != w) return false;
+        ++j;
+    }
+    return true;
+}
+static std::string shape_str(const TensorEntry& t) {
+    std::string o = "[";
+    for (uint32_t j = 0; j < t.rank; ++j) o += (j ? "," : "") + std::to_string(t.ne[j]);
+    return o + "]";
+}
+static std::string shape_str(std::initializer_list<int64_t> want) {
+    std::string o = "[";
+    size_t j = 0;
+    for (int64_t w : want) o += (j++ ? "," : "") + (w < 0 ? std::string("*") : std::to_string(w));
+    return o + "]";
+}
+
+float* Engine::upload_tensor(const ModelFile& f, const std::string& name, std::string& err, std::initializer_list<int64_t> want) {
     const TensorEntry* t = f.find(name);
     if (!t) {
         err = "[ERROR] tensor not found: " + name;  // message of the reference, vits_model_data.cpp:144
+        return nullptr;
+    }
+    if (!shape_is(*t, want)) {
+        err = "tensor '" + name + "' has shape " + shape_str(*t) + ", the hyper-parameters need " + shape_str(want);
         return nullptr;
     }
     float* d = upload(t->to_f32());
@@ -221,8 +259,9 @@ static bool get_conv(const ModelFile& f, const std::string& wname, std::vector<f
 }
 
 // transform: 0 none | 1 reverse input channels | 2 negate | 3 negate + reverse output channels
-bool Engine::pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, int, PackedConv& out, std::string& err, int ct_stride,
-                  int transform) {
+// want = {cout, cin, k} the hyper-parameters imply (-1: taken from the file)
+bool Engine::pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, ConvShape want, PackedConv& out, std::string& err,
+                  int ct_stride, int transform) {
     std::vector<float> w;
     int d0, d1, k;
     if (!get_conv(f, wname, w, d0, d1, k, err)) return false;
@@ -231,11 +270,22 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
         cin = d0;
         cout = d1;
     }
+    if ((want.cout >= 0 && cout != want.cout) || (want.cin >= 0 && cin != want.cin) || (want.k >= 0 && k != want.k) || cout <= 0 || cin <= 0 || k <= 0 ||
+        (epi == EPI_CONVT && (ct_stride <= 0 || k != 2 * ct_stride)) || (epi == EPI_GATE && (cout & 1))) {
+        err = "tensor '" + wname + "' is a " + std::to_string(cout) + "x" + std::to_string(cin) + "x" + std::to_string(k) + " kernel (out x in x taps), the hyper-parameters need " +
+              (want.cout < 0 ? std::string("*") : std::to_string(want.cout)) + "x" + (want.cin < 0 ? std::string("*") : std::to_string(want.cin)) + "x" +
+              (want.k < 0 ? std::string("*") : std::to_string(want.k));
+        return false;
+    }
     std::vector<float> bias;
     if (!bname.empty()) {
         const TensorEntry* b = f.find(bname);
         if (!b) {
             err = "[ERROR] tensor not found: " + bname;
+            return false;
+        }
+        if (b->count() != cout) {
+            err = "tensor '" + bname + "' has " + std::to_string(b->count()) + " elements, expected " + std::to_string(cout);
             return false;
         }
         bias = b->to_f32();
@@ -273,23 +323,24 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
 }
 
 bool Engine::load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err) {
+    const int H = hp.hidden;
     for (int i = 0; i < hp.dds_layers; ++i) {
         const std::string si = std::to_string(i);
         float* p;
-        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".weight", err))) return false;
+        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".weight", err, {hp.dp_k, 1, H}))) return false;  // depthwise: torch [H][1][k]
         d.dw_w.push_back(p);
-        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".bias", err))) return false;
+        if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".bias", err, {H}))) return false;
         d.dw_b.push_back(p);
         PackedConv pc;
-        if (!pack(f, base + "convs_pointwise." + si + ".weight", base + "convs_pointwise." + si + ".bias", EPI_STD, 0, pc, err)) return false;
+        if (!pack(f, base + "convs_pointwise." + si + ".weight", base + "convs_pointwise." + si + ".bias", EPI_STD, {H, H, 1}, pc, err)) return false;
         d.pw.push_back(pc);
-        if (!(p = upload_tensor(f, base + "norms_1." + si + ".weight", err))) return false;
+        if (!(p = upload_tensor(f, base + "norms_1." + si + ".weight", err, {H}))) return false;
         d.n1_g.push_back(p);
-        if (!(p = upload_tensor(f, base + "norms_1." + si + ".bias", err))) return false;
+        if (!(p = upload_tensor(f, base + "norms_1." + si + ".bias", err, {H}))) return false;
         d.n1_b.push_back(p);
-        if (!(p = upload_tensor(f, base + "norms_2." + si + ".weight", err))) return false;
+        if (!(p = upload_tensor(f, base + "norms_2." + si + ".weight", err, {H}))) return false;
         d.n2_g.push_back(p);
-        if (!(p = upload_tensor(f, base + "norms_2." + si + ".bias", err))) return false;
+        if (!(p = upload_tensor(f, base + "norms_2." + si + ".bias", err, {H}))) return false;
         d.n2_b.push_back(p);
     }
     return true;
@@ -301,17 +352,17 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
     if (!hp.load(f, err)) return false;
     tok.init(f);
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    if (!dry_run_ && (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)) {
         err = "no HIP device available: this library has no CPU path";
         return false;
     }
-    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!dry_run_ && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
         err = "hipStreamCreate failed";
         return false;
     }
     if (const char* e = std::getenv("VITS_RB_STREAMS")) rb_streams_ = std::atoi(e) >= 2 ? 3 : 1;
     if (const char* e = std::getenv("VITS_LRELU_COPY_MINC")) lrelu_copy_minc_ = std::atoi(e);
-    if (rb_streams_ > 1) {
+    if (rb_streams_ > 1 && !dry_run_) {
         bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
         for (auto& s : side_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
         for (auto& ev : ev_done_) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -320,12 +371,24 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             return false;
         }
     }
-    const int H = hp.hidden;
-    if (!(emb_ = upload_tensor(f, "text_encoder.embed_tokens.weight", err))) return false;
+    const int H = hp.hidden, F = hp.flow_size;
+    // structural limits of the kernels (what the shapes below are checked against)
+    if (H <= 0 || hp.heads <= 0 || H % hp.heads != 0 || F <= 0 || (F & 1) || hp.window < 0 || hp.layers < 0 || hp.up_rates.size() != hp.up_k.size() ||
+        hp.up_rates.size() > 6 || hp.rb_k.empty() || hp.rb_k.size() != hp.rb_d.size() || hp.dp_bins <= 0 || hp.dp_k <= 0 || hp.dds_layers < 0 ||
+        hp.dp_flows < 1 || hp.n_flows < 0 || hp.wn_layers < 1) {
+        err = "unsupported hyper-parameters";
+        return false;
+    }
     {
         const TensorEntry* e = f.find("text_encoder.embed_tokens.weight");
+        if (!e || e->rank != 2 || e->ne[0] != H || e->ne[1] <= 0) {
+            err = e ? "tensor 'text_encoder.embed_tokens.weight' must be [hidden, vocab]" : "[ERROR] tensor not found: text_encoder.embed_tokens.weight";
+            return false;
+        }
         hp.vocab_size = (int)e->ne[1];
     }
+    if (!(emb_ = upload_tensor(f, "text_encoder.embed_tokens.weight", err, {H, hp.vocab_size}))) return false;
+    const int hd = H / hp.heads, nrel = 2 * hp.window + 1;
     enc_.resize(hp.layers);
     for (int l = 0; l < hp.layers; ++l) {
         const std::string b = "text_encoder.encoder.layers." + std::to_string(l) + ".";
@@ -339,6 +402,10 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
                 const TensorEntry* tb = f.find(b + "attention." + names[i] + ".bias");
                 if (!tw || !tb) {
                     err = "[ERROR] tensor not found: " + b + "attention." + names[i];
+                    return false;
+                }
+                if (!shape_is(*tw, {H, H}) || !shape_is(*tb, {H})) {
+                    err = "tensor '" + b + "attention." + names[i] + "' must be a [hidden, hidden] Linear with a [hidden] bias";
                     return false;
                 }
                 auto wv = tw->to_f32();
@@ -355,35 +422,39 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             pc.wp = upload(packed);
             pc.bias = upload(bias);
             pc.bytes = (int64_t)packed.size() * 4;
+            if (!pc.wp || !pc.bias) {
+                err = "hipMalloc failed for " + b + "attention";
+                return false;
+            }
         }
-        if (!pack(f, b + "attention.out_proj.weight", b + "attention.out_proj.bias", EPI_STD, 0, L.out, err)) return false;
-        if (!pack(f, b + "feed_forward.conv_1.weight", b + "feed_forward.conv_1.bias", EPI_STD, 0, L.ffn1, err)) return false;
-        if (!pack(f, b + "feed_forward.conv_2.weight", b + "feed_forward.conv_2.bias", EPI_STD, 0, L.ffn2, err)) return false;
-        if (!(L.rel_k = upload_tensor(f, b + "attention.emb_rel_k", err))) return false;
-        if (!(L.rel_v = upload_tensor(f, b + "attention.emb_rel_v", err))) return false;
-        if (!(L.ln1_g = upload_tensor(f, b + "layer_norm.weight", err))) return false;
-        if (!(L.ln1_b = upload_tensor(f, b + "layer_norm.bias", err))) return false;
-        if (!(L.ln2_g = upload_tensor(f, b + "final_layer_norm.weight", err))) return false;
-        if (!(L.ln2_b = upload_tensor(f, b + "final_layer_norm.bias", err))) return false;
+        if (!pack(f, b + "attention.out_proj.weight", b + "attention.out_proj.bias", EPI_STD, {H, H, 1}, L.out, err)) return false;
+        if (!pack(f, b + "feed_forward.conv_1.weight", b + "feed_forward.conv_1.bias", EPI_STD, {hp.ffn_dim, H, hp.ffn_k}, L.ffn1, err)) return false;
+        if (!pack(f, b + "feed_forward.conv_2.weight", b + "feed_forward.conv_2.bias", EPI_STD, {H, hp.ffn_dim, hp.ffn_k}, L.ffn2, err)) return false;
+        if (!(L.rel_k = upload_tensor(f, b + "attention.emb_rel_k", err, {hd, nrel, 1}))) return false;  // shared by the heads (vits.cpp:323)
+        if (!(L.rel_v = upload_tensor(f, b + "attention.emb_rel_v", err, {hd, nrel, 1}))) return false;
+        if (!(L.ln1_g = upload_tensor(f, b + "layer_norm.weight", err, {H}))) return false;
+        if (!(L.ln1_b = upload_tensor(f, b + "layer_norm.bias", err, {H}))) return false;
+        if (!(L.ln2_g = upload_tensor(f, b + "final_layer_norm.weight", err, {H}))) return false;
+        if (!(L.ln2_b = upload_tensor(f, b + "final_layer_norm.bias", err, {H}))) return false;
     }
-    if (!pack(f, "text_encoder.project.weight", "text_encoder.project.bias", EPI_STD, 0, enc_proj_, err)) return false;
+    if (!pack(f, "text_encoder.project.weight", "text_encoder.project.bias", EPI_STD, {2 * F, H, 1}, enc_proj_, err)) return false;
     // duration predictor
     {
         const std::string dp = "duration_predictor.";
-        if (!pack(f, dp + "conv_pre.weight", dp + "conv_pre.bias", EPI_STD, 0, dp_pre_, err)) return false;
-        if (!pack(f, dp + "conv_proj.weight", dp + "conv_proj.bias", EPI_STD, 0, dp_proj_, err)) return false;
+        if (!pack(f, dp + "conv_pre.weight", dp + "conv_pre.bias", EPI_STD, {H, H, 1}, dp_pre_, err)) return false;
+        if (!pack(f, dp + "conv_proj.weight", dp + "conv_proj.bias", EPI_STD, {H, H, 1}, dp_proj_, err)) return false;
         if (!load_dds(f, dp + "conv_dds.", dp_dds_, err)) return false;
-        if (!(dp_translate_ = upload_tensor(f, dp + "flows.0.translate", err))) return false;
-        if (!(dp_logscale_ = upload_tensor(f, dp + "flows.0.log_scale", err))) return false;
+        if (!(dp_translate_ = upload_tensor(f, dp + "flows.0.translate", err, {1, 2}))) return false;
+        if (!(dp_logscale_ = upload_tensor(f, dp + "flows.0.log_scale", err, {1, 2}))) return false;
         dp_flows_.resize(hp.dp_flows);
         for (int fl = 1; fl <= hp.dp_flows; ++fl) {
             if (fl == 1) continue;  // never evaluated (vits.cpp:954; HF "remove a useless vflow")
             const std::string b = dp + "flows." + std::to_string(fl) + ".";
             DpFlowW& W = dp_flows_[fl - 1];
-            if (!(W.pre_w = upload_tensor(f, b + "conv_pre.weight", err))) return false;
-            if (!(W.pre_b = upload_tensor(f, b + "conv_pre.bias", err))) return false;
+            if (!(W.pre_w = upload_tensor(f, b + "conv_pre.weight", err, {1, 1, H}))) return false;  // Conv1d(1 -> H, 1) (vits.cpp:864)
+            if (!(W.pre_b = upload_tensor(f, b + "conv_pre.bias", err, {H}))) return false;
             if (!load_dds(f, b + "conv_dds.", W.dds, err)) return false;
-            if (!pack(f, b + "conv_proj.weight", b + "conv_proj.bias", EPI_STD, 0, W.proj, err)) return false;
+            if (!pack(f, b + "conv_proj.weight", b + "conv_proj.bias", EPI_STD, {3 * hp.dp_bins - 1, H, 1}, W.proj, err)) return false;
         }
     }
     // coupling flow: channel flips (vits.cpp:532) are folded into the weights. Layer i (processed i = n-1 .. 0) sees
@@ -393,19 +464,24 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         const std::string b = "flow.flows." + std::to_string(i) + ".";
         const bool flipped = ((hp.n_flows - i) % 2) == 1;
         FlowLayerW& L = flow_[i];
-        if (!pack(f, b + "conv_pre.weight", b + "conv_pre.bias", EPI_STD, 0, L.pre, err, 0, flipped ? 1 : 0)) return false;
-        if (!pack(f, b + "conv_post.weight", b + "conv_post.bias", EPI_STD, 0, L.post, err, 0, flipped ? 3 : 2)) return false;  // x1 -= mean
+        if (!pack(f, b + "conv_pre.weight", b + "conv_pre.bias", EPI_STD, {H, F / 2, 1}, L.pre, err, 0, flipped ? 1 : 0)) return false;
+        if (!pack(f, b + "conv_post.weight", b + "conv_post.bias", EPI_STD, {F / 2, H, 1}, L.post, err, 0, flipped ? 3 : 2)) return false;  // x1 -= mean
         L.in_layers.resize(hp.wn_layers);
         L.res_skip.resize(hp.wn_layers);
         for (int l = 0; l < hp.wn_layers; ++l) {
             const std::string sl = std::to_string(l);
-            if (!pack(f, b + "wavenet.in_layers." + sl + ".weight", b + "wavenet.in_layers." + sl + ".bias", EPI_GATE, 0, L.in_layers[l], err)) return false;
-            if (!pack(f, b + "wavenet.res_skip_layers." + sl + ".weight", b + "wavenet.res_skip_layers." + sl + ".bias", EPI_STD, 0, L.res_skip[l], err))
+            if (!pack(f, b + "wavenet.in_layers." + sl + ".weight", b + "wavenet.in_layers." + sl + ".bias", EPI_GATE, {2 * H, H, hp.wn_k}, L.in_layers[l], err)) return false;
+            if (!pack(f, b + "wavenet.res_skip_layers." + sl + ".weight", b + "wavenet.res_skip_layers." + sl + ".bias", EPI_STD,
+                      {l + 1 < hp.wn_layers ? 2 * H : H, H, 1}, L.res_skip[l], err))
                 return false;
         }
     }
     // HiFiGAN
-    if (!pack(f, "decoder.conv_pre.weight", "decoder.conv_pre.bias", EPI_STD, 0, dec_pre_, err)) return false;
+    if (!pack(f, "decoder.conv_pre.weight", "decoder.conv_pre.bias", EPI_STD, {hp.up_init, F, -1}, dec_pre_, err)) return false;
+    if (!(dec_pre_.kt & 1)) {
+        err = "decoder.conv_pre needs an odd kernel size";
+        return false;
+    }
     ups_.resize(hp.up_rates.size());
     {
         int c = hp.up_init;
@@ -413,26 +489,31 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             UpStageW& U = ups_[i];
             U.stride = hp.up_rates[i];
             U.k = hp.up_k[i];
+            if (U.stride <= 0 || U.k != 2 * U.stride || (c & 1)) {
+                err = "unsupported upsampler (kernel size must be twice the stride)";
+                return false;
+            }
+            const int cin_stage = c;
             c /= 2;
             U.channels = c;
             const std::string si = std::to_string(i);
-            if (!pack(f, "decoder.upsampler." + si + ".weight", "decoder.upsampler." + si + ".bias", EPI_CONVT, 0, U.up, err, U.stride)) return false;
-            if (U.up.cout != c) {
-                err = "upsampler channel mismatch";
-                return false;
-            }
+            if (!pack(f, "decoder.upsampler." + si + ".weight", "decoder.upsampler." + si + ".bias", EPI_CONVT, {c, cin_stage, U.k}, U.up, err, U.stride)) return false;
             U.rbs.resize(hp.rb_k.size());
             for (size_t j = 0; j < hp.rb_k.size(); ++j) {
                 ResBlockW& R = U.rbs[j];
                 R.k = hp.rb_k[j];
                 R.dil = hp.rb_d[j];
+                if (R.k <= 0 || !(R.k & 1)) {
+                    err = "resblock kernel sizes must be odd";
+                    return false;
+                }
                 const std::string rb = "decoder.resblocks." + std::to_string(i * hp.rb_k.size() + j) + ".";
                 R.c1.resize(R.dil.size());
                 R.c2.resize(R.dil.size());
                 for (size_t d = 0; d < R.dil.size(); ++d) {
                     const std::string sd = std::to_string(d);
-                    if (!pack(f, rb + "convs1." + sd + ".weight", rb + "convs1." + sd + ".bias", EPI_STD, 0, R.c1[d], err)) return false;
-                    if (!pack(f, rb + "convs2." + sd + ".weight", rb + "convs2." + sd + ".bias", EPI_STD, 0, R.c2[d], err)) return false;
+                    if (!pack(f, rb + "convs1." + sd + ".weight", rb + "convs1." + sd + ".bias", EPI_STD, {c, c, R.k}, R.c1[d], err)) return false;
+                    if (!pack(f, rb + "convs2." + sd + ".weight", rb + "convs2." + sd + ".bias", EPI_STD, {c, c, R.k}, R.c2[d], err)) return false;
                 }
             }
         }
@@ -441,9 +522,13 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             err = "[ERROR] tensor not found: decoder.conv_post.weight";
             return false;
         }
+        if (pw->rank != 3 || pw->ne[1] != c || pw->ne[2] != 1 || pw->ne[0] <= 0 || pw->ne[0] > 63 || !(pw->ne[0] & 1)) {
+            err = "tensor 'decoder.conv_post.weight' has shape " + shape_str(*pw) + ", expected [odd k, " + std::to_string(c) + ", 1]";
+            return false;
+        }
         dec_post_k_ = (int)pw->ne[0];
         dec_post_cin_ = (int)pw->ne[1];
-        if (!(dec_post_w_ = upload_tensor(f, "decoder.conv_post.weight", err))) return false;
+        if (!(dec_post_w_ = upload_tensor(f, "decoder.conv_post.weight", err, {dec_post_k_, dec_post_cin_, 1}))) return false;
         // one-sided receptive field of the vocoder, walked from the waveform back to the frames: conv_post, then per stage
         // the deepest resblock chain (k/2 * (d + 1) per conv pair) and the transposed conv (K taps over stride s)
         int h = dec_post_k_ / 2;
@@ -458,11 +543,18 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         }
         halo_frames_ = h + dec_pre_.kt / 2 + 1;
     }
-    if (hipDeviceSynchronize() != hipSuccess) {
+    if (!dry_run_ && hipDeviceSynchronize() != hipSuccess) {
         err = "device error while uploading weights";
         return false;
     }
     return true;
+}
+
+bool Engine::validate(const uint8_t* bytes, size_t size, std::string& err) {
+    dry_run_ = true;
+    const bool ok = load(bytes, size, err);
+    owned_.clear();  // (dry-run "pointers" are not allocations)
+    return ok;
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
@@ -476,10 +568,13 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
         char full[160];
         std::snprintf(full, sizeof(full), "%s|k%d|d%d|t%d|e%d|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, w.cin,
                       w.cout);
-        const int64_t cols = (int64_t)c.batch * (w.epi == EPI_CONVT ? c.t_in : c.t_out);
+        // algorithmic work over the REAL lengths (sum over utterances), not the padded grid extent
+        const int64_t tot_in = c.sum_in >= 0 ? c.sum_in : (int64_t)c.batch * c.t_in;
+        const int64_t tot_out = c.sum_out >= 0 ? c.sum_out : (int64_t)c.batch * c.t_out;
+        const int64_t cols = w.epi == EPI_CONVT ? tot_in : tot_out;
         // algorithmic bytes: input read once, output (and its activated copy, if any) written once, residual/accumulator read once, weights once
-        double bytes = 4.0 * ((double)c.batch * w.cin * c.t_in + (double)c.batch * w.cout * c.t_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0) + (c.y2 ? 1 : 0))) +
-                       (double)w.bytes;
+        const int cout_stored = w.epi == EPI_GATE ? w.cout / 2 : w.cout;
+        double bytes = 4.0 * ((double)w.cin * tot_in + (double)cout_stored * tot_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0) + (c.y2 ? 1 : 0))) + (double)w.bytes;
         prof.begin(full, conv_flops(w, c, cols), bytes, stream, /*chain=*/true);
     }
     hipError_t e = launch_conv(w, c, stream);
@@ -496,7 +591,7 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
     } while (0)
 
 // DDS block (vits.cpp:646-692): x is updated in place; y, p are scratch [B][H][ts]
-hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax) {
+hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax, int64_t sum_t) {
     const int H = hp.hidden;
     TensorRef none;
     int dil = 1;
@@ -509,6 +604,7 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
         c.len_out = lens;
         c.batch = batch;
         c.t_in = c.t_out = tmax;
+        c.sum_in = c.sum_out = sum_t;
         hipError_t e = conv("conv1x1_dp", d.pw[i], c);
         if (e != hipSuccess) return e;
         KPROF("ln_gelu_residual", launch_add_layer_norm(p, none, d.n2_g[i], d.n2_b[i], none, lens, batch, H, tmax, 1e-5f, 1, x, stream));
@@ -556,6 +652,16 @@ int64_t Engine::get_tap(const char* name, int utt, float* dst, size_t cap) {
     return n;
 }
 
+int Engine::set_arith(int a, std::string& err) {
+    if (a == arith) return 0;
+    if (a != VITS_ARITH_F32) {
+        err = "16-bit operand arithmetic is not available in this build";
+        return -1;
+    }
+    arith = a;
+    return 0;
+}
+
 int Engine::sync(std::string& err) {
     HIP_OK(hipStreamSynchronize(stream));
     return 0;
@@ -565,6 +671,10 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                           std::string& err) {
     if (B <= 0 || id_stride <= 0) {
         err = "empty batch";
+        return -1;
+    }
+    if (o.on_chunk && o.skip_host_copy) {  // (the only misuse of the sink; checked before any work is queued)
+        err = "on_chunk needs a host copy (skip_host_copy = 0)";
         return -1;
     }
     const int md = o.mode == VITS_MODE_DEFAULT ? mode : o.mode;
@@ -599,17 +709,20 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
 
     // ---- stage one buffers ------------------------------------------------------------------------------
     struct S1 {
-        int *ids, *lens, *cum, *frames, *stage_lens, *stage_mul, *stage_add;
+        int *ids, *lens, *cum, *frames, *stage_lens, *stage_mul, *stage_add, *seed_off;
         float *x, *qkv, *att, *tmp, *ffn, *stats, *dpx, *dpy, *dpp, *cond, *z, *u, *dur;
     } s1;
+    const size_t hdr_ints = (size_t)B * id_stride + 2 * (size_t)B + 2 * (size_t)(n_up + 1);
     auto layout1 = [&](Arena& a) {
-        s1.ids = a.alloc<int>((size_t)B * id_stride);
-        s1.lens = a.alloc<int>(B);
+        // host-written header, one block = one H2D copy: ids | lens | stage_mul | stage_add | seed_off
+        s1.ids = a.alloc<int>(hdr_ints);
+        s1.lens = s1.ids + (size_t)B * id_stride;
+        s1.stage_mul = s1.lens + B;
+        s1.stage_add = s1.stage_mul + (n_up + 1);
+        s1.seed_off = s1.stage_add + (n_up + 1);
         s1.cum = a.alloc<int>((size_t)B * id_stride);
         s1.frames = a.alloc<int>(B);
         s1.stage_lens = a.alloc<int>((size_t)(n_up + 1) * B);
-        s1.stage_mul = a.alloc<int>(n_up + 1);
-        s1.stage_add = a.alloc<int>(n_up + 1);
         s1.dur = a.alloc<float>((size_t)B * id_stride);
         s1.x = a.alloc<float>((size_t)B * H * ts);
         s1.qkv = a.alloc<float>((size_t)B * 3 * H * ts);
@@ -642,10 +755,6 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         return t;
     };
     TensorRef none;
-    HIP_OK(hipMemcpyAsync(s1.ids, ids, sizeof(int) * (size_t)B * id_stride, hipMemcpyHostToDevice, stream));
-    prof.fence();
-    HIP_OK(hipMemcpyAsync(s1.lens, tlen.data(), sizeof(int) * B, hipMemcpyHostToDevice, stream));
-    prof.fence();
     // vocoder stage lengths as affine functions of the frame count L: len_i = L*mul_i + add_i (Q1: the reference
     // never crops the transposed conv, so every stage gains K - s samples; vits.cpp:187)
     std::vector<int> smul(n_up + 1), sadd(n_up + 1);
@@ -657,12 +766,37 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         smul[i + 1] = smul[i] * s;
         sadd[i + 1] = sadd[i] * s + (K - s - 2 * crop);
     }
-    HIP_OK(hipMemcpyAsync(s1.stage_mul, smul.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
-    prof.fence();
-    HIP_OK(hipMemcpyAsync(s1.stage_add, sadd.data(), sizeof(int) * (n_up + 1), hipMemcpyHostToDevice, stream));
-    prof.fence();
+    {
+        // The header travels through engine-owned PINNED memory (two slots, each guarded by an event): an async call may
+        // return while the copy is still queued, so neither the caller's ids nor locals of this function may be its source.
+        HStage& hs = hstage_[hstage_next_];
+        hstage_next_ ^= 1;
+        if (hs.pending) HIP_OK(hipEventSynchronize(hs.ev));
+        hs.pending = false;
+        if (!hs.ev) HIP_OK(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+        if (hs.cap < hdr_ints) {
+            if (hs.p) hipHostFree(hs.p);
+            hs.p = nullptr;
+            hs.cap = 0;
+            HIP_OK(hipHostMalloc((void**)&hs.p, (hdr_ints + hdr_ints / 4 + 64) * sizeof(int), hipHostMallocDefault));
+            hs.cap = hdr_ints + hdr_ints / 4 + 64;
+        }
+        std::memcpy(hs.p, ids, sizeof(int) * (size_t)B * id_stride);
+        std::memcpy(hs.p + (size_t)B * id_stride, tlen.data(), sizeof(int) * B);
+        std::memcpy(hs.p + (size_t)B * id_stride + B, smul.data(), sizeof(int) * (n_up + 1));
+        std::memcpy(hs.p + (size_t)B * id_stride + B + (n_up + 1), sadd.data(), sizeof(int) * (n_up + 1));
+        // counter-noise stream of utterance b: noise_seed + seed_off[b] (default b; a dispatcher that re-orders utterances
+        // across ranks passes each one's global index so that its audio does not depend on where it ran)
+        for (int b = 0; b < B; ++b) hs.p[(size_t)B * id_stride + B + 2 * (n_up + 1) + b] = o.noise_seed_offsets ? o.noise_seed_offsets[b] : b;
+        HIP_OK(hipMemcpyAsync(s1.ids, hs.p, sizeof(int) * hdr_ints, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipEventRecord(hs.ev, stream));
+        hs.pending = true;
+        prof.fence();
+    }
 
     const int* dl = s1.lens;
+    int64_t sum_t = 0;  // (profiler accounting: real work = sum of the utterance lengths)
+    for (int b = 0; b < B; ++b) sum_t += tlen[b];
     TensorRef x = TR(s1.x, H, ts), qkv = TR(s1.qkv, 3 * H, ts), att = TR(s1.att, H, ts), tmp = TR(s1.tmp, H, ts), ffn = TR(s1.ffn, hp.ffn_dim, ts);
     auto sub = [](TensorRef t, int c0) {
         t.p += (int64_t)c0 * t.cs;
@@ -676,6 +810,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         c.len_out = dl;
         c.batch = B;
         c.t_in = c.t_out = tmax_;
+        c.sum_in = c.sum_out = sum_t;
         return c;
     };
 
@@ -725,12 +860,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     // ---- stochastic duration predictor, reverse (vits.cpp:927-972) ----------------------------------------
     TensorRef dpx = TR(s1.dpx, H, ts), dpy = TR(s1.dpy, H, ts), dpp = TR(s1.dpp, H, ts), cond = TR(s1.cond, H, ts), z = TR(s1.z, 2, ts), u = TR(s1.u, 32, ts);
     HIP_OK(conv("conv1x1_dp", dp_pre_, mk(x, dpx, Tmax)));
-    HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax));
+    HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax, sum_t));
     HIP_OK(conv("conv1x1_dp", dp_proj_, mk(dpx, cond, Tmax)));
     std::vector<float> host_noise;
     if (o.noise_kind == VITS_NOISE_COUNTER) {
         prof.begin("noise_dur", 0, 0, stream);
-        HIP_OK(launch_noise_dur(z, dl, B, Tmax, o.noise_seed, hp.noise_scale_dur, stream));
+        HIP_OK(launch_noise_dur(z, dl, B, Tmax, o.noise_seed, s1.seed_off, hp.noise_scale_dur, stream));
         prof.end(stream);
     } else {
         host_noise.assign((size_t)B * 2 * ts, 0.f);
@@ -767,7 +902,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             prof.begin("dp_flow_pre", 0, 0, stream);
             HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream));
             prof.end(stream);
-            HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax));
+            HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax, sum_t));
             HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
             prof.begin("dp_spline", 0, 0, stream);
             HIP_OK(launch_spline(u, z, 1 - c_first, dl, B, Tmax, hp.dp_bins, hp.dp_tail, inv_sqrt, md, stream));
@@ -799,6 +934,23 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             slen[i][b] = frames[b] * smul[i] + sadd[i];
             smax[i] = std::max(smax[i], slen[i][b]);
         }
+    if (o.frames_only) {
+        // dispatcher query: predicted frames / samples per utterance, no audio (buffer sizing, shard balancing by frames)
+        if (out) {
+            out->batch = (size_t)B;
+            out->stride = (size_t)smax[n_up];
+            out->lengths = new int64_t[B];
+            out->frames = new int64_t[B];
+            out->data = nullptr;
+            for (int b = 0; b < B; ++b) {
+                out->lengths[b] = slen[n_up][b];
+                out->frames[b] = frames[b];
+            }
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+        prof.fence();
+        return 0;
+    }
     if (o.collect_taps) {
         TensorRef d;
         d.p = s1.dur;
@@ -825,10 +977,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             }
     }
     const bool windowed = wins.size() > 1;
-    if (o.on_chunk && (!windowed || o.skip_host_copy)) {
-        err = "on_chunk needs vocoder_chunk_frames > 0 (smaller than the utterance), no collect_taps and a host copy";
-        return -1;
-    }
+    // (a run that is not windowed — no chunking asked for, a window at least as long as the longest utterance, which the
+    // caller cannot know in advance, or collect_taps — streams as ONE window: the sink gets each utterance in a single call)
     int Lw_max = 0;
     for (const Win& w : wins) Lw_max = std::max(Lw_max, w.hi - w.lo);
     const int M = smul[n_up];  // samples per frame
@@ -905,13 +1055,15 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     }
     prof.begin("prior_sample_gather", 0, 0, stream);
     HIP_OK(launch_zp(sub(stats, 0), sub(stats, F), s1.cum, id_stride, dl, s1.frames, noise, o.noise_kind == VITS_NOISE_COUNTER ? VITS_NOISE_COUNTER : VITS_NOISE_EXPLICIT,
-                     o.noise_seed, hp.noise_scale, zp, B, F, Lmax, stream));
+                     o.noise_seed, s1.seed_off, hp.noise_scale, zp, B, F, Lmax, stream));
     prof.end(stream);
     if (o.collect_taps) snapshot("z_p", zp, F, Lmax, B, frames);
 
     // ---- residual coupling flow, reverse (vits.cpp:519-538,500-517,452-498) ------------------------------------
     {
         const int* ll = d_len[0];
+        int64_t sum_frames = 0;
+        for (int b = 0; b < B; ++b) sum_frames += frames[b];
         TensorRef hout = TR(s2.hout, 2 * H, ls), gate = TR(s2.gate, H, ls);
         TensorRef hh = hout;  // channels [0,H) = h, [H,2H) = skip accumulator "outputs" (vits.cpp:460)
         auto mk2 = [&](TensorRef xin, TensorRef yout) {
@@ -922,6 +1074,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             c.len_out = ll;
             c.batch = B;
             c.t_in = c.t_out = Lmax;
+            c.sum_in = c.sum_out = sum_frames;
             return c;
         };
         for (int i = hp.n_flows - 1; i > -1; --i) {
@@ -993,17 +1146,17 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         HIP_OK(hipMemcpyAsync(s2.win_lens, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
         prof.fence();
         HIP_OK(hipStreamSynchronize(stream));  // wl goes out of scope
-        if (o.on_chunk) {
-            const size_t need = (size_t)B * out_stride * sizeof(float);
-            if (need > pinned_cap_) {
-                if (pinned_) hipHostFree(pinned_);
-                pinned_ = nullptr;
-                pinned_cap_ = 0;
-                HIP_OK(hipHostMalloc((void**)&pinned_, need, hipHostMallocDefault));
-                pinned_cap_ = need;
-            }
-            host_pcm = (float*)pinned_;
+    }
+    if (o.on_chunk) {
+        const size_t need = (size_t)B * out_stride * sizeof(float);
+        if (need > pinned_cap_) {
+            if (pinned_) hipHostFree(pinned_);
+            pinned_ = nullptr;
+            pinned_cap_ = 0;
+            HIP_OK(hipHostMalloc((void**)&pinned_, need, hipHostMallocDefault));
+            pinned_cap_ = need;
         }
+        host_pcm = (float*)pinned_;
     }
     // hands the finished window `w` to the caller's sink (blocks until its PCM is on the host)
     auto deliver = [&](size_t w) -> int {
@@ -1026,6 +1179,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             d_len[i] = windowed ? s2.win_lens + (wi * (size_t)(n_up + 2) + i) * B : d_len_full[i];
             smax[i] = Lw * smul[i] + sadd[i];
         }
+        std::vector<int64_t> ssum(n_up + 1, 0);  // (profiler accounting) sum over utterances of the stage lengths inside this window
+        for (int b = 0; b < B; ++b) {
+            const int lf = std::min(frames[b], wn.hi) - wn.lo;
+            if (lf <= 0) continue;
+            for (int i = 0; i <= n_up; ++i) ssum[i] += (int64_t)lf * smul[i] + sadd[i];
+        }
         const int* emit_hi = windowed ? s2.win_lens + (wi * (size_t)(n_up + 2) + n_up + 1) * B : nullptr;
         const int emit_lo = (wn.f0 - wn.lo) * M;
         TensorRef zwin = zp;
@@ -1039,6 +1198,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             c.len_out = d_len[0];
             c.batch = B;
             c.t_in = c.t_out = Lw;
+            c.sum_in = c.sum_out = ssum[0];
             c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
             c.post_act = 2;  // its only reader is the first upsampler, which takes leaky_relu(h0) (vits.cpp:613): activate at the writer
             c.post_slope = hp.lrelu;
@@ -1059,6 +1219,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                 c.batch = B;
                 c.t_in = smax[st_in];
                 c.t_out = smax[st_out];
+                c.sum_in = ssum[st_in];
+                c.sum_out = ssum[st_out];
                 c.pre_act = 0;  // leaky_relu before the upsampler (vits.cpp:613) was applied by whoever wrote `cur`
                 c.slope = hp.lrelu;
                 c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
@@ -1095,6 +1257,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     c1.len_in = c1.len_out = d_len[st_out];
                     c1.batch = B;
                     c1.t_in = c1.t_out = smax[st_out];
+                    c1.sum_in = c1.sum_out = ssum[st_out];
                     c1.dil = R.dil[d];
                     c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
                     c1.pre_act = lcopy ? 0 : 1;
@@ -1152,7 +1315,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         wv.p = wave_dst + (int64_t)wn.lo * M;  // window-local sample 0 is global sample lo * M
         wv.bs = wave_stride;
         wv.cs = (int)wave_stride;
-        prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)B * smax[n_up], 0, stream);
+        prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 4.0 * (dec_post_cin_ + 1) * (double)ssum[n_up], stream);
         HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, refmode ? hp.lrelu : 0.01f, pre, wv, d_len[n_up], B, smax[n_up], stream, emit_lo, emit_hi));  // Q2
         prof.end(stream);
         if (o.on_chunk) {

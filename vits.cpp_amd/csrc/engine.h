@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -109,9 +110,13 @@ class Engine {
   public:
     ~Engine();
     bool load(const uint8_t* bytes, size_t size, std::string& err);
+    // host-only: everything load() checks (format, hyper-parameters, every tensor's shape) without touching a device
+    bool validate(const uint8_t* bytes, size_t size, std::string& err);
     int process_batch(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out,
                       std::string& err);
     int sync(std::string& err);
+    int set_arith(int arith, std::string& err);  // VITS_ARITH_*: packs the 16-bit weight fragments on first use
+    int arith = VITS_ARITH_F32;
     int64_t get_tap(const char* name, int utt, float* dst, size_t cap);
 
     HParams hp;
@@ -136,6 +141,7 @@ class Engine {
     float* dec_post_w_ = nullptr;
     int dec_post_cin_ = 0, dec_post_k_ = 0;
     std::vector<void*> owned_;  // every device allocation made at load
+    bool dry_run_ = false;
 
     Arena a1_, a2_;
     // The three resblocks of a vocoder stage (kernel sizes 3/7/11) are independent chains of six convolutions; they run on
@@ -147,16 +153,26 @@ class Engine {
     int halo_frames_ = 0;      // receptive field of the vocoder in frames, one side (computed at load)
     void* pinned_ = nullptr;   // grow-only pinned staging for streamed PCM
     size_t pinned_cap_ = 0;  // VITS_RB_STREAMS=1 serialises everything on the main stream
+    struct HStage {  // pinned staging of the per-call host header (ids, lengths, stage tables)
+        int* p = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+    } hstage_[2];
+    int hstage_next_ = 0;
     std::map<std::string, Tap> taps_;
     int tap_batch_ = 0;
 
     float* upload(const std::vector<float>& v);
-    float* upload_tensor(const ModelFile& f, const std::string& name, std::string& err);
-    bool pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, int t_hint, PackedConv& out, std::string& err,
+    struct ConvShape {
+        int cout, cin, k;
+    };
+    float* upload_tensor(const ModelFile& f, const std::string& name, std::string& err, std::initializer_list<int64_t> want);
+    bool pack(const ModelFile& f, const std::string& wname, const std::string& bname, int epi, ConvShape want, PackedConv& out, std::string& err,
               int ct_stride = 0, int transform = 0);
     bool load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err);
     hipError_t conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on = nullptr);  // on == nullptr: the main stream
-    hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax);
+    hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax, int64_t sum_t);
     void snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens);
     void clear_taps();
 };

@@ -43,6 +43,9 @@ struct ConvCall {
     const int* len_out = nullptr;  // per-utterance valid output length (nullptr: t_out)
     int batch = 1;
     int t_in = 0, t_out = 0;  // maximum lengths (grid extent)
+    // profiler accounting only: sum over the batch of the per-utterance valid input / output lengths (< 0: batch * t_in / t_out).
+    // Blocks past an utterance's length exit at once, so work and traffic are counted over the real lengths, not the padded extent.
+    int64_t sum_in = -1, sum_out = -1;
     int dil = 1, pad_l = 0;
     int pre_act = 0;  // 1: leaky_relu(slope) on load
     float slope = 0.f;
@@ -78,11 +81,11 @@ hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int 
                          hipStream_t s);
 hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
                          hipStream_t s);
-hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, float scale, hipStream_t s);
+hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, const int* seed_off, float scale, hipStream_t s);
 hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
                             int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s);
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
-                     uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
+                     uint64_t seed, const int* seed_off, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s);
 // fp32 -> int16 PCM rows on the device (test/main.cpp:31-33); lens (device, optional) limits each row

@@ -494,15 +494,15 @@ hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const
 }
 
 // duration latents: z[c][t] = N(0,1) * noise_scale_duration (vits.cpp:948-949), counter-based stream
-__global__ void noise_dur_kernel(float* z, int64_t z_bs, int z_cs, const int* lens, int tmax, uint64_t seed, float scale) {
+__global__ void noise_dur_kernel(float* z, int64_t z_bs, int z_cs, const int* lens, int tmax, uint64_t seed, const int* seed_off, float scale) {
     const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     const int len = lens ? lens[b] : tmax;
     if (t >= len) return;
-    z[(int64_t)b * z_bs + (int64_t)c * z_cs + t] = vits_counter_normal(seed + (uint64_t)b, VITS_STREAM_NOISE_DUR, (uint64_t)c * len + t) * scale;
+    z[(int64_t)b * z_bs + (int64_t)c * z_cs + t] = vits_counter_normal(seed + (uint64_t)(seed_off ? seed_off[b] : b), VITS_STREAM_NOISE_DUR, (uint64_t)c * len + t) * scale;
 }
-hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, float scale, hipStream_t s) {
+hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, const int* seed_off, float scale, hipStream_t s) {
     dim3 grid((tmax + 63) / 64, 2, batch);
-    hipLaunchKernelGGL(noise_dur_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, lens, tmax, seed, scale);
+    hipLaunchKernelGGL(noise_dur_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, lens, tmax, seed, seed_off, scale);
     return hipGetLastError();
 }
 
@@ -575,7 +575,7 @@ hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, i
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs, int m_cs, const float* logvar, int64_t v_bs, int v_cs, const int* cum,
                                                  int cum_stride, const int* tok_lens, const int* frames, const float* noise, int64_t n_bs, int n_cs,
-                                                 int noise_kind, uint64_t seed, float noise_scale, float* zp, int64_t z_bs, int z_cs, int channels, int tmax_tok) {
+                                                 int noise_kind, uint64_t seed, const int* seed_off, float noise_scale, float* zp, int64_t z_bs, int z_cs, int channels, int tmax_tok) {
     __shared__ int tok[256];
     const int b = blockIdx.y, j0 = blockIdx.x * 256, tid = threadIdx.x;
     const int L = frames[b];
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs
         const float mu = a >= 0 ? mean[(int64_t)b * m_bs + (int64_t)c * m_cs + a] : 0.f;
         const float lv = a >= 0 ? logvar[(int64_t)b * v_bs + (int64_t)c * v_cs + a] : 0.f;
         float e;
-        if (noise_kind == VITS_NOISE_COUNTER) e = vits_counter_normal(seed + (uint64_t)b, VITS_STREAM_NOISE_PRIOR, (uint64_t)c * L + j);
+        if (noise_kind == VITS_NOISE_COUNTER) e = vits_counter_normal(seed + (uint64_t)(seed_off ? seed_off[b] : b), VITS_STREAM_NOISE_PRIOR, (uint64_t)c * L + j);
         else e = noise[(int64_t)b * n_bs + (int64_t)c * n_cs + j];
         float n = e * expf(lv);  // vits.cpp:1060
         n = n * noise_scale;     // :1061
@@ -613,10 +613,10 @@ __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs
 }
 
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
-                     uint64_t seed, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s) {
+                     uint64_t seed, const int* seed_off, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s) {
     dim3 grid((lmax + 255) / 256, batch, 16);
     hipLaunchKernelGGL(zp_kernel, grid, dim3(256), 0, s, mean.p, mean.bs, mean.cs, logvar.p, logvar.bs, logvar.cs, cum, cum_stride, tok_lens, frames, noise.p,
-                       noise.bs, noise.cs, noise_kind, seed, noise_scale, zp.p, zp.bs, zp.cs, channels, cum_stride);
+                       noise.bs, noise.cs, noise_kind, seed, seed_off, noise_scale, zp.p, zp.bs, zp.cs, channels, cum_stride);
     return hipGetLastError();
 }
 

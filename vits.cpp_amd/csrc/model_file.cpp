@@ -154,8 +154,20 @@ bool ModelFile::parse(const uint8_t* bytes, size_t size, std::string& err) {
             err = "tensor '" + t.name + "': rank > 4";
             return false;
         }
-        for (uint32_t j = 0; j < t.rank; ++j) t.ne[j] = r.u32();
+        // element count with an overflow guard: four u32 dimensions can wrap a 64-bit product, and nbytes is a u32, so a
+        // count above 2^32 can never match the payload anyway
+        uint64_t cnt = 1;
+        bool too_big = false;
+        for (uint32_t j = 0; j < t.rank; ++j) {
+            t.ne[j] = r.u32();
+            cnt *= (uint64_t)t.ne[j];  // cnt <= 2^32 before, factor < 2^32: no wrap
+            if (cnt > ((uint64_t)1 << 32)) too_big = true, cnt = ((uint64_t)1 << 32) + 1;
+        }
         const uint32_t nbytes = r.u32();
+        if (r.ok && too_big) {
+            err = "tensor '" + t.name + "': shape overflows the payload size";
+            return false;
+        }
         if (!r.ok || r.off + nbytes > r.n) {
             err = "truncated tensor '" + t.name + "'";
             return false;
