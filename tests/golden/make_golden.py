@@ -14,6 +14,12 @@ Fixtures (data only):
 The stage outputs are what transformers.VitsModel — the model the reference ports (src/vits.cpp:113) and was
 checked against (scripts/verify_layers.py:25) — computes; the oracle's VO_MODE_HF must reproduce them.
 
+  *_refmode_taps.npz       the same three models and inputs through a PATCHED transformers.VitsModel that restates, in
+                           torch and straight from the cited reference lines (never through the oracle), the five places
+                           where /root/reference/src/vits.cpp computes something else than the model it ports (SURVEY.md
+                           App. B Q1-Q5; see `reference_mode_patches`). They pin VO_MODE_REFERENCE / VITS_MODE_REFERENCE —
+                           the default mode of vits_model_process and of bench.py — independently of the oracle's own reading.
+
 usage: python tests/golden/make_golden.py            (from the repo root, after building csrc/libvits_hip.so)
 """
 import ast
@@ -74,10 +80,106 @@ def hf_model_from_file(parsed):
     return model
 
 
+# ---- reference mode: what /root/reference/src/vits.cpp computes where it deviates from transformers.VitsModel ----------------
+def _put_last_wrapped(t, value, add=False):
+    """index_put_last_dim / index_add_last_dim called with index = -1 (src/vits.cpp:726,742,750,830):
+    `auto offset = tensor->nb[0] * index;` (src/include/ggml-util.h:235,252) multiplies a size_t by -1, so the strided
+    view [1, rows] starts ONE FLOAT BEFORE the data: the write meant for the last element of row r lands on the last
+    element of row r-1, row 0's write falls in front of the tensor, and the last element of the LAST row is never written.
+    t: [rows = tokens, n] (the reference's ne = [n, tokens, 1])."""
+    if add:
+        t[:-1, -1] += value
+    else:
+        t[:-1, -1] = value
+
+
+def _ref_rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, reverse=False, tail_bound=5.0,
+                                   min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+    """src/vits.cpp:695-802, statement by statement, on [tokens, bins] tensors (reverse only, like the reference :708)."""
+    assert reverse
+    f32 = np.float32
+    upper, lower = f32(tail_bound), f32(-tail_bound)
+    nb = unnormalized_widths.shape[-1]
+    widths = torch.softmax(unnormalized_widths, -1)                                                   # :719
+    widths = widths * float(f32(min_bin_width) + (f32(1) - f32(min_bin_width) * f32(nb)))              # :720  (Q3: the sum SCALES)
+    cumwidths = torch.cumsum(widths, -1)                                                              # :721
+    cumwidths = torch.nn.functional.pad(cumwidths, (1, 0))                                            # :723
+    cumwidths = cumwidths * float(upper - lower) + float(lower)                                       # :724
+    cumwidths[:, 0] = float(lower)                                                                    # :725
+    _put_last_wrapped(cumwidths, float(upper))                                                        # :726  (Q4)
+    widths = cumwidths[:, 1:] - cumwidths[:, :-1]                                                     # :728-731
+    derivatives = torch.nn.functional.softplus(unnormalized_derivatives) + min_derivative             # :733
+    heights = torch.softmax(unnormalized_heights, -1)                                                 # :735
+    heights = heights * float(f32(1) - f32(min_bin_height) * f32(nb)) + min_bin_height                # :736
+    cumheights = torch.cumsum(heights, -1)                                                            # :737
+    cumheights = torch.nn.functional.pad(cumheights, (1, 0))                                          # :739
+    cumheights = cumheights * float(upper - lower) + float(lower)                                     # :740
+    cumheights[:, 0] = float(lower)                                                                   # :741
+    _put_last_wrapped(cumheights, float(upper))                                                       # :742  (Q4)
+    heights = cumheights[:, 1:] - cumheights[:, :-1]                                                  # :743-746
+    bin_locations = cumheights.clone()                                                                # :748
+    _put_last_wrapped(bin_locations, 1e-6, add=True)                                                  # :750  (Q4)
+    bin_idx = (inputs[:, None] >= bin_locations).sum(-1) - 1                                          # :752-762
+    g = lambda t: t.gather(-1, bin_idx[:, None])[:, 0]
+    input_cumwidths, input_bin_widths, input_cumheights = g(cumwidths), g(widths), g(cumheights)      # :764-766
+    delta = heights / widths                                                                          # :768
+    input_delta = g(delta)
+    input_derivatives, input_derivatives_plus_one = g(derivatives), g(derivatives[:, 1:])             # :771-772
+    input_heights = g(heights)
+    intermediate1 = input_derivatives + input_derivatives_plus_one - 2 * input_delta                  # :775
+    intermediate2 = inputs - input_cumheights                                                         # :782
+    intermediate3 = intermediate2 * intermediate1
+    a = input_heights * (input_delta - input_derivatives) + intermediate3                             # :785
+    b = input_heights * input_derivatives - intermediate3
+    c = -input_delta * intermediate2
+    discriminant = b.pow(2) - 4 * a * c                                                               # :789-791
+    root = (2 * c) / (-b - torch.sqrt(discriminant))                                                  # :792-795
+    return root * input_bin_widths + input_cumwidths                                                  # :797
+
+
+def _ref_unconstrained_rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, reverse=False,
+                                                 tail_bound=5.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+    """src/vits.cpp:804-852. inputs [1, 1, T]; the others [1, 1, T, bins(-1)]. Every latent of the fixtures lies inside
+    [-tail_bound, tail_bound] (asserted), so the masked get/set pair of :832-849 — whose misalignment outside the interval
+    (Q6) is documented as not reproduced — is the identity here."""
+    assert reverse and inputs.shape[0] == 1 and inputs.shape[1] == 1
+    assert bool(((inputs >= -tail_bound) & (inputs <= tail_bound)).all()), "fixture latent outside the spline interval (Q6 territory)"
+    constant = float(np.log(np.exp(1 - min_derivative) - 1))                                         # :826
+    ud = torch.nn.functional.pad(unnormalized_derivatives[0, 0], (1, 1))                              # :828
+    ud[:, 0] = constant                                                                               # :829
+    _put_last_wrapped(ud, constant)                                                                   # :830  (Q4)
+    out = _ref_rational_quadratic_spline(inputs[0, 0], unnormalized_widths[0, 0], unnormalized_heights[0, 0], ud, reverse, tail_bound,
+                                         min_bin_width, min_bin_height, min_derivative)
+    return out[None, None], torch.zeros_like(inputs)
+
+
+def _ref_elementwise_affine_forward(self, inputs, padding_mask, global_conditioning=None, reverse=False):
+    """src/vits.cpp:901-925: (inputs - translate) * exp(+log_scale)  (Q5; HF: exp(-log_scale), modeling_vits.py:703)."""
+    assert reverse
+    return (inputs - self.translate) * torch.exp(self.log_scale) * padding_mask, None
+
+
+class reference_mode_patches:
+    """Context manager: transformers' VITS with the reference's Q3/Q4/Q5 arithmetic (Q1/Q2 are applied in hf_taps' decoder)."""
+
+    def __enter__(self):
+        from transformers.models.vits import modeling_vits as mv
+        self.mv = mv
+        self.saved = (mv._unconstrained_rational_quadratic_spline, mv.VitsElementwiseAffine.forward)
+        mv._unconstrained_rational_quadratic_spline = _ref_unconstrained_rational_quadratic_spline
+        mv.VitsElementwiseAffine.forward = _ref_elementwise_affine_forward
+        return self
+
+    def __exit__(self, *exc):
+        self.mv._unconstrained_rational_quadratic_spline, self.mv.VitsElementwiseAffine.forward = self.saved
+
+
 @torch.no_grad()
-def hf_taps(model, ids, noise_dur, noise_prior_fn):
+def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False):
     """Restates VitsModel.forward (modeling_vits.py:1298-1394) step by step to expose the stage outputs, with the two
-    torch.randn draws replaced by the supplied arrays."""
+    torch.randn draws replaced by the supplied arrays. refmode: call inside `reference_mode_patches()`; additionally the
+    transposed convs run without padding (Q1, src/vits.cpp:187 overwrites padding with 0), the resblock mean is a multiply by
+    float(1/num_kernels) (:607,635) and the final LeakyReLU uses the config slope (Q2, :638)."""
     cfg = model.config
     input_ids = torch.from_numpy(ids.astype(np.int64))[None]
     mask = torch.ones_like(input_ids).unsqueeze(-1).float()
@@ -115,16 +217,21 @@ def hf_taps(model, ids, noise_dur, noise_prior_fn):
     h = dec.conv_pre(spec)
     for i in range(dec.num_upsamples):
         h = torch.nn.functional.leaky_relu(h, cfg.leaky_relu_slope)
-        h = dec.upsampler[i](h)
+        up = dec.upsampler[i]
+        if refmode:
+            h = torch.nn.functional.conv_transpose1d(h, up.weight, up.bias, stride=up.stride, padding=0)  # Q1
+        else:
+            h = up(h)
         res = dec.resblocks[i * dec.num_kernels](h)
         for j in range(1, dec.num_kernels):
             res = res + dec.resblocks[i * dec.num_kernels + j](h)
-        h = res / dec.num_kernels
-    h = torch.nn.functional.leaky_relu(h)
+        h = res * float(np.float32(1.0 / dec.num_kernels)) if refmode else res / dec.num_kernels
+    h = torch.nn.functional.leaky_relu(h, cfg.leaky_relu_slope) if refmode else torch.nn.functional.leaky_relu(h)  # Q2
     pre = dec.conv_post(h)
     wave = torch.tanh(pre)
-    # cross-check against the unmodified forward of the decoder
-    assert torch.allclose(wave, dec(spec), atol=1e-6)
+    if not refmode:
+        # cross-check against the unmodified forward of the decoder
+        assert torch.allclose(wave, dec(spec), atol=1e-6)
     f = lambda t: t[0].numpy().astype(np.float32)
     return dict(
         ids=ids.astype(np.int32), noise_dur=noise_dur.astype(np.float32), noise_prior=noise_prior.astype(np.float32),
@@ -140,12 +247,15 @@ def make_ids(T, vocab, seed):
     return ids
 
 
-def taps_for(parsed, T, seed):
+def taps_for(parsed, T, seed, refmode=False):
     model = hf_model_from_file(parsed)
     rng = np.random.default_rng(seed)
     ids = make_ids(T, model.config.vocab_size, seed)
     nd = rng.standard_normal((2, T)).astype(np.float32)
     F = model.config.flow_size
+    if refmode:
+        with reference_mode_patches():
+            return hf_taps(model, ids, nd, lambda L: rng.standard_normal((F, L)).astype(np.float32), refmode=True)
     return hf_taps(model, ids, nd, lambda L: rng.standard_normal((F, L)).astype(np.float32))
 
 
@@ -200,14 +310,19 @@ def main():
     data = reference_exported_tiny()
     parsed = parse_model_file(data)
     np.savez(os.path.join(HERE, "tiny_hf_export_taps.npz"), **taps_for(parsed, 14, 11))
+    np.savez(os.path.join(HERE, "tiny_hf_export_refmode_taps.npz"), **taps_for(parsed, 14, 11, refmode=True))
     print("tiny_hf_export.ggml", len(data), "bytes,", len(parsed["tensors"]), "tensors")
     # (B) tiny synthetic
     data = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)
     np.savez(os.path.join(HERE, "tiny_synth_taps.npz"), **taps_for(parse_model_file(data), 20, 12))
+    np.savez(os.path.join(HERE, "tiny_synth_refmode_taps.npz"), **taps_for(parse_model_file(data), 20, 12, refmode=True))
     # (C) full synthetic (MMS-TTS architecture)
     data = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL)
     taps = taps_for(parse_model_file(data), 16, 13)
     np.savez(os.path.join(HERE, "full_synth_taps.npz"), **taps)
+    rtaps = taps_for(parse_model_file(data), 16, 13, refmode=True)
+    np.savez(os.path.join(HERE, "full_synth_refmode_taps.npz"), **rtaps)
+    print("reference mode: frames", int(rtaps["durations"].sum()), "vs HF", int(taps["durations"].sum()), "; samples", rtaps["waveform"].size, "vs", taps["waveform"].size)
     for k, v in taps.items():
         print(k, v.shape, float(np.sqrt((v.astype(np.float64) ** 2).mean())))
 
