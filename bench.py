@@ -322,6 +322,7 @@ def main():
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         total_samples = int(ts.item())
 
+    res = None
     if rank == 0:
         sr = models[0].sampling_rate
         value = total_samples / elapsed
@@ -420,12 +421,17 @@ def main():
             cb = cpu_baseline([(j["bytes"], j["ids"][:n_cpu], noise_base) for j in jobs], args.mode, with_one_thread=not c5)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_baseline"] = value / cb["value"]
-        print(json.dumps(res))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     for m in models:
         m.close()
+    if rank == 0:
+        # the JSON line goes out LAST: RCCL writes a version banner to the C stdout, which would otherwise follow it
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

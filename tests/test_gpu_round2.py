@@ -186,6 +186,7 @@ def test_c_caller_synthesises_through_the_reference_entry_points(pkg, oracle, tm
 #include <stdio.h>
 #include "vits.h"
 int main(int argc, char** argv) {
+    if (argc < 3) return 1;
     vits_model* m = vits_model_load_from_file(argv[1]);
     if (!m) { fprintf(stderr, "load: %s\n", vits_last_error()); return 2; }
     for (int rep = 0; rep < 2; ++rep) {
