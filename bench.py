@@ -142,13 +142,21 @@ def launcher(args):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+    # watch every rank: one that dies would leave the others waiting in the collective forever
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # (our own children, by handle)
+    out0 = procs[0].stdout.read() if procs[0].stdout else b""
     codes = [p.wait() for p in procs]
     if any(codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         return 1
     line = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
     if not line:
@@ -187,7 +195,7 @@ def main():
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
+    if env_world is None and (args.gpus > 1 or os.environ.get("VITS_BENCH_LAUNCH") == "1"):  # (VITS_BENCH_LAUNCH=1: launcher path at N = 1, for tests)
         sys.exit(launcher(args))
     world = int(env_world or "1")
     if world != args.gpus and not (world == 1 and args.gpus == 1):

@@ -55,12 +55,14 @@ def test_bench_forced_dist_line(tmp_path):
     """bench.py with the RCCL exchange inside the timed step (VITS_BENCH_FORCE_DIST=1 on a 1-GPU box): n_gpus, value and
     the roofline block must be there, and the line must parse."""
     import json
-    env = dict(os.environ)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["VITS_BENCH_FORCE_DIST"] = "1"
+    env["VITS_BENCH_LAUNCH"] = "1"  # through the launcher (fresh child rank, JSON relayed), as `--gpus N` does for N > 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra-passes"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r.stdout.count("\n") == 1, r.stdout[:400]  # ONE line, nothing else on stdout
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
 
 
