@@ -324,6 +324,60 @@ inline float softplusf(float x) {                                            // 
 }
 inline float gelu_erf(float x) { return 0.5f * x * (1.0f + std::erf(x * 0.70710678118654752440f)); }  // HF:636
 
+// ------------------------------------------------------------------------------------------------
+// Q7: the reference's conv arithmetic. conv1d_impl unfolds the input with ggml_im2col_1d into an
+// fp16 tensor and multiplies it with the fp16 weights (custom-ops.h:684-690; weights cast by scripts/export_vits.py:87), and
+// ggml_conv_transpose_1d converts its source to fp16 the same way: every Conv1d / ConvTranspose1d (incl. the 192
+// one-channel depthwise convs, vits.cpp:157-166) sees operands ROUNDED TO 16 BITS, products summed in fp32. Linear layers
+// (q/k/v/out projections, ggml_mul_mat on f32 x f32, vits.cpp:287-289,358) do not. VO_ARITH_F16 / VO_ARITH_BF16 reproduce
+// that (round-to-nearest-even of the conv input after its fused leaky_relu, and of the weights — a no-op when the file
+// already stores that type); VO_ARITH_F32 (default) keeps everything fp32.
+// ------------------------------------------------------------------------------------------------
+thread_local int g_arith = 0;  // VO_ARITH_*; read on the calling thread at conv entry, captured by value in the workers
+
+inline float round_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return f;  // inf / nan
+    u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even on the upper 16 bits
+    u &= 0xffff0000u;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline float round_f16(float f) {
+    // fp32 -> fp16 (round to nearest even, subnormals kept, overflow to inf) -> fp32, in integer arithmetic
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7fffffffu;
+    float out;
+    if (a >= 0x7f800000u) return f;  // inf / nan
+    if (a >= 0x477ff000u) {          // >= 65520: rounds to inf
+        a = 0x7f800000u;
+    } else if (a < 0x38800000u) {  // < 2^-14: fp16 subnormal, quantum 2^-24
+        float v;
+        std::memcpy(&v, &a, 4);
+        const float q = v * 16777216.0f;                                  // exact scaling
+        const float r = std::nearbyintf(q);                               // round-half-even in the default rounding mode
+        v = r * (1.0f / 16777216.0f);
+        std::memcpy(&a, &v, 4);
+    } else {
+        a += 0xfffu + ((a >> 13) & 1u);  // keep 10 mantissa bits
+        a &= 0xffffe000u;
+    }
+    a |= sign;
+    std::memcpy(&out, &a, 4);
+    return out;
+}
+inline float round_arith(float v, int arith) { return arith == 2 ? round_f16(v) : arith == 1 ? round_bf16(v) : v; }
+// weights rounded to the arithmetic type (cached per call site is not worth it: the oracle is a checker)
+inline const float* rounded_weights(const float* w, size_t n, int arith, std::vector<float>& store) {
+    if (!arith) return w;
+    store.resize(n);
+    for (size_t i = 0; i < n; ++i) store[i] = round_arith(w[i], arith);
+    return store.data();
+}
+
 /*
  * conv1d_with_bias, ref: vits.cpp:171-176 -> conv1d_impl custom-ops.h:680-694 (im2col + mul_mat == direct conv),
  * bias broadcast over time custom-ops.h:397-431. Weights w[Cout][Cin][K] (torch layout, file ne=[K,Cin,Cout]).
@@ -334,6 +388,9 @@ void conv1d_raw(const float* x, int cin, int T, int x_stride, const float* w, co
                 int pad_l, int pad_r, bool pre_lrelu, float slope, float* y, int y_stride, int threads) {
     const int Tp = T + pad_l + pad_r;
     const int To = Tp - (K - 1) * dil;
+    const int arith = g_arith;
+    std::vector<float> wstore;
+    w = rounded_weights(w, (size_t)cout * cin * K, arith, wstore);
     std::vector<float> xp((size_t)cin * Tp);
     parallel_for(threads, cin, [&](int64_t b0, int64_t e0) {
         for (int64_t ci = b0; ci < e0; ++ci) {
@@ -346,6 +403,8 @@ void conv1d_raw(const float* x, int cin, int T, int x_stride, const float* w, co
                 for (int t = 0; t < T; ++t) dst[t] = leaky(src[t], slope);
             else
                 std::memcpy(dst, src, sizeof(float) * T);
+            if (arith)
+                for (int t = 0; t < T; ++t) dst[t] = round_arith(dst[t], arith);  // the fp16 im2col (custom-ops.h:684-690)
         }
     });
     // register-blocked direct convolution: 4 output channels x 32 time steps of accumulators stay in vector registers
@@ -428,8 +487,11 @@ void conv_transpose1d_raw(const float* x, int cin, int T, int x_stride, const fl
     const int Q = T + taps - 1;              // q range: 0 .. T + taps - 2
     std::vector<float> xa((size_t)cin * (Q + taps), 0.f);  // x with (taps-1) zeros in front: xa[ci][q + taps-1 - m] = x[ci][q - m]
     const int XS = Q + taps;
+    const int arith = g_arith;
+    std::vector<float> wstore;
+    w = rounded_weights(w, (size_t)cin * cout * K, arith, wstore);
     for (int ci = 0; ci < cin; ++ci)
-        for (int t = 0; t < T; ++t) xa[(size_t)ci * XS + (taps - 1) + t] = leaky(x[(size_t)ci * x_stride + t], pre_slope);
+        for (int t = 0; t < T; ++t) xa[(size_t)ci * XS + (taps - 1) + t] = round_arith(leaky(x[(size_t)ci * x_stride + t], pre_slope), arith);
     if (threads <= 0) threads = default_threads();
     parallel_for(threads, cout, [&](int64_t b, int64_t e) {
         std::vector<float> ph((size_t)s * Q);
@@ -574,7 +636,12 @@ void text_encoder(const Ctx& c, const int32_t* ids, int T, Act& enc_out, Act& m_
             const Tensor& W = m.T(base + "attention." + name + ".weight");  // [out][in]
             const Tensor& B = m.T(base + "attention." + name + ".bias");
             Act y(H, T);
-            conv1d_raw(x.d.data(), H, T, T, W.d.data(), B.d.data(), H, 1, 1, 0, 0, false, 0.f, y.d.data(), T, c.threads);
+            {
+                const int keep = g_arith;
+                g_arith = 0;  // Linear: ggml_mul_mat on f32 x f32 (vits.cpp:287-289,358), no fp16 im2col
+                conv1d_raw(x.d.data(), H, T, T, W.d.data(), B.d.data(), H, 1, 1, 0, 0, false, 0.f, y.d.data(), T, c.threads);
+                g_arith = keep;
+            }
             return y;
         };
         Act q = lin("q_proj"), k = lin("k_proj"), v = lin("v_proj");
@@ -586,7 +653,12 @@ void text_encoder(const Ctx& c, const int32_t* ids, int T, Act& enc_out, Act& m_
         {
             const Tensor& W = m.T(base + "attention.out_proj.weight");
             const Tensor& B = m.T(base + "attention.out_proj.bias");
-            conv1d_raw(att.d.data(), H, T, T, W.d.data(), B.d.data(), H, 1, 1, 0, 0, false, 0.f, o.d.data(), T, c.threads);
+            {
+                const int keep = g_arith;
+                g_arith = 0;  // Linear: ggml_mul_mat on f32 x f32 (vits.cpp:287-289,358), no fp16 im2col
+                conv1d_raw(att.d.data(), H, T, T, W.d.data(), B.d.data(), H, 1, 1, 0, 0, false, 0.f, o.d.data(), T, c.threads);
+                g_arith = keep;
+            }
         }
         for (size_t i = 0; i < x.d.size(); ++i) x.d[i] = x.d[i] + o.d[i];  // ref: vits.cpp:367 (residual + cur)
         layer_norm_channels(x, m.T(base + "layer_norm.weight"), m.T(base + "layer_norm.bias"), m.ln_eps);
@@ -626,7 +698,7 @@ Act dds(const Ctx& c, const std::string& base, Act x, const Act* g) {
                 float a = bd.d[ch];
                 for (int j = 0; j < K; ++j) {
                     const int tt = t + j * dil - pad;
-                    if (tt >= 0 && tt < T) a += wd.d[(size_t)ch * K + j] * x.d[(size_t)ch * T + tt];
+                    if (tt >= 0 && tt < T) a += round_arith(wd.d[(size_t)ch * K + j], g_arith) * round_arith(x.d[(size_t)ch * T + tt], g_arith);
                 }
                 h.d[(size_t)ch * T + t] = a;
             }
@@ -988,6 +1060,10 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
     try {
         const vo_model& m = *mp;
         if (T <= 0) throw std::runtime_error("empty input");
+        g_arith = opts ? opts->arith : 0;
+        struct ArithReset {
+            ~ArithReset() { g_arith = 0; }
+        } arith_reset;
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         auto run = std::make_unique<vo_run>();
         Act enc, m_p, logs_p;
@@ -1131,6 +1207,10 @@ VO_API int vo_conv1d(const vo_conv1d_desc* d, const float* x, const float* w, co
                      const int32_t* lens, float* y, int32_t threads) {
     const int gate = d->post_act == 2;
     const int cy = gate ? d->cout / 2 : d->cout;
+    g_arith = d->arith;
+    struct ArithReset {
+        ~ArithReset() { g_arith = 0; }
+    } arith_reset;
     const int pad_r = (d->k - 1) * d->dilation - d->pad_left;
     if (pad_r < 0) return -1;
     if (threads <= 0) threads = default_threads();
@@ -1158,6 +1238,10 @@ VO_API int vo_conv1d(const vo_conv1d_desc* d, const float* x, const float* w, co
 }
 
 VO_API int vo_conv_transpose1d(const vo_convt1d_desc* d, const float* x, const float* w, const float* bias, const int32_t* lens, float* y) {
+    g_arith = d->arith;
+    struct ArithReset {
+        ~ArithReset() { g_arith = 0; }
+    } arith_reset;
     for (int b = 0; b < d->batch; ++b) {
         const int len = lens ? lens[b] : d->t;
         conv_transpose1d_raw(x + (size_t)b * d->cin * d->t_stride, d->cin, len, d->t_stride, w, bias, d->cout, d->k, d->stride, d->crop, d->pre_slope,

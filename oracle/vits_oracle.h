@@ -34,6 +34,10 @@ typedef struct vo_run vo_run;
 
 #define VO_MODE_REFERENCE 0
 #define VO_MODE_HF 1
+/* conv arithmetic (Q7): F32 = exact; F16 = the reference's fp16 im2col x fp16 weights -> fp32 (custom-ops.h:684-690); BF16 likewise */
+#define VO_ARITH_F32 0
+#define VO_ARITH_BF16 1
+#define VO_ARITH_F16 2
 #define VO_NOISE_REFERENCE 0
 #define VO_NOISE_COUNTER 1
 #define VO_NOISE_EXPLICIT 2
@@ -47,6 +51,7 @@ typedef struct vo_opts {
     int64_t noise_prior_stride;
     int32_t fixed_duration;     /* >0: pin every id to this many frames */
     int32_t threads;            /* <=0: max(hardware_concurrency, 6) like src/include/common.h:19-21 */
+    int32_t arith;              /* VO_ARITH_*: operand rounding of every Conv1d / ConvTranspose1d (not of the Linear layers) */
 } vo_opts;
 
 VO_API const char* vo_last_error(void);
@@ -79,6 +84,7 @@ typedef struct vo_conv1d_desc {
     float pre_slope;
     int32_t post_act;
     float out_scale;
+    int32_t arith; /* VO_ARITH_* */
 } vo_conv1d_desc;
 VO_API int vo_conv1d(const vo_conv1d_desc* d, const float* x, const float* w, const float* bias, const float* residual,
                      const float* accum, const int32_t* lens, float* y, int32_t threads);
@@ -86,6 +92,7 @@ typedef struct vo_convt1d_desc {
     int32_t batch, cin, cout, t, t_stride, t_out_stride;
     int32_t k, stride, crop;
     float pre_slope;
+    int32_t arith; /* VO_ARITH_* */
 } vo_convt1d_desc;
 VO_API int vo_conv_transpose1d(const vo_convt1d_desc* d, const float* x, const float* w, const float* bias,
                                const int32_t* lens, float* y);

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profile job: rocprofv3 kernel stats + PMC passes (HBM traffic, MFMA busy, LDS conflicts) over the bench workload, reduced into
+# profiles-ready files under gpurun_out/$TAG/. usage: bash tools/jobs/profile.sh TAG [extra bench args]
+TAG=${1:-prof}; shift
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $O
+BENCH="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --single-pass $*"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $BENCH --steps 5 --warmup 2 > $O/bench_under_rocprof.json 2> $O/stats.err
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass -d $O/pmc_$name --output-format csv -- python3 $BENCH --steps 2 --warmup 1 > /dev/null 2> $O/pmc_$name.err
+done
+cd $GRAFT_REPO_ROOT
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
+python3 tools/pmc_traffic.py $O/pmc_traffic.json --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
+python3 tools/pmc_mfma.py $O/pmc_mfma.json $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
+# keep the merged payload small: drop the raw traces
+rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
+head -12 $O/kernel_stats.csv | cut -c1-150
