@@ -391,13 +391,19 @@ def main():
             avg_ms = dom["ms"] / dom["calls"]
             achieved = dom["flop"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
             all_ms = sum(g["ms"] for g in groups.values())
-            peak = PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0
-            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                               "traffic": None, "kernel": dom_key, "avg_launch_ms": avg_ms, "launches": dom["calls"],
-                               "share_of_gpu_time": dom["ms"] / all_ms,
-                               "flop_accounting": "algorithmic: 2 * rows * c_in * taps * (sum over utterances of the real output length), not the padded grid",
-                               "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
-                               "hbm_frac_if_algorithmic": dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            peak = PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
+            alg_gbs = dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
+            mfma_frac, hbm_frac = achieved / peak, alg_gbs / PEAK_HBM_GBS
+            if args.arith == "f32" or mfma_frac >= hbm_frac:
+                res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": mfma_frac}
+            else:  # 16-bit operands: 16x the MFMA rate, the same bytes -> the conv is bound by HBM, not by the matrix cores
+                res["roofline"] = {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
+            res["roofline"].update({"traffic": None, "kernel": dom_key, "avg_launch_ms": avg_ms, "launches": dom["calls"],
+                                    "share_of_gpu_time": dom["ms"] / all_ms,
+                                    "flop_accounting": "algorithmic: 2 * rows * c_in * taps * (sum over utterances of the real output length), not the padded grid",
+                                    "algorithmic_tflops": achieved, "mfma_frac_if_algorithmic": mfma_frac,
+                                    "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
+                                    "hbm_frac_if_algorithmic": hbm_frac})
             # HBM bytes per launch of that kernel and MFMA-busy fraction from the PMC passes (separate rocprofv3 --pmc runs over
             # this same command, reduced by tools/pmc_traffic.py / tools/pmc_summary.py): only a file collected for THIS
             # build (same source hash) is used, otherwise the fields stay null

@@ -198,6 +198,9 @@ VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap);
  * of the same reference lines. All tensors are dense fp32, layout [batch][channels][time], time fastest
  * (== the reference's ggml ne order [time, channels, batch]). lens may be NULL (all = T). */
 
+/* Arithmetic of the operator-level conv entry points below on this thread (VITS_ARITH_*; default fp32). */
+VITS_API int vits_op_set_arith(int32_t arith);
+
 /* conv1d_with_bias (vits.cpp:171-176 -> custom-ops.h:680-694) with the fusions the engine uses.
  * y = post( conv(pre(x)) + bias ), pre: 0 none, 1 leaky_relu(slope); post: 0 none, 1 relu,
  * 2 gated tanh*sigmoid over channel halves (vits.cpp:442-450; Cout must be even, output has Cout/2 channels);

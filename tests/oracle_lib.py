@@ -14,6 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libvits_oracle.so")
 
 MODE_REFERENCE, MODE_HF = 0, 1
+ARITH_F32, ARITH_BF16, ARITH_F16 = 0, 1, 2
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
 
 TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "noise_dur", "noise_prior", "z_p", "z_flow",
@@ -23,19 +24,19 @@ TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "n
 class Opts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("noise_kind", C.c_int32), ("noise_seed", C.c_uint64), ("noise_dur", C.c_void_p),
                 ("noise_prior", C.c_void_p), ("noise_prior_stride", C.c_int64), ("fixed_duration", C.c_int32),
-                ("threads", C.c_int32)]
+                ("threads", C.c_int32), ("arith", C.c_int32)]
 
 
 class Conv1dDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("t", C.c_int32), ("t_stride", C.c_int32),
                 ("k", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32), ("pre_act", C.c_int32),
-                ("pre_slope", C.c_float), ("post_act", C.c_int32), ("out_scale", C.c_float)]
+                ("pre_slope", C.c_float), ("post_act", C.c_int32), ("out_scale", C.c_float), ("arith", C.c_int32)]
 
 
 class ConvT1dDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("t", C.c_int32), ("t_stride", C.c_int32),
                 ("t_out_stride", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("crop", C.c_int32),
-                ("pre_slope", C.c_float)]
+                ("pre_slope", C.c_float), ("arith", C.c_int32)]
 
 
 _lib = None
@@ -136,13 +137,13 @@ class Model:
         return buf[:n].copy()
 
     def process_ids(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, noise_dur=None,
-                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS):
+                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS, arith=0):
         """Runs the full restated graph for ONE utterance. Returns {tap: np.ndarray} (flat [C*len] arrays reshaped
         to [C, len] where C is known)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         nd, npr = _f32(noise_dur), _f32(noise_prior)
         o = Opts(mode, noise_kind, noise_seed, _ptr(nd), _ptr(npr), 0 if npr is None else npr.shape[-1], fixed_duration,
-                 threads)
+                 threads, arith)
         r = lib().vo_process_ids(self._h, _ptr(ids), ids.size, C.byref(o))
         if not r:
             raise OracleError(lib().vo_last_error().decode())
@@ -167,12 +168,12 @@ def reference_noise(n, seed=None):
 
 
 def conv1d(x, w, bias=None, dilation=1, pad_left=None, pre_slope=None, post_act=0, residual=None, accum=None, out_scale=1.0,
-           lens=None, threads=0):
+           lens=None, threads=0, arith=0):
     x, w = _f32(x), _f32(w)
     B, cin, T = x.shape
     cout, _, k = w.shape
     d = Conv1dDesc(B, cin, cout, T, T, k, dilation, (k - 1) * dilation // 2 if pad_left is None else pad_left,
-                   0 if pre_slope is None else 1, 0.0 if pre_slope is None else pre_slope, post_act, out_scale)
+                   0 if pre_slope is None else 1, 0.0 if pre_slope is None else pre_slope, post_act, out_scale, arith)
     cy = cout // 2 if post_act == 2 else cout
     y = np.zeros((B, cy, T), np.float32)
     bias, residual, accum = _f32(bias), _f32(residual), _f32(accum)
@@ -182,12 +183,12 @@ def conv1d(x, w, bias=None, dilation=1, pad_left=None, pre_slope=None, post_act=
     return y
 
 
-def conv_transpose1d(x, w, bias, stride, crop, pre_slope=1.0, lens=None):
+def conv_transpose1d(x, w, bias, stride, crop, pre_slope=1.0, lens=None, arith=0):
     x, w, bias = _f32(x), _f32(w), _f32(bias)
     B, cin, T = x.shape
     _, cout, k = w.shape
     To = stride * T + k - stride - 2 * crop
-    d = ConvT1dDesc(B, cin, cout, T, T, To, k, stride, crop, pre_slope)
+    d = ConvT1dDesc(B, cin, cout, T, T, To, k, stride, crop, pre_slope, arith)
     y = np.zeros((B, cout, To), np.float32)
     lens = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
     assert lib().vo_conv_transpose1d(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(lens), _ptr(y)) == 0

@@ -7,6 +7,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = 3
 m = pkg.Model(pkg.synth_model_bytes(0x5EED, 0))
+if len(sys.argv) > 3:
+    m.set_arith({"f32": 0, "bf16": 1, "f16": 2}[sys.argv[3]])
 ids = pkg.synth_ids(B, T)
 for _ in range(2):
     m.process_batch(ids, noise_seed=4321, skip_host_copy=True)

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "vits_prof_enable", "vits_prof_reset", "vits_prof_report", "vits_op_conv1d", "vits_op_conv_transpose1d",
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
     "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
-    "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate",
+    "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
 ]
 
 
@@ -413,6 +413,14 @@ class Model:
 
 
 # ---- operator-level wrappers (parity tests) ----------------------------------------------------------
+def op_set_arith(arith):
+    """Arithmetic of op_conv1d / op_conv_transpose1d on this thread (ARITH_F32 | ARITH_BF16 | ARITH_F16)."""
+    f = lib().vits_op_set_arith
+    f.restype, f.argtypes = C.c_int32, [C.c_int32]
+    if f(arith) != 0:
+        raise VitsError(last_error())
+
+
 def op_conv1d(x, w, bias=None, dilation=1, pad_left=None, pre_slope=None, post_act=0, residual=None, accum=None,
               out_scale=1.0, lens=None):
     x, w = _f32(x), _f32(w)

@@ -421,7 +421,50 @@ int fail(const char* what) {
     set_err(what);
     return -1;
 }
+thread_local int g_op_arith = VITS_ARITH_F32;
+// one operator-level conv in the selected arithmetic: the fp32 MFMA kernel, or (16-bit modes) the converter + conv16 pair the
+// engine uses for fp32-layout tensors
+hipError_t run_op_conv(vits::PackedConv& pc, const vits::ConvCall& c, const float* w_torch, int k, DevBuf& w16, DevBuf& x16) {
+    using namespace vits;
+    if (g_op_arith == VITS_ARITH_F32) return launch_conv(pc, c, nullptr);
+    const std::vector<uint16_t> packed = pack_conv_weights16(w_torch, pc.cout, pc.cin, k, pc.epi, pc.ct_stride, g_op_arith);
+    if (!w16.put(nullptr, packed.size() / 2 + 1)) return hipErrorOutOfMemory;
+    if (hipMemcpy(w16.p, packed.data(), packed.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return hipErrorUnknown;
+    pc.wp16 = reinterpret_cast<uint16_t*>(w16.p);
+    Ref16 r;
+    r.ts = (c.t_in + 7) / 8 * 8;
+    r.bs = (int64_t)((pc.cin + 7) / 8) * r.ts * 8;
+    if (!x16.put(nullptr, (size_t)c.batch * r.bs / 2 + 1)) return hipErrorOutOfMemory;
+    r.p = reinterpret_cast<uint16_t*>(x16.p);
+    hipError_t e = launch_to_group16(c.x, c.len_in, c.batch, pc.cin, c.t_in, c.pre_act ? c.slope : 1.0f, r, g_op_arith, nullptr);
+    if (e != hipSuccess) return e;
+    Conv16Call q;
+    q.x = r;
+    q.len_in = c.len_in;
+    q.len_out = c.len_out;
+    q.batch = c.batch;
+    q.t_in = c.t_in;
+    q.t_out = c.t_out;
+    q.dil = c.dil;
+    q.pad_l = c.pad_l;
+    q.post_act = c.post_act;
+    q.post_slope = c.post_slope;
+    q.scale = c.scale;
+    q.scale_div = c.scale_div;
+    q.ct_crop = c.ct_crop;
+    q.y = c.y;
+    q.res = c.res;
+    q.acc = c.acc;
+    q.tile = c.tile;
+    return launch_conv16(pc, q, g_op_arith, nullptr);
+}
 }  // namespace
+
+VITS_API int vits_op_set_arith(int32_t arith) {
+    if (arith != VITS_ARITH_F32 && arith != VITS_ARITH_BF16 && arith != VITS_ARITH_F16) return fail("bad arithmetic mode");
+    g_op_arith = arith;
+    return 0;
+}
 
 VITS_API int vits_op_conv1d(const vits_conv1d_desc* d, const float* x, const float* w, const float* bias, const float* residual, const float* accum,
                             const int32_t* lens, float* y) {
@@ -460,7 +503,8 @@ VITS_API int vits_op_conv1d(const vits_conv1d_desc* d, const float* x, const flo
     c.slope = d->pre_slope;
     c.post_act = d->post_act == 1 ? 1 : 0;
     c.scale = d->out_scale;
-    hipError_t e = launch_conv(pc, c, nullptr);
+    DevBuf w16, x16;
+    hipError_t e = run_op_conv(pc, c, w, d->k, w16, x16);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(hipGetErrorString(e));
     if (hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
@@ -504,7 +548,8 @@ VITS_API int vits_op_conv_transpose1d(const vits_convt1d_desc* d, const float* x
     c.pre_act = d->pre_slope != 1.0f;
     c.slope = d->pre_slope;
     c.ct_crop = d->crop;
-    hipError_t e = launch_conv(pc, c, nullptr);
+    DevBuf w16, x16;
+    hipError_t e = run_op_conv(pc, c, w, d->k, w16, x16);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(hipGetErrorString(e));
     if (hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");

@@ -168,8 +168,11 @@ Engine::~Engine() {
     for (hipStream_t s : side_)
         if (s) hipStreamSynchronize(s);
     clear_taps();
-    if (!dry_run_)
+    if (!dry_run_) {
         for (void* p : owned_) hipFree(p);
+        for (PackSrc& ps : packs_)
+            if (ps.pc->wp16) hipFree(ps.pc->wp16);
+    }
     if (pinned_) hipHostFree(pinned_);
     for (HStage& hs : hstage_) {
         if (hs.p) hipHostFree(hs.p);
@@ -312,6 +315,7 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
     out.ct_stride = ct_stride;
     out.kt = epi == EPI_CONVT ? k / ct_stride : k;
     std::vector<float> packed = pack_conv_weights(w.data(), cout, cin, k, epi, ct_stride, &out.rows, &out.mtiles_used, &out.mtiles, &out.nchunks);
+    if (!dry_run_) packs_.push_back(PackSrc{&out, w, cout, cin, k, epi, ct_stride});
     out.wp = upload(packed);
     out.bias = bias.empty() ? nullptr : upload(bias);
     out.bytes = (int64_t)packed.size() * 4;
@@ -324,6 +328,7 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
 
 bool Engine::load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err) {
     const int H = hp.hidden;
+    d.pw.resize(hp.dds_layers);  // (sized first: set_arith keeps pointers to the PackedConv entries)
     for (int i = 0; i < hp.dds_layers; ++i) {
         const std::string si = std::to_string(i);
         float* p;
@@ -331,9 +336,7 @@ bool Engine::load_dds(const ModelFile& f, const std::string& base, DdsW& d, std:
         d.dw_w.push_back(p);
         if (!(p = upload_tensor(f, base + "convs_dilated." + si + ".bias", err, {H}))) return false;
         d.dw_b.push_back(p);
-        PackedConv pc;
-        if (!pack(f, base + "convs_pointwise." + si + ".weight", base + "convs_pointwise." + si + ".bias", EPI_STD, {H, H, 1}, pc, err)) return false;
-        d.pw.push_back(pc);
+        if (!pack(f, base + "convs_pointwise." + si + ".weight", base + "convs_pointwise." + si + ".bias", EPI_STD, {H, H, 1}, d.pw[i], err)) return false;
         if (!(p = upload_tensor(f, base + "norms_1." + si + ".weight", err, {H}))) return false;
         d.n1_g.push_back(p);
         if (!(p = upload_tensor(f, base + "norms_1." + si + ".bias", err, {H}))) return false;
@@ -428,6 +431,7 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             }
         }
         if (!pack(f, b + "attention.out_proj.weight", b + "attention.out_proj.bias", EPI_STD, {H, H, 1}, L.out, err)) return false;
+        if (!dry_run_) packs_.pop_back();  // a Linear (ggml_mul_mat on f32 x f32, vits.cpp:358), not a conv: no 16-bit operands in any mode
         if (!pack(f, b + "feed_forward.conv_1.weight", b + "feed_forward.conv_1.bias", EPI_STD, {hp.ffn_dim, H, hp.ffn_k}, L.ffn1, err)) return false;
         if (!pack(f, b + "feed_forward.conv_2.weight", b + "feed_forward.conv_2.bias", EPI_STD, {H, hp.ffn_dim, hp.ffn_k}, L.ffn2, err)) return false;
         if (!(L.rel_k = upload_tensor(f, b + "attention.emb_rel_k", err, {hd, nrel, 1}))) return false;  // shared by the heads (vits.cpp:323)
@@ -542,6 +546,8 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             h = (h + reach + ups_[i].k + ups_[i].stride - 1) / ups_[i].stride + 1;
         }
         halo_frames_ = h + dec_pre_.kt / 2 + 1;
+        vocoder_group_ok_ = (hp.flow_size % 8 == 0) && (hp.up_init % 8 == 0);
+        for (const UpStageW& U : ups_) vocoder_group_ok_ = vocoder_group_ok_ && (U.channels % 8 == 0);
     }
     if (!dry_run_ && hipDeviceSynchronize() != hipSuccess) {
         err = "device error while uploading weights";
@@ -558,8 +564,72 @@ bool Engine::validate(const uint8_t* bytes, size_t size, std::string& err) {
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
+// One 16-bit-operand convolution launch (conv16.hip), profiled like conv(): tile names carry a capital T
+hipError_t Engine::conv16(const char* name, const PackedConv& w, const Conv16Call& c, hipStream_t stream, double bytes) {
+    if (prof.on) {
+        const int ncols = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
+        const int tile = c.tile >= 0 ? c.tile : choose_conv16_tile(w.rows, w.epi, ncols, w.mtiles_used, c.batch);
+        const bool group = c.yg || c.y16.p;
+        char full[160];
+        std::snprintf(full, sizeof(full), "%s|k%d|d%d|T%d|e%d%s|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, group ? "g" : "", w.cin,
+                      w.cout);
+        const int64_t tot_in = c.sum_in >= 0 ? c.sum_in : (int64_t)c.batch * c.t_in;
+        const int64_t tot_out = c.sum_out >= 0 ? c.sum_out : (int64_t)c.batch * c.t_out;
+        const int64_t cols = w.epi == EPI_CONVT ? tot_in : tot_out;
+        prof.begin(full, 2.0 * (double)w.rows * (double)w.cin * (double)w.kt * (double)cols, bytes, stream, /*chain=*/true);
+    }
+    hipError_t e = launch_conv16(w, c, arith, stream);
+    prof.end(stream);
+    return e;
+}
+
+// A conv of the fp32-layout orchestration in a 16-bit arithmetic mode: (1) the input is rounded into the 16-bit group layout,
+// with the conv's input leaky_relu fused (the reference's leaky_relu node + fp16 im2col, vits.cpp:554 + custom-ops.h:684-690),
+// (2) the 16-bit-operand kernel writes the same fp32 outputs the fp32 kernel would. Used for stage one, the flow, and any
+// vocoder whose channel counts rule out the group-layout fast path.
+hipError_t Engine::conv16_transparent(const char* name, const PackedConv& w, const ConvCall& c, hipStream_t stream) {
+    int si = 0;
+    if (stream == side_[0]) si = 1;
+    else if (stream == side_[1]) si = 2;
+    Ref16 x16 = x16_[si];
+    const int groups = (w.cin + 7) / 8;
+    x16.ts = round_up(std::max(c.t_in, 1), 8);
+    x16.bs = (int64_t)groups * x16.ts * 8;
+    if (!x16.p || (size_t)c.batch * (size_t)x16.bs > x16_cap_[si]) return hipErrorOutOfMemory;
+    const int64_t tot_in = c.sum_in >= 0 ? c.sum_in : (int64_t)c.batch * c.t_in;
+    const int64_t tot_out = c.sum_out >= 0 ? c.sum_out : (int64_t)c.batch * c.t_out;
+    prof.begin("to_group16", 0, 6.0 * (double)w.cin * (double)tot_in, stream, true);
+    hipError_t e = launch_to_group16(c.x, c.len_in, c.batch, w.cin, c.t_in, c.pre_act ? c.slope : 1.0f, x16, arith, stream);
+    prof.end(stream);
+    if (e != hipSuccess) return e;
+    Conv16Call k;
+    k.x = x16;
+    k.len_in = c.len_in;
+    k.len_out = c.len_out;
+    k.batch = c.batch;
+    k.t_in = c.t_in;
+    k.t_out = c.t_out;
+    k.dil = c.dil;
+    k.pad_l = c.pad_l;
+    k.post_act = c.post_act;
+    k.post_slope = c.post_slope;
+    k.scale = c.scale;
+    k.scale_div = c.scale_div;
+    k.ct_crop = c.ct_crop;
+    k.y = c.y;
+    k.res = c.res;
+    k.acc = c.acc;
+    k.y2 = c.y2;
+    k.sum_in = c.sum_in;
+    k.sum_out = c.sum_out;
+    const int cout_stored = w.epi == EPI_GATE ? w.cout / 2 : w.cout;
+    const double bytes = 2.0 * (double)w.cin * tot_in + 4.0 * (double)cout_stored * tot_out * (1 + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0) + (c.y2 ? 1 : 0)) + (double)w.bytes16;
+    return conv16(name, w, k, stream, bytes);
+}
+
 hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on) {
     hipStream_t stream = on ? on : this->stream;
+    if (arith != VITS_ARITH_F32 && w.wp16) return conv16_transparent(name, w, c, stream);
     if (prof.on) {
         // name = label|k<taps>|d<dilation>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
         // bench can line entries up with rocprofv3's per-kernel-name statistics
@@ -596,7 +666,7 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
     TensorRef none;
     int dil = 1;
     for (int i = 0; i < hp.dds_layers; ++i) {
-        KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream));
+        KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream, arith));
         ConvCall c;
         c.x = y;
         c.y = p;
@@ -655,8 +725,18 @@ int64_t Engine::get_tap(const char* name, int utt, float* dst, size_t cap) {
 int Engine::set_arith(int a, std::string& err) {
     if (a == arith) return 0;
     if (a != VITS_ARITH_F32) {
-        err = "16-bit operand arithmetic is not available in this build";
-        return -1;
+        // pack every conv's weights as 16-bit A fragments of the requested type (rounded to nearest even; a no-op on the values
+        // when the file already stores that type, as the reference's exporter does for fp16: export_vits.py:87)
+        HIP_OK(hipStreamSynchronize(stream));
+        for (PackSrc& ps : packs_) {
+            const std::vector<uint16_t> packed = pack_conv_weights16(ps.w.data(), ps.cout, ps.cin, ps.k, ps.epi, ps.ct_stride, a);
+            uint16_t* d = nullptr;
+            HIP_OK(hipMalloc((void**)&d, packed.size() * sizeof(uint16_t)));
+            HIP_OK(hipMemcpy(d, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            if (ps.pc->wp16) hipFree(ps.pc->wp16);
+            ps.pc->wp16 = d;
+            ps.pc->bytes16 = (int64_t)packed.size() * 2;
+        }
     }
     arith = a;
     return 0;
@@ -711,7 +791,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     struct S1 {
         int *ids, *lens, *cum, *frames, *stage_lens, *stage_mul, *stage_add, *seed_off;
         float *x, *qkv, *att, *tmp, *ffn, *stats, *dpx, *dpy, *dpp, *cond, *z, *u, *dur;
+        uint16_t* x16;
     } s1;
+    size_t x16_elems1 = 0;
     const size_t hdr_ints = (size_t)B * id_stride + 2 * (size_t)B + 2 * (size_t)(n_up + 1);
     auto layout1 = [&](Arena& a) {
         // host-written header, one block = one H2D copy: ids | lens | stage_mul | stage_add | seed_off
@@ -736,6 +818,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         s1.cond = a.alloc<float>((size_t)B * H * ts);
         s1.z = a.alloc<float>((size_t)B * 2 * ts);
         s1.u = a.alloc<float>((size_t)B * 32 * ts);
+        // 16-bit arithmetic modes: scratch for the rounded copy of a conv input (largest c_in of stage one)
+        x16_elems1 = arith != VITS_ARITH_F32 ? (size_t)B * round_up(std::max({hp.ffn_dim, 2 * F, H}), 8) * round_up(ts, 8) : 0;
+        s1.x16 = x16_elems1 ? a.alloc<uint16_t>(x16_elems1) : nullptr;
     };
     {
         Arena measure;
@@ -746,6 +831,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         if (need > a1_.cap) HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(a1_.reserve(need));
         layout1(a1_);
+        for (int i = 0; i < 3; ++i) {
+            x16_[i] = Ref16();
+            x16_cap_[i] = 0;
+        }
+        x16_[0].p = s1.x16;
+        x16_cap_[0] = x16_elems1;
     }
     auto TR = [](float* p, int channels, int stride) {
         TensorRef t;
@@ -900,7 +991,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             const DpFlowW& W = dp_flows_[fl - 1];
             // conv_pre (1 -> H, vits.cpp:864) fused with "inputs + global_conditioning" of the DDS block (:651-653)
             prof.begin("dp_flow_pre", 0, 0, stream);
-            HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream));
+            HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream, arith));
             prof.end(stream);
             HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax, sum_t));
             HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
@@ -990,10 +1081,15 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     for (int i = 0; i <= n_up; ++i) sts[i] = round_up(Lw_max * smul[i] + sadd[i], 32);
     for (int i = 0; i < n_up; ++i) big = std::max(big, (size_t)B * ups_[i].channels * sts[i + 1]);
     struct S2 {
-        float *zp, *noise, *hout, *gate, *h0, *bu, *bul, *by[3], *bt[3], *byl[3], *bs, *pre, *wave;
+        float *zp, *noise, *hout, *gate, *h0, *bu, *bul, *by[3], *bt[3], *byl[3], *bs, *bs16, *pre, *wave;
+        uint16_t* x16[3];
         int* win_lens;  // [window][n_up + 2][B]: stage lengths of each utterance inside the window, then its emit end
     } s2;
     const bool need_noise_buf = o.noise_kind != VITS_NOISE_COUNTER;
+    // 16-bit arithmetic modes: the vocoder runs in the group layout of conv16.hip when its channel counts allow it (taps need the
+    // fp32 layout of the transparent path: collect_taps keeps to that one); scratch for the transparent path's rounded inputs
+    const bool fast16 = arith != VITS_ARITH_F32 && vocoder_group_ok_ && std::getenv("VITS_NO_GROUP16") == nullptr;
+    const size_t x16_elems2 = arith != VITS_ARITH_F32 ? std::max({big, (size_t)B * H * round_up(ls, 8), (size_t)B * hp.up_init * round_up(lws, 8), (size_t)B * round_up(F, 8) * round_up(ls, 8)}) + 64 : 0;
     const int S_stride = round_up(smax[n_up], 32);
     auto layout2 = [&](Arena& a) {
         s2.zp = a.alloc<float>((size_t)B * F * ls);
@@ -1012,6 +1108,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             s2.byl[j] = own ? a.alloc<float>(big) : s2.byl[0];
         }
         s2.bs = a.alloc<float>(big);
+        s2.bs16 = fast16 ? a.alloc<float>(big / 2 + 64) : nullptr;
+        for (int j = 0; j < 3; ++j) s2.x16[j] = (x16_elems2 && (j == 0 || (rb_streams_ > 1 && !fast16))) ? a.alloc<uint16_t>(x16_elems2) : nullptr;
         s2.pre = o.collect_taps ? a.alloc<float>((size_t)B * S_stride) : nullptr;
         s2.wave = a.alloc<float>((size_t)B * S_stride);
     };
@@ -1024,6 +1122,11 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         if (need > a2_.cap) HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(a2_.reserve(need));
         layout2(a2_);
+        for (int j = 0; j < 3; ++j) {
+            x16_[j] = Ref16();
+            x16_[j].p = s2.x16[j];
+            x16_cap_[j] = s2.x16[j] ? x16_elems2 : 0;
+        }
     }
     const int* d_len_full[8];
     for (int i = 0; i <= n_up && i < 8; ++i) d_len_full[i] = s1.stage_lens + (size_t)i * B;
@@ -1189,124 +1292,6 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         const int emit_lo = (wn.f0 - wn.lo) * M;
         TensorRef zwin = zp;
         zwin.p += wn.lo;
-        TensorRef h0 = TR(s2.h0, hp.up_init, lws);
-        {
-            ConvCall c;
-            c.x = zwin;
-            c.y = h0;
-            c.len_in = d_len[0];
-            c.len_out = d_len[0];
-            c.batch = B;
-            c.t_in = c.t_out = Lw;
-            c.sum_in = c.sum_out = ssum[0];
-            c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
-            c.post_act = 2;  // its only reader is the first upsampler, which takes leaky_relu(h0) (vits.cpp:613): activate at the writer
-            c.post_slope = hp.lrelu;
-            HIP_OK(conv("hifigan_conv_pre", dec_pre_, c));
-        }
-        TensorRef cur = h0;
-        const size_t nk = hp.rb_k.size();
-        for (int i = 0; i < n_up; ++i) {
-            const UpStageW& U = ups_[i];
-            const int C = U.channels, st_in = i, st_out = i + 1;
-            TensorRef bu = TR(s2.bu, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
-            {
-                ConvCall c;
-                c.x = cur;
-                c.y = bu;
-                c.len_in = d_len[st_in];
-                c.len_out = d_len[st_out];
-                c.batch = B;
-                c.t_in = smax[st_in];
-                c.t_out = smax[st_out];
-                c.sum_in = ssum[st_in];
-                c.sum_out = ssum[st_out];
-                c.pre_act = 0;  // leaky_relu before the upsampler (vits.cpp:613) was applied by whoever wrote `cur`
-                c.slope = hp.lrelu;
-                c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
-                if (C >= lrelu_copy_minc_) {  // activated copy for the first conv of each resblock (see below)
-                    c.y2 = s2.bul;
-                    c.post_slope = hp.lrelu;
-                }
-                HIP_OK(conv("hifigan_upsample_convT", U.up, c));
-            }
-            // resblock j runs on its own stream (engine.h); only the LAST convolution of each resblock touches the shared
-            // sum, and those are chained j-1 -> j by events so the additions keep the reference's order (vits.cpp:622-635)
-            // (per-kernel event timing needs kernels that do not overlap: the profiler serialises the stage)
-            const bool par = rb_streams_ > 1 && nk >= 2 && nk <= 3 && !prof.on;
-            if (par) {
-                HIP_OK(hipEventRecord(ev_fork_, stream));
-                for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
-            }
-            for (size_t j = 0; j < nk; ++j) {
-                const ResBlockW& R = U.rbs[j];
-                const size_t nd = R.dil.size();
-                hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
-                TensorRef by = TR(s2.by[par ? j : 0], C, sts[st_out]), bt = TR(s2.bt[par ? j : 0], C, sts[st_out]);
-                // LeakyReLU is applied where a tensor is WRITTEN, not where it is read: the first conv of a pair stores
-                // leaky_relu(t) (t has no other reader), and for wide stages the second conv stores leaky_relu(y) beside y
-                // (y itself stays the residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the
-                // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
-                const bool lcopy = C >= lrelu_copy_minc_;
-                TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]), bul = TR(s2.bul, C, sts[st_out]);
-                for (size_t d = 0; d < nd; ++d) {
-                    TensorRef resid = d == 0 ? bu : by;
-                    ConvCall c1;
-                    c1.x = lcopy ? (d > 0 ? byl : bul) : resid;
-                    c1.y = bt;
-                    c1.len_in = c1.len_out = d_len[st_out];
-                    c1.batch = B;
-                    c1.t_in = c1.t_out = smax[st_out];
-                    c1.sum_in = c1.sum_out = ssum[st_out];
-                    c1.dil = R.dil[d];
-                    c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
-                    c1.pre_act = lcopy ? 0 : 1;
-                    c1.slope = hp.lrelu;
-                    c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
-                    c1.post_slope = hp.lrelu;
-                    HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1, sj));
-                    ConvCall c2 = c1;
-                    c2.x = bt;
-                    c2.pre_act = 0;
-                    c2.post_act = 0;
-                    c2.y2 = (d + 1 < nd && lcopy) ? byl.p : nullptr;
-                    c2.dil = 1;
-                    c2.pad_l = (R.k - 1) / 2;
-                    c2.res = resid;  // residual add (vits.cpp:578)
-                    if (d + 1 < nd) c2.y = by;
-                    else {
-                        // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)
-                        c2.y = bsum;
-                        if (j > 0) c2.acc = bsum;
-                        if (j + 1 == nk) {
-                            if (refmode) {
-                                c2.scale = (float)(1.0 / (double)nk);  // ggml_scale by float(1/num_kernels) (vits.cpp:607)
-                                c2.scale_div = 0;
-                            } else {
-                                c2.scale = (float)nk;  // HF divides (modeling_vits.py:546)
-                                c2.scale_div = 1;
-                            }
-                        } else {
-                            c2.scale = 1.f;
-                        }
-                        // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
-                        // scale 1/1 is the identity, so no special case is needed)
-                        if (j + 1 == nk && i + 1 < n_up) {
-                            // the stage output feeds only the next upsampler, which wants leaky_relu of it (vits.cpp:613);
-                            // the last stage stays raw: conv_post applies its own slope (Q2)
-                            c2.post_act = 2;
-                            c2.post_slope = hp.lrelu;
-                        }
-                    }
-                    const bool last = d + 1 == nd;
-                    if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
-                    HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2, sj));
-                    if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
-                }
-            }
-            if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
-            cur = bsum;
-        }
         TensorRef pre;
         pre.p = s2.pre;
         pre.bs = S_stride;
@@ -1315,9 +1300,260 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         wv.p = wave_dst + (int64_t)wn.lo * M;  // window-local sample 0 is global sample lo * M
         wv.bs = wave_stride;
         wv.cs = (int)wave_stride;
-        prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 4.0 * (dec_post_cin_ + 1) * (double)ssum[n_up], stream);
-        HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, refmode ? hp.lrelu : 0.01f, pre, wv, d_len[n_up], B, smax[n_up], stream, emit_lo, emit_hi));  // Q2
-        prof.end(stream);
+        const float final_slope = refmode ? hp.lrelu : 0.01f;  // Q2 (vits.cpp:638)
+        if (fast16) {
+            // ---- 16-bit-operand vocoder in the group layout of conv16.hip -----------------------------------------------
+            // Every conv input is a 16-bit tensor WRITTEN by its producer (leaky_relu and rounding fused into the writer's
+            // epilogue: what the reference's leaky_relu node + fp16 im2col compute, vits.cpp:554,567,613 + custom-ops.h:684-690);
+            // the residual stream (vits.cpp:578) and the resblock sum (:622-635) stay fp32, in the same [c/8][t][8] layout.
+            auto R16 = [](float* base, int channels, int stride) {
+                Ref16 r;
+                r.p = reinterpret_cast<uint16_t*>(base);
+                r.ts = stride;
+                r.bs = (int64_t)channels * stride;
+                return r;
+            };
+            const size_t nk = hp.rb_k.size();
+            Ref16 z16 = x16_[0];
+            z16.ts = round_up(Lw, 8);
+            z16.bs = (int64_t)(F / 8) * z16.ts * 8;
+            prof.begin("to_group16", 0, 6.0 * F * (double)ssum[0], stream, true);
+            HIP_OK(launch_to_group16(zwin, d_len[0], B, F, Lw, 1.0f, z16, arith, stream));
+            prof.end(stream);
+            Ref16 cur16 = R16(s2.h0, hp.up_init, lws);
+            {
+                Conv16Call c;
+                c.x = z16;
+                c.len_in = c.len_out = d_len[0];
+                c.batch = B;
+                c.t_in = c.t_out = Lw;
+                c.sum_in = c.sum_out = ssum[0];
+                c.pad_l = (dec_pre_.kt - 1) / 2;
+                c.y16 = cur16;
+                c.y16_slope = hp.lrelu;  // only reader: the first upsampler, behind its leaky_relu (vits.cpp:613)
+                HIP_OK(conv16("hifigan_conv_pre", dec_pre_, c, stream, 2.0 * (F + hp.up_init) * (double)ssum[0] + (double)dec_pre_.bytes16));
+            }
+            for (int i = 0; i < n_up; ++i) {
+                const UpStageW& U = ups_[i];
+                const int C = U.channels, st_in = i, st_out = i + 1;
+                const int64_t g_bs = (int64_t)C * sts[st_out];
+                const int g_ts = sts[st_out];
+                const double n_out = (double)C * (double)ssum[st_out];
+                const Ref16 bul16 = R16(s2.bul, C, sts[st_out]), bsum16 = R16(s2.bs16, C, sts[st_out]);
+                {
+                    Conv16Call c;
+                    c.x = cur16;
+                    c.len_in = d_len[st_in];
+                    c.len_out = d_len[st_out];
+                    c.batch = B;
+                    c.t_in = smax[st_in];
+                    c.t_out = smax[st_out];
+                    c.sum_in = ssum[st_in];
+                    c.sum_out = ssum[st_out];
+                    c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1
+                    c.yg = s2.bu;
+                    c.g_bs = g_bs;
+                    c.g_ts = g_ts;
+                    c.y16 = bul16;
+                    c.y16_slope = hp.lrelu;
+                    HIP_OK(conv16("hifigan_upsample_convT", U.up, c, stream, 2.0 * U.up.cin * (double)ssum[st_in] + 6.0 * n_out + (double)U.up.bytes16));
+                }
+                const bool par = rb_streams_ > 1 && nk >= 2 && nk <= 3 && !prof.on;
+                if (par) {
+                    HIP_OK(hipEventRecord(ev_fork_, stream));
+                    for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
+                }
+                for (size_t j = 0; j < nk; ++j) {
+                    const ResBlockW& R = U.rbs[j];
+                    const size_t nd = R.dil.size();
+                    hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
+                    const int q = par ? (int)j : 0;
+                    const Ref16 byl16 = R16(s2.byl[q], C, sts[st_out]), bt16 = R16(s2.bt[q], C, sts[st_out]);
+                    for (size_t d = 0; d < nd; ++d) {
+                        Conv16Call c1;
+                        c1.x = d == 0 ? bul16 : byl16;
+                        c1.len_in = c1.len_out = d_len[st_out];
+                        c1.batch = B;
+                        c1.t_in = c1.t_out = smax[st_out];
+                        c1.sum_in = c1.sum_out = ssum[st_out];
+                        c1.dil = R.dil[d];
+                        c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;
+                        c1.y16 = bt16;  // t = leaky_relu(conv1(...)), rounded: what the second conv consumes (vits.cpp:556-567)
+                        c1.y16_slope = hp.lrelu;
+                        HIP_OK(conv16("hifigan_resblock_conv", R.c1[d], c1, sj, 4.0 * n_out + (double)R.c1[d].bytes16));
+                        Conv16Call c2 = c1;
+                        c2.x = bt16;
+                        c2.dil = 1;
+                        c2.pad_l = (R.k - 1) / 2;
+                        c2.g_bs = g_bs;
+                        c2.g_ts = g_ts;
+                        c2.resg = d == 0 ? s2.bu : s2.by[q];  // residual add (vits.cpp:578), fp32
+                        c2.y16 = Ref16();
+                        c2.y16_slope = 1.f;
+                        double bytes2 = 2.0 * n_out + 4.0 * n_out + 4.0 * n_out + (double)R.c2[d].bytes16;
+                        if (d + 1 < nd) {
+                            c2.yg = s2.by[q];
+                            c2.y16 = byl16;  // next pair's input
+                            c2.y16_slope = hp.lrelu;
+                            bytes2 += 2.0 * n_out;
+                        } else {
+                            c2.yg = s2.bs;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635)
+                            if (j > 0) {
+                                c2.accg = s2.bs;
+                                bytes2 += 4.0 * n_out;
+                            }
+                            if (j + 1 == nk) {
+                                if (refmode) {
+                                    c2.scale = (float)(1.0 / (double)nk);
+                                    c2.scale_div = 0;
+                                } else {
+                                    c2.scale = (float)nk;
+                                    c2.scale_div = 1;
+                                }
+                                // the stage output is read by the next upsampler (behind leaky_relu, vits.cpp:613) or by conv_post
+                                // (behind the final leaky_relu, Q2): its 16-bit copy carries that activation
+                                c2.y16 = bsum16;
+                                c2.y16_slope = i + 1 < n_up ? hp.lrelu : final_slope;
+                                bytes2 += 2.0 * n_out;
+                            } else {
+                                c2.scale = 1.f;
+                            }
+                        }
+                        const bool last = d + 1 == nd;
+                        if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                        HIP_OK(conv16("hifigan_resblock_conv", R.c2[d], c2, sj, bytes2));
+                        if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
+                    }
+                }
+                if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
+                cur16 = bsum16;
+            }
+            prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 2.0 * (dec_post_cin_ + 2) * (double)ssum[n_up], stream);
+            HIP_OK(launch_conv_post16(cur16, dec_post_w_, dec_post_cin_, dec_post_k_, pre, wv, d_len[n_up], B, smax[n_up], arith, stream, emit_lo, emit_hi));
+            prof.end(stream);
+        } else {
+            TensorRef h0 = TR(s2.h0, hp.up_init, lws);
+            {
+                ConvCall c;
+                c.x = zwin;
+                c.y = h0;
+                c.len_in = d_len[0];
+                c.len_out = d_len[0];
+                c.batch = B;
+                c.t_in = c.t_out = Lw;
+                c.sum_in = c.sum_out = ssum[0];
+                c.pad_l = (dec_pre_.kt - 1) / 2;  // padding 3 (vits.cpp:601)
+                c.post_act = 2;  // its only reader is the first upsampler, which takes leaky_relu(h0) (vits.cpp:613): activate at the writer
+                c.post_slope = hp.lrelu;
+                HIP_OK(conv("hifigan_conv_pre", dec_pre_, c));
+            }
+            TensorRef cur = h0;
+            const size_t nk = hp.rb_k.size();
+            for (int i = 0; i < n_up; ++i) {
+                const UpStageW& U = ups_[i];
+                const int C = U.channels, st_in = i, st_out = i + 1;
+                TensorRef bu = TR(s2.bu, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
+                {
+                    ConvCall c;
+                    c.x = cur;
+                    c.y = bu;
+                    c.len_in = d_len[st_in];
+                    c.len_out = d_len[st_out];
+                    c.batch = B;
+                    c.t_in = smax[st_in];
+                    c.t_out = smax[st_out];
+                    c.sum_in = ssum[st_in];
+                    c.sum_out = ssum[st_out];
+                    c.pre_act = 0;  // leaky_relu before the upsampler (vits.cpp:613) was applied by whoever wrote `cur`
+                    c.slope = hp.lrelu;
+                    c.ct_crop = refmode ? 0 : (U.k - U.stride) / 2;  // Q1 (vits.cpp:187) / HF padding
+                    if (C >= lrelu_copy_minc_) {  // activated copy for the first conv of each resblock (see below)
+                        c.y2 = s2.bul;
+                        c.post_slope = hp.lrelu;
+                    }
+                    HIP_OK(conv("hifigan_upsample_convT", U.up, c));
+                }
+                // resblock j runs on its own stream (engine.h); only the LAST convolution of each resblock touches the shared
+                // sum, and those are chained j-1 -> j by events so the additions keep the reference's order (vits.cpp:622-635)
+                // (per-kernel event timing needs kernels that do not overlap: the profiler serialises the stage)
+                const bool par = rb_streams_ > 1 && nk >= 2 && nk <= 3 && !prof.on;
+                if (par) {
+                    HIP_OK(hipEventRecord(ev_fork_, stream));
+                    for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
+                }
+                for (size_t j = 0; j < nk; ++j) {
+                    const ResBlockW& R = U.rbs[j];
+                    const size_t nd = R.dil.size();
+                    hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
+                    TensorRef by = TR(s2.by[par ? j : 0], C, sts[st_out]), bt = TR(s2.bt[par ? j : 0], C, sts[st_out]);
+                    // LeakyReLU is applied where a tensor is WRITTEN, not where it is read: the first conv of a pair stores
+                    // leaky_relu(t) (t has no other reader), and for wide stages the second conv stores leaky_relu(y) beside y
+                    // (y itself stays the residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the
+                    // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
+                    const bool lcopy = C >= lrelu_copy_minc_;
+                    TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]), bul = TR(s2.bul, C, sts[st_out]);
+                    for (size_t d = 0; d < nd; ++d) {
+                        TensorRef resid = d == 0 ? bu : by;
+                        ConvCall c1;
+                        c1.x = lcopy ? (d > 0 ? byl : bul) : resid;
+                        c1.y = bt;
+                        c1.len_in = c1.len_out = d_len[st_out];
+                        c1.batch = B;
+                        c1.t_in = c1.t_out = smax[st_out];
+                        c1.sum_in = c1.sum_out = ssum[st_out];
+                        c1.dil = R.dil[d];
+                        c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
+                        c1.pre_act = lcopy ? 0 : 1;
+                        c1.slope = hp.lrelu;
+                        c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
+                        c1.post_slope = hp.lrelu;
+                        HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1, sj));
+                        ConvCall c2 = c1;
+                        c2.x = bt;
+                        c2.pre_act = 0;
+                        c2.post_act = 0;
+                        c2.y2 = (d + 1 < nd && lcopy) ? byl.p : nullptr;
+                        c2.dil = 1;
+                        c2.pad_l = (R.k - 1) / 2;
+                        c2.res = resid;  // residual add (vits.cpp:578)
+                        if (d + 1 < nd) c2.y = by;
+                        else {
+                            // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)
+                            c2.y = bsum;
+                            if (j > 0) c2.acc = bsum;
+                            if (j + 1 == nk) {
+                                if (refmode) {
+                                    c2.scale = (float)(1.0 / (double)nk);  // ggml_scale by float(1/num_kernels) (vits.cpp:607)
+                                    c2.scale_div = 0;
+                                } else {
+                                    c2.scale = (float)nk;  // HF divides (modeling_vits.py:546)
+                                    c2.scale_div = 1;
+                                }
+                            } else {
+                                c2.scale = 1.f;
+                            }
+                            // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
+                            // scale 1/1 is the identity, so no special case is needed)
+                            if (j + 1 == nk && i + 1 < n_up) {
+                                // the stage output feeds only the next upsampler, which wants leaky_relu of it (vits.cpp:613);
+                                // the last stage stays raw: conv_post applies its own slope (Q2)
+                                c2.post_act = 2;
+                                c2.post_slope = hp.lrelu;
+                            }
+                        }
+                        const bool last = d + 1 == nd;
+                        if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                        HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2, sj));
+                        if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
+                    }
+                }
+                if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
+                cur = bsum;
+            }
+            prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 4.0 * (dec_post_cin_ + 1) * (double)ssum[n_up], stream);
+            HIP_OK(launch_conv_post(cur, dec_post_w_, dec_post_cin_, dec_post_k_, final_slope, pre, wv, d_len[n_up], B, smax[n_up], stream, emit_lo, emit_hi, arith));
+            prof.end(stream);
+        }
         if (o.on_chunk) {
             // ship this window's samples to the host behind the kernels, then serve the PREVIOUS window's callbacks while
             // the device works on this one

@@ -140,6 +140,19 @@ class Engine {
     std::vector<UpStageW> ups_;
     float* dec_post_w_ = nullptr;
     int dec_post_cin_ = 0, dec_post_k_ = 0;
+    // host copies of every Conv1d / ConvTranspose1d weight (torch layout, after the flip / negation folds), kept so that
+    // set_arith can pack the 16-bit A fragments on demand. Linear layers (q/k/v/out) are not listed: they stay fp32 (Q7).
+    struct PackSrc {
+        PackedConv* pc;
+        std::vector<float> w;
+        int cout, cin, k, epi, ct_stride;
+    };
+    std::vector<PackSrc> packs_;
+    Ref16 x16_[3];           // per-stream scratch for the 16-bit copy of a conv input (transparent 16-bit path)
+    size_t x16_cap_[3] = {0, 0, 0};
+    bool vocoder_group_ok_ = false;  // every vocoder channel count is a multiple of 8: group-layout fast path available
+    hipError_t conv16_transparent(const char* name, const PackedConv& w, const ConvCall& c, hipStream_t stream);
+    hipError_t conv16(const char* name, const PackedConv& w, const Conv16Call& c, hipStream_t stream, double bytes);
     std::vector<void*> owned_;  // every device allocation made at load
     bool dry_run_ = false;
 

@@ -35,6 +35,15 @@ struct PackedConv {
     int epi = EPI_STD;
     int ct_stride = 0;  // EPI_CONVT: upsampling stride s
     int64_t bytes = 0;
+    uint16_t* wp16 = nullptr;  // 16-bit A fragments of the VITS_ARITH_F16 / BF16 path (packed by Engine::set_arith)
+    int64_t bytes16 = 0;
+};
+
+// 16-bit activation in "group layout" [batch][channel/8][time][8] (conv16.hip): one 16-byte slot = 8 channels of one time step
+struct Ref16 {
+    uint16_t* p = nullptr;
+    int64_t bs = 0;  // batch stride (16-bit elements)
+    int32_t ts = 0;  // slots per group row (time stride)
 };
 
 struct ConvCall {
@@ -65,6 +74,38 @@ int choose_conv_tile(int rows, int epi, int t_hint);
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s);
 double conv_flops(const PackedConv& w, const ConvCall& c, int64_t total_cols);
 
+// ---- 16-bit-operand convolution (conv16.hip): v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate --------------------
+struct Conv16Call {
+    Ref16 x;  // input, group layout (already activated: the writer / converter applies the leaky_relu)
+    const int* len_in = nullptr;
+    const int* len_out = nullptr;
+    int batch = 1, t_in = 0, t_out = 0, dil = 1, pad_l = 0;
+    int post_act = 0;  // standard outputs: 1 relu, 2 leaky_relu(post_slope) of the stored value; group outputs: 1 relu
+    float post_slope = 0.f;
+    float scale = 1.f;
+    int scale_div = 0;
+    int ct_crop = 0;
+    int tile = -1;
+    // standard-layout fp32 outputs / inputs ([b][c][t]): used when neither yg nor y16 is set
+    TensorRef y, res, acc;
+    float* y2 = nullptr;
+    // group-layout outputs: fp32 residual stream [b][c/8][g_ts][8] (yg / resg / accg share strides) and the 16-bit copy
+    float* yg = nullptr;
+    const float* resg = nullptr;
+    const float* accg = nullptr;
+    int64_t g_bs = 0;
+    int g_ts = 0;
+    Ref16 y16;
+    float y16_slope = 1.f;  // leaky_relu fused into the 16-bit copy (1 = none)
+    int64_t sum_in = -1, sum_out = -1;  // profiler accounting (see ConvCall)
+};
+std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);
+int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch);
+hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
+hipError_t launch_to_group16(TensorRef x, const int* lens, int batch, int channels, int tmax, float slope, Ref16 y, int arith, hipStream_t s);
+hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef pre, TensorRef wave, const int* lens, int batch, int tmax, int arith, hipStream_t s,
+                              int emit_lo = 0, const int* emit_hi = nullptr);
+
 // ---- small kernels ------------------------------------------------------------------------------------
 hipError_t launch_embed(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, TensorRef x, int batch, int tmax,
                         hipStream_t s);
@@ -74,9 +115,9 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
 hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
                                  int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s);
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
-                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s);
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith = 0);
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch,
-                                  int channels, int tmax, hipStream_t s);
+                                  int channels, int tmax, hipStream_t s, int arith = 0);
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode,
                          hipStream_t s);
 hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
@@ -91,6 +132,6 @@ hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int t
 // fp32 -> int16 PCM rows on the device (test/main.cpp:31-33); lens (device, optional) limits each row
 hipError_t launch_pcm16(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride, const int64_t* lens, int rows, int64_t cols, hipStream_t s);
 hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch,
-                            int tmax, hipStream_t s, int emit_lo = 0, const int* emit_hi = nullptr);
+                            int tmax, hipStream_t s, int emit_lo = 0, const int* emit_hi = nullptr, int arith = 0);
 
 }  // namespace vits

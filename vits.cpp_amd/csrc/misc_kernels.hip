@@ -250,9 +250,17 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
 //   (vits.cpp:651-653 happens once before the layer loop; the engine passes g only for layer 0).
 // Block = 64 time steps x all channels, input tile with halo in LDS.
 // ---------------------------------------------------------------------------------------------------------
+// Q7 (custom-ops.h:684-690): in the 16-bit arithmetic modes every conv operand is rounded (nearest even) to fp16 / bf16; the
+// products are then exact in fp32. arith: 0 fp32, 1 bf16, 2 fp16 (VITS_ARITH_*).
+__device__ __forceinline__ float round_arith(float v, int arith) {
+    if (arith == 2) return (float)(_Float16)v;
+    if (arith == 1) return (float)(__bf16)v;
+    return v;
+}
+
 __global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x, int64_t x_bs, int x_cs, const float* g, int64_t g_bs, int g_cs, const float* w,
                                                             const float* bias, const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs,
-                                                            const int* lens, int channels, int tmax, int k, int dil, float eps) {
+                                                            const int* lens, int channels, int tmax, int k, int dil, float eps, int arith) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int pad = (k * dil - dil) / 2;  // vits.cpp:660
     const int xw = 64 + 2 * pad;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x,
     float s = 0.f;
     for (int c = gq; c < channels; c += LN_GROUPS) {
         float a = bias[c];
-        for (int j = 0; j < k; ++j) a += w[c * k + j] * xt[c * xw + tl + j * dil];
+        for (int j = 0; j < k; ++j) a += round_arith(w[c * k + j], arith) * round_arith(xt[c * xw + tl + j * dil], arith);
         ht[c * 64 + tl] = a;
         s += a;
     }
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x,
 }
 
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
-                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s) {
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith) {
     const int pad = (k * dil - dil) / 2;
     const size_t lds = sizeof(float) * ((size_t)channels * (64 + 2 * pad) + (size_t)channels * 64 + 2 * 64 * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -325,25 +333,25 @@ hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const 
     }
     dim3 grid((tmax + 63) / 64, batch);
     hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
-                       k, dil, eps);
+                       k, dil, eps, arith);
     return hipGetLastError();
 }
 
 // conv_pre of a conv flow: 1 -> channels pointwise conv of latent row zc (vits.cpp:864): y[c][t] = w[c]*z[zc][t] + b[c]
 //   optionally + cond[c][t]: the DDS block's "inputs + global_conditioning" (vits.cpp:651-653), same order of additions
 __global__ void pointwise_from1_kernel(const float* z, int64_t z_bs, int z_cs, int zc, const float* w, const float* bias, const float* cond, int64_t c_bs,
-                                       int c_cs, float* y, int64_t y_bs, int y_cs, const int* lens, int tmax) {
+                                       int c_cs, float* y, int64_t y_bs, int y_cs, const int* lens, int tmax, int arith) {
     const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     const int len = lens ? lens[b] : tmax;
     if (t >= len) return;
-    float v = w[c] * z[(int64_t)b * z_bs + (int64_t)zc * z_cs + t] + bias[c];
+    float v = round_arith(w[c], arith) * round_arith(z[(int64_t)b * z_bs + (int64_t)zc * z_cs + t], arith) + bias[c];
     if (cond) v = v + cond[(int64_t)b * c_bs + (int64_t)c * c_cs + t];
     y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = v;
 }
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch, int channels,
-                                  int tmax, hipStream_t s) {
+                                  int tmax, hipStream_t s, int arith) {
     dim3 grid((tmax + 63) / 64, channels, batch);
-    hipLaunchKernelGGL(pointwise_from1_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, zc, w, bias, cond.p, cond.bs, cond.cs, y.p, y.bs, y.cs, lens, tmax);
+    hipLaunchKernelGGL(pointwise_from1_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, zc, w, bias, cond.p, cond.bs, cond.cs, y.p, y.bs, y.cs, lens, tmax, arith);
     return hipGetLastError();
 }
 
@@ -625,7 +633,7 @@ hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_s
 // tile would be 31/32 empty, so this is a VALU kernel; HBM-bound (reads C floats per output sample).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t x_bs, int x_cs, const float* w, int cin, int k, float slope, float* pre,
-                                                        int64_t p_bs, float* wave, int64_t w_bs, const int* lens, int tmax, int emit_lo, const int* emit_hi) {
+                                                        int64_t p_bs, float* wave, int64_t w_bs, const int* lens, int tmax, int emit_lo, const int* emit_hi, int arith) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [cin][k]
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : tmax;
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
     const int hi = emit_hi ? min(emit_hi[b], len) : len;
     const int t0 = emit_lo + blockIdx.x * 1024;
     if (t0 >= hi) return;
-    for (int i = threadIdx.x; i < cin * k; i += 256) sm[i] = w[i];
+    for (int i = threadIdx.x; i < cin * k; i += 256) sm[i] = round_arith(w[i], arith);
     __syncthreads();
     const int pad = (k - 1) / 2;
     const float* xb = x + (int64_t)b * x_bs;
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
                 const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
                 float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};  // v[i] = x[t - 4 + i]
 #pragma unroll
-                for (int i = 1; i < 11; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+                for (int i = 1; i < 11; ++i) v[i] = round_arith(v[i] > 0.f ? v[i] : v[i] * slope, arith);
                 const float* wc = sm + c * 7;
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {  // sample t + e reads x[t + e + j - 3] = v[e + j + 1]
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
                 for (int j = 0; j < k; ++j) {
                     const int tt = te + j - pad;
                     float v = (tt >= 0 && tt < len) ? xr[tt] : 0.f;
-                    v = v > 0.f ? v : v * slope;
+                    v = round_arith(v > 0.f ? v : v * slope, arith);
                     a += sm[c * k + j] * v;
                 }
             }
@@ -695,7 +703,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
             for (int j = 0; j < k; ++j) {
                 const int tt = t + j - pad;
                 float v = (tt >= 0 && tt < len) ? xr[tt] : 0.f;
-                v = v > 0.f ? v : v * slope;
+                v = round_arith(v > 0.f ? v : v * slope, arith);
                 a += sm[c * k + j] * v;
             }
         }
@@ -705,10 +713,10 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
 }
 
 hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch, int tmax,
-                            hipStream_t s, int emit_lo, const int* emit_hi) {
+                            hipStream_t s, int emit_lo, const int* emit_hi, int arith) {
     dim3 grid((std::max(tmax - emit_lo, 1) + 1023) / 1024, batch);
     hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * cin * k, s, x.p, x.bs, x.cs, w, cin, k, slope, pre_tanh.p, pre_tanh.bs, wave.p, wave.bs,
-                       lens, tmax, emit_lo, emit_hi);
+                       lens, tmax, emit_lo, emit_hi, arith);
     return hipGetLastError();
 }
 
