@@ -238,3 +238,21 @@ def test_bf16_storage_extension_round_trips(pkg, oracle):
     ea, _ = ma.tensor("text_encoder.embed_tokens.weight")
     eb, _ = mb.tensor("text_encoder.embed_tokens.weight")
     np.testing.assert_array_equal(ea, eb)  # fp32 tensors untouched
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """The reference's Debug configuration is an AddressSanitizer build (/root/reference/CMakeLists.txt:9-13). The GPU pool has no
+    device-side sanitizer, so the CPU restatement gets it: `make -C oracle asan` builds the oracle + a driver with
+    -fsanitize=address,undefined, and the driver runs the tiny exporter-written model through every mode / arithmetic / short
+    input, the reference noise stream, a truncated file and the index -1 wrap of Q4 (an out-of-bounds write in the reference,
+    ggml-util.h:235 — the restatement must model its effect without one)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(root, "oracle", "_asan", "asan_driver"), os.path.join(root, "tests", "golden", "tiny_hf_export.ggml")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "asan driver ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

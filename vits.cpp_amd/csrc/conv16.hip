@@ -316,49 +316,63 @@ __global__ __launch_bounds__(320) void conv16_kernel(const Conv16Params p) {
         const float* rg = p.resg ? p.resg + (int64_t)b * p.g_bs : nullptr;
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
+        // The residual of group it + 2 is fetched BEFORE group it is stored (a ring of three): the residual may alias the output
+        // (in-place update of the stream), so the compiler cannot hoist a later group's loads above an earlier group's stores by
+        // itself, and every group would otherwise be one load -> wait -> store round trip to HBM (measured: that, not HBM bandwidth,
+        // bounded the C >= 128 layers). The accumulator of the resblock sum (2 of 18 convs per stage) is read in place.
+        constexpr int NG = MR * 4;
+        float4v rv[3][NR];
+        auto load_res = [&](int it, float4v* dst) __attribute__((always_inline)) {
+            const int ch0 = (mt0 + it / 4) * 32 + 8 * (it & 3) + rowoff;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = colbase + nr * 32;
+                dst[nr] = float4v{0.f, 0.f, 0.f, 0.f};
+                if (rg && ch0 < p.cout && t < ncols) dst[nr] = *reinterpret_cast<const float4v*>(rg + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+            }
+        };
+        load_res(0, rv[0]);
+        if (NG > 1) load_res(1, rv[1]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = (mt0 + mr) * 32 + 8 * g + rowoff;
-                if (ch0 >= p.cout) continue;
-                float4v bias = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bias = *reinterpret_cast<const float4v*>(p.bias + ch0);
+        for (int it = 0; it < NG; ++it) {
+            const int mr = it / 4, g = it & 3;
+            if (it + 2 < NG) load_res(it + 2, rv[(it + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ch0 = (mt0 + mr) * 32 + 8 * g + rowoff;
+            if (ch0 >= p.cout) continue;
+            float4v bias = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias = *reinterpret_cast<const float4v*>(p.bias + ch0);
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    const int t = colbase + nr * 32;
-                    if (t >= ncols) continue;
-                    const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
-                    float v[4];
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = colbase + nr * 32;
+                if (t >= ncols) continue;
+                const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[mr][nr][4 * g + e] + bias[e];
+                    if (p.post_act == 1) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if (rg) v[e] = rv[it % 3][nr][e] + v[e];
+                }
+                if (ag) {
+                    const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mr][nr][4 * g + e] + bias[e];
-                        if (p.post_act == 1) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                    }
-                    if (rg) {
-                        const float4v r4 = *reinterpret_cast<const float4v*>(rg + go);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = r4[e] + v[e];
-                    }
-                    if (ag) {
-                        const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = a4[e] + v[e];
-                            v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
-                        }
-                    }
-                    if (yg) *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
-                    if (y16) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);  // slope 1 = identity
-                        int2v w2;
-                        w2.x = (int)pack16<BF>(v[0], v[1]);
-                        w2.y = (int)pack16<BF>(v[2], v[3]);
-                        *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
+                        v[e] = a4[e] + v[e];
+                        v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
                     }
                 }
+                if (yg) *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+                if (y16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);  // slope 1 = identity
+                    int2v w2;
+                    w2.x = (int)pack16<BF>(v[0], v[1]);
+                    w2.y = (int)pack16<BF>(v[2], v[3]);
+                    *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
+                }
             }
+        }
     } else if constexpr (EPI == E16_STD) {
         float* yb = p.y + (int64_t)b * p.y_bs;
         float* y2b = p.y2 ? p.y2 + (int64_t)b * p.y_bs : nullptr;
