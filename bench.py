@@ -354,8 +354,10 @@ def main():
                        "source_sha16": pkg.source_sha16()},
             "rtf": elapsed / (total_samples / float(sr)), "rtf_22050": elapsed / (total_samples / 22050.0),
             "algorithmic_tflops": flops_step * args.steps / elapsed / 1e12,
-            "frac_fp32_peak_whole_path": flops_step * args.steps / elapsed / 1e12 / (PEAK_F32_TFLOPS * world),
         }
+        # whole-path fraction of the matrix-core peak of the arithmetic in use (fp32: 157.3 TFLOP/s; 16-bit operands: 2.5 PFLOP/s dense)
+        res["frac_fp32_peak_whole_path" if args.arith == "f32" else "frac_mfma16_peak_whole_path"] = \
+            flops_step * args.steps / elapsed / 1e12 / ((PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0) * world)
         if "plain" in extra:
             e, s = extra["plain"]
             res["value_without_kernel_events"] = s / e
@@ -365,7 +367,8 @@ def main():
             e, s, fr = extra["pinned"]
             fl = sum(algorithmic_flops(T, int(f)) for f in fr)
             res["pinned_durations"] = {"value": s / e, "ms_per_step": 1000.0 * e / args.steps, "samples_per_step": s // args.steps, "frames_per_id": 2,
-                                       "algorithmic_tflops": fl * args.steps / e / 1e12, "frac_fp32_peak_whole_path": fl * args.steps / e / 1e12 / PEAK_F32_TFLOPS,
+                                       "algorithmic_tflops": fl * args.steps / e / 1e12,
+                                       "frac_peak_whole_path": fl * args.steps / e / 1e12 / (PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0),
                                        "note": "SURVEY 8d run (ii): every id lasts 2 frames (equal lengths), library default configuration"}
         if "host" in extra:
             e, s = extra["host"]
