@@ -165,3 +165,30 @@ def test_tiny_models_run_in_16bit_modes(pkg, oracle, tiny_bytes, tiny_hf_bytes, 
         assert lengths[0] == ref["waveform"].size
         for tap in ("enc_out", "z_flow", "pre_tanh"):
             assert rel_err(m.tap(tap), ref[tap]) < 3e-3, tap
+
+
+@pytest.mark.parametrize("name,arith,_tol", ARITHS)
+def test_fused_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, full_bytes, monkeypatch, name, arith, _tol):
+    """rbpair16.hip (C = 32 / 64: conv1 -> LDS -> conv2 in one kernel) uses the same operands, rounding points and k-order as two
+    conv16 launches: the PCM must not move by a bit — ragged batch, windowed vocoder, both semantics modes."""
+    Ts = [30, 11, 40]
+    ids = np.zeros((3, 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = _ids(T, 90 + b)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("VITS_NO_FUSE16", "1")
+        with pkg.Model(full_bytes) as m:
+            m.set_arith(arith)
+            for mode in (0, 1):
+                outs[(fused, mode, 0)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33)
+                outs[(fused, mode, 1)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33, vocoder_chunk_frames=24)
+    for mode in (0, 1):
+        for w in (0, 1):
+            a, b_ = outs[(True, mode, w)], outs[(False, mode, w)]
+            assert np.array_equal(a[1], b_[1])
+            for x, y in zip(a[0], b_[0]):
+                assert np.array_equal(x, y), (mode, w)
+        for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
+            assert np.array_equal(x, y)

@@ -3,7 +3,7 @@ import csv, sys, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.Counter()
 for path in sys.argv[1:]:
-    for f in glob.glob(path):
+    for f in glob.glob(path, recursive=True):
         seen = set()
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]

@@ -618,6 +618,8 @@ static Tile16 tile16_shape(int tile) {
         case 1: return {1, 4, 2, 2};  // 64 x 256
         case 2: return {1, 4, 1, 2};  // 32 x 256
         case 3: return {1, 4, 2, 1};  // 64 x 128
+        case 5: return {2, 2, 2, 2};  // 128 x 128
+        case 6: return {4, 1, 1, 4};  // 128 x 128, one row tile per wave: every A fragment feeds 4 MFMAs
         default: return {1, 4, 1, 1};  // 32 x 128
     }
 }
@@ -665,6 +667,14 @@ static hipError_t launch_tile16(int tile, const Conv16Params& p, int mtiles_used
             else return hipErrorInvalidValue;
             break;
         case 3: VITS_LAUNCH16(1, 4, 2, 1); break;
+        case 5:
+            if constexpr (group && DIL != 0) VITS_LAUNCH16(2, 2, 2, 2);
+            else return hipErrorInvalidValue;
+            break;
+        case 6:
+            if constexpr (group && DIL != 0) VITS_LAUNCH16(4, 1, 1, 4);
+            else return hipErrorInvalidValue;
+            break;
         default:
             if constexpr (EPI != E16_GATE) VITS_LAUNCH16(1, 4, 1, 1);
             else return hipErrorInvalidValue;
@@ -765,11 +775,12 @@ VITS_DISPATCH16(VITS_FN16(3)) {
 int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch) {
     int tile;
     const bool small_t = ncols_max <= 128;
-    // 128 x 256 tiles hold one block per CU (196 VGPRs), whose K loop and epilogue then run back to back; 64 x 256 tiles (121 VGPRs,
-    // 3 blocks per CU) overlap one block's epilogue traffic with another's MFMAs: measured 33.6 -> 29.6 ms per step. VITS_T16_TILE0=1 opts in.
+    // c_out multiple of 128: 128 x 128 tiles (default) read the input tile once per 128 rows at 3 blocks per CU. 128 x 256 tiles
+    // (VITS_T16_TILE0=1) hold one block per CU (196 VGPRs: K loop and epilogue run back to back: 33.6 ms per step); 64 x 256 tiles
+    // (VITS_T16_TILE0=2: 29.6 ms) overlap epilogue traffic with MFMAs but fetch the input once per 64 rows.
     static const int tile0 = getenv("VITS_T16_TILE0") ? atoi(getenv("VITS_T16_TILE0")) : 0;
     if (epi == EPI_GATE) tile = small_t ? 3 : 1;
-    else if (rows % 128 == 0) tile = small_t ? 3 : (tile0 ? 0 : 1);
+    else if (rows % 128 == 0) tile = small_t ? 3 : (tile0 == 1 ? 0 : tile0 == 2 ? 1 : tile0 == 3 ? 5 : tile0 == 4 ? 3 : 6);
     else if (rows % 64 == 0) tile = small_t ? 3 : 1;
     else tile = small_t ? 4 : 2;
     // small grids (batch 1, short inputs): step down until the launch has >= 512 blocks
@@ -779,7 +790,7 @@ int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int ba
         const int64_t mb = (mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
         return nb * mb * batch;
     };
-    if (blocks(tile) < 512 && (tile == 0 || tile == 1)) tile = 3;
+    if (blocks(tile) < 512 && (tile == 0 || tile == 1 || tile == 5 || tile == 6)) tile = 3;
     if (epi != EPI_GATE && blocks(tile) < 512 && (tile == 3 || tile == 2)) tile = 4;
     return tile;
 }
@@ -840,7 +851,7 @@ hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hi
         p.pad_l = c.pad_l;
     }
     int tile = c.tile >= 0 ? c.tile : choose_conv16_tile(w.rows, w.epi, ncols_max, w.mtiles_used, c.batch);
-    if (tile == 0 && !conv16_has_tile0(epi16, w.kt, p.dil)) tile = 1;
+    if ((tile == 0 || tile == 5 || tile == 6) && !conv16_has_tile0(epi16, w.kt, p.dil)) tile = 1;
     if (tile == 2 && !(epi16 == E16_GROUP || epi16 == E16_CONVT_GROUP)) tile = 4;
     const Tile16 ts = tile16_shape(tile);
     const int bn = ts.wn * ts.nr * 32;

@@ -1089,6 +1089,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     // 16-bit arithmetic modes: the vocoder runs in the group layout of conv16.hip when its channel counts allow it (taps need the
     // fp32 layout of the transparent path: collect_taps keeps to that one); scratch for the transparent path's rounded inputs
     const bool fast16 = arith != VITS_ARITH_F32 && vocoder_group_ok_ && std::getenv("VITS_NO_GROUP16") == nullptr;
+    const bool fuse16 = fast16 && std::getenv("VITS_NO_FUSE16") == nullptr;  // resblock conv pairs of the narrow stages as one kernel
     const size_t x16_elems2 = arith != VITS_ARITH_F32 ? std::max({big, (size_t)B * H * round_up(ls, 8), (size_t)B * hp.up_init * round_up(lws, 8), (size_t)B * round_up(F, 8) * round_up(ls, 8)}) + 64 : 0;
     const int S_stride = round_up(smax[n_up], 32);
     auto layout2 = [&](Arena& a) {
@@ -1380,7 +1381,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;
                         c1.y16 = bt16;  // t = leaky_relu(conv1(...)), rounded: what the second conv consumes (vits.cpp:556-567)
                         c1.y16_slope = hp.lrelu;
-                        HIP_OK(conv16("hifigan_resblock_conv", R.c1[d], c1, sj, 4.0 * n_out + (double)R.c1[d].bytes16));
+                        // narrow stages: the pair runs as ONE kernel and t stays in LDS (rbpair16.hip; bit-identical to the two-kernel path)
+                        const bool fuse = fuse16 && rbpair16_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
+                        if (!fuse) HIP_OK(conv16("hifigan_resblock_conv1", R.c1[d], c1, sj, 4.0 * n_out + (double)R.c1[d].bytes16));
                         Conv16Call c2 = c1;
                         c2.x = bt16;
                         c2.dil = 1;
@@ -1421,7 +1424,33 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         }
                         const bool last = d + 1 == nd;
                         if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
-                        HIP_OK(conv16("hifigan_resblock_conv", R.c2[d], c2, sj, bytes2));
+                        if (fuse) {
+                            RbPair16Call f;
+                            f.x = c1.x;
+                            f.lens = d_len[st_out];
+                            f.batch = B;
+                            f.tmax = smax[st_out];
+                            f.dil = R.dil[d];
+                            f.slope = hp.lrelu;
+                            f.yg = c2.yg;
+                            f.resg = c2.resg;
+                            f.accg = c2.accg;
+                            f.g_bs = g_bs;
+                            f.g_ts = g_ts;
+                            f.y16 = c2.y16;
+                            f.y16_slope = c2.y16_slope;
+                            f.scale = c2.scale;
+                            f.scale_div = c2.scale_div;
+                            if (prof.on) {
+                                char full[160];
+                                std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|F|e0g|c%dx%d", R.k, R.dil[d], C, C);
+                                prof.begin(full, 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], bytes2 - 2.0 * n_out + (double)R.c1[d].bytes16 + 2.0 * n_out, sj, true);
+                            }
+                            HIP_OK(launch_rbpair16(R.c1[d], R.c2[d], f, arith, sj));
+                            prof.end(sj);
+                        } else {
+                            HIP_OK(conv16("hifigan_resblock_conv2", R.c2[d], c2, sj, bytes2));
+                        }
                         if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
                     }
                 }

@@ -99,6 +99,25 @@ struct Conv16Call {
     float y16_slope = 1.f;  // leaky_relu fused into the 16-bit copy (1 = none)
     int64_t sum_in = -1, sum_out = -1;  // profiler accounting (see ConvCall)
 };
+// One HiFiGAN ResBlock conv pair as a single kernel (rbpair16.hip): y' = y + conv2(leaky_relu(conv1(x) + b1)) + b2 with x =
+// the 16-bit leaky_relu(y); the intermediate stays in LDS. C = 32 / 64, k = 3 / 7 / 11, conv1 dilation 1 / 3 / 5.
+struct RbPair16Call {
+    Ref16 x;
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0, dil = 1;
+    float slope = 0.1f;
+    float* yg = nullptr;
+    const float* resg = nullptr;
+    const float* accg = nullptr;
+    int64_t g_bs = 0;
+    int g_ts = 0;
+    Ref16 y16;
+    float y16_slope = 1.f;
+    float scale = 1.f;
+    int scale_div = 0;
+};
+bool rbpair16_supported(int channels, int kt, int dil);
+hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);
 int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch);
 hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);

@@ -1,0 +1,359 @@
+// rbpair16.hip — one HiFiGAN ResBlock conv PAIR as a single kernel, 16-bit-operand modes, narrow stages (C = 32 / 64):
+//     y' = y + Conv_{k,1}( leaky_relu( Conv_{k,d}( leaky_relu(y) ) + b1 ) ) + b2        (/root/reference/src/vits.cpp:545-581)
+// The intermediate t = leaky_relu(conv1 + b1) never goes to HBM: the block computes a 256-column tile of it (the output tile
+// plus the (k-1)-column halo the second conv needs), rounds it to the arithmetic type exactly as the unfused path's epilogue
+// does, keeps it in LDS in the group layout, and runs the second conv from there. Per element and pair that is
+// read x16 (2 B) + residual (4) + write y' (4) + its 16-bit copy (2) = 12 B instead of 16 B — these stages run at the HBM
+// roof in the 16-bit modes (conv16.hip), so bytes are time. Same operands, same k-order of accumulation
+// (chunk, tap, k-half) and same rounding points as conv16_kernel: the results are bit-identical to the two-kernel path
+// (GPU test), which the engine keeps for C >= 128 and as the VITS_NO_FUSE16=1 fallback.
+//
+// Block = 4 waves, no producer wave: the whole input tile (C/8 groups x (256 + (k-1)(d+1)) slots) is streamed in with LDS-DMA
+// by all four waves at once, then conv1 -> t tile (LDS) -> conv2 -> epilogue; 3-4 blocks per CU overlap one block's DMA and
+// epilogue traffic with another's MFMAs.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <type_traits>
+
+#include "../../include/vits.h"
+#include "kernels.h"
+
+namespace vits {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+
+template <bool BF>
+__device__ __forceinline__ unsigned rb_pack16(float a, float b) {
+    float2v f = {a, b};
+    if constexpr (BF) return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2v));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, half2v));
+}
+
+struct RbPairParams {
+    const uint16_t* x;  // leaky_relu(y), rounded: group layout [b][C/8][x_ts][8]
+    int64_t x_bs;
+    int x_ts;
+    const uint16_t *w1, *w2;  // A fragments of the two convs (pack_conv_weights16)
+    const float *b1, *b2;
+    const int* lens;
+    int tmax;
+    float slope;  // leaky_relu between the convs
+    // epilogue (group layout, as conv16's E16_GROUP)
+    float* yg;
+    const float* resg;
+    const float* accg;
+    int64_t g_bs;
+    int g_ts;
+    uint16_t* y16;
+    int64_t y16_bs;
+    int y16_ts;
+    float y16_slope;
+    float scale;
+    int scale_div;
+};
+
+template <int KT, int DIL, int C, bool BF>
+__global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
+    constexpr int G = C / 8;         // channel groups
+    constexpr int NCH = C / 32;      // 32-channel chunks
+    constexpr int MR = C / 32;       // row tiles per wave (every wave owns all C output rows of its columns)
+    constexpr int NR = 2;            // 64 columns per wave, 4 waves = 256 mid columns
+    constexpr int BM = 256;          // columns of t computed per block
+    constexpr int BO = BM - (KT - 1);  // output columns per block
+    constexpr int P2 = (KT - 1) / 2, P1 = (KT - 1) * DIL / 2;
+    constexpr int XW = BM + (KT - 1) * DIL;
+    constexpr int XWP = (XW + 7) / 8 * 8;
+    constexpr int TW = (BM + KT - 1 + 7) / 8 * 8;
+    constexpr int STEPS = 2 * KT;
+    extern __shared__ __attribute__((aligned(16))) int4v lds[];  // x tile [G][XWP] | t tile [G][TW]
+    int4v* xs = lds;
+    int4v* ts = lds + G * XWP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    const int t0 = blockIdx.x * BO;
+    if (t0 >= len) return;
+    const int h = lane >> 5;
+    typedef const __attribute__((address_space(3))) int4v* LdsV;
+
+    // ---- phase 0: the input tile, all groups, straight into LDS (slot s <-> global time t0 - P2 - P1 + s) -------------------
+    {
+        const uint16_t* xb = p.x + (int64_t)b * p.x_bs;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, 0x7fffffff, 0x00020000);
+        const int tx0 = t0 - P2 - P1;
+        constexpr int NP = (XWP + 63) / 64;
+#pragma unroll
+        for (int gi = 0; gi < G / 4; ++gi) {
+            const int g = wid + 4 * gi;
+            const unsigned soff = (unsigned)g * (unsigned)p.x_ts * 16u;
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const int t = tx0 + lane + 64 * m;
+                const int tc = t < 0 ? 0 : (t < len ? t : len - 1);
+                if (64 * m + lane < XWP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xs + g * XWP + 64 * m), 16, tc * 16, (int)soff, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tx0 < 0 || tx0 + XWP > len) {  // sequence ends: zero padding
+            const int4v z = {0, 0, 0, 0};
+#pragma unroll
+            for (int gi = 0; gi < G / 4; ++gi) {
+                const int g = wid + 4 * gi;
+#pragma unroll
+                for (int m = 0; m < NP; ++m) {
+                    const int t = tx0 + lane + 64 * m;
+                    if (64 * m + lane < XWP && (t < 0 || t >= len)) xs[g * XWP + 64 * m + lane] = z;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    auto mfma = [&](int4v a, int4v bq, floatx16 c) __attribute__((always_inline)) -> floatx16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, bq), c, 0, 0, 0);
+    };
+    floatx16 acc[MR][NR];
+
+    // one conv over the LDS tile `base` (group row pitch `pitch` slots, tap step `dstep` slots): acc = sum over (chunk, tap, k-half)
+    auto conv = [&](const uint16_t* wp, LdsV base, const int pitch, const int dstep) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+        constexpr int TOTAL = NCH * STEPS;
+        int wvoff[MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)mr * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int mr, int step) __attribute__((always_inline)) -> int4v {
+            return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
+        };
+        int4v ring[4][MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            ring[0][mr] = load_a(mr, 0);
+            ring[1][mr] = load_a(mr, 1);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            LdsV xb = base + c * 4 * pitch;
+            int4v b_nxt[NR];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[nr * 32];
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int s = c * STEPS + j * 2 + kk;  // compile time after unrolling
+                    {
+                        const int nstep = s + 2 < TOTAL ? s + 2 : TOTAL - 1;
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) ring[(s + 2) & 3][mr] = load_a(mr, nstep);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    int4v b_cur[NR];
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
+                    {
+                        const int noff = kk == 0 ? 2 * pitch + j * dstep : (j + 1) * dstep;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[noff + nr * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s & 3][mr], b_cur[nr], acc[mr][nr]);
+                }
+        }
+    };
+
+    __syncthreads();
+    // ---- phase 1: conv1 over the x tile: mid column i reads x slots i + j*DIL ------------------------------------------------
+    conv(p.w1, (LdsV)(xs + h * XWP + wid * (NR * 32) + (lane & 31)), XWP, DIL);
+
+    // ---- phase 2: t = round(leaky_relu(conv1 + b1)), zero outside the sequence, into LDS (group layout) -------------------
+    {
+        typedef __attribute__((address_space(3))) int2v* LdsW;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = mr * 32 + 8 * g + 4 * h;
+                const float4v bias = *reinterpret_cast<const float4v*>(p.b1 + ch0);
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int i = wid * (NR * 32) + nr * 32 + (lane & 31);
+                    const int tm = t0 - P2 + i;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[mr][nr][4 * g + e] + bias[e];
+                        v[e] = fmaxf(v[e], v[e] * p.slope);
+                        if (tm < 0 || tm >= len) v[e] = 0.f;  // the second conv's zero padding
+                    }
+                    int2v w2;
+                    w2.x = (int)rb_pack16<BF>(v[0], v[1]);
+                    w2.y = (int)rb_pack16<BF>(v[2], v[3]);
+                    *((LdsW)(ts + (mr * 4 + g) * TW + i) + h) = w2;
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    // ---- phase 3: conv2 over the t tile: output column o reads t slots o + j -------------------------------------------------
+    conv(p.w2, (LdsV)(ts + h * TW + wid * (NR * 32) + (lane & 31)), TW, 1);
+
+    // ---- phase 4: epilogue (as conv16's group epilogue): + b2, + residual, resblock sum / scale, fp32 stream + 16-bit copy ----
+    {
+        float* yg = p.yg ? p.yg + (int64_t)b * p.g_bs : nullptr;
+        const float* rg = p.resg ? p.resg + (int64_t)b * p.g_bs : nullptr;
+        const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
+        uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
+        constexpr int NGR = MR * 4;
+        float4v rv[3][NR];
+        auto col_ok = [&](int nr, int& t) __attribute__((always_inline)) -> bool {
+            const int o = wid * (NR * 32) + nr * 32 + (lane & 31);
+            t = t0 + o;
+            return o < BO && t < len;
+        };
+        auto load_res = [&](int it, float4v* dst) __attribute__((always_inline)) {
+            const int ch0 = (it / 4) * 32 + 8 * (it & 3) + 4 * h;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                int t;
+                dst[nr] = float4v{0.f, 0.f, 0.f, 0.f};
+                if (rg && col_ok(nr, t)) dst[nr] = *reinterpret_cast<const float4v*>(rg + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+            }
+        };
+        load_res(0, rv[0]);
+        load_res(1, rv[1]);
+#pragma unroll
+        for (int it = 0; it < NGR; ++it) {
+            const int mr = it / 4, g = it & 3;
+            if (it + 2 < NGR) load_res(it + 2, rv[(it + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ch0 = mr * 32 + 8 * g + 4 * h;
+            const float4v bias = *reinterpret_cast<const float4v*>(p.b2 + ch0);
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                int t;
+                if (!col_ok(nr, t)) continue;
+                const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[mr][nr][4 * g + e] + bias[e];
+                    if (rg) v[e] = rv[it % 3][nr][e] + v[e];
+                }
+                if (ag) {
+                    const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = a4[e] + v[e];
+                        v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
+                    }
+                }
+                if (yg) *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+                if (y16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
+                    int2v w2;
+                    w2.x = (int)rb_pack16<BF>(v[0], v[1]);
+                    w2.y = (int)rb_pack16<BF>(v[2], v[3]);
+                    *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+template <int KT, int DIL, int C, bool BF>
+static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
+    constexpr int BO = 256 - (KT - 1);
+    constexpr int XWP = (256 + (KT - 1) * DIL + 7) / 8 * 8, TW = (256 + KT - 1 + 7) / 8 * 8;
+    const size_t lds = (size_t)(C / 8) * (XWP + TW) * 16;
+    static std::atomic<bool> big_lds_set{false};
+    if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        big_lds_set.store(true, std::memory_order_release);
+    }
+    dim3 grid((p.tmax + BO - 1) / BO, batch);
+    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, BF>), grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int KT, int C, bool BF>
+static hipError_t launch_rb_dil(int dil, const RbPairParams& p, int batch, hipStream_t s) {
+    switch (dil) {
+        case 1: return launch_rb<KT, 1, C, BF>(p, batch, s);
+        case 3: return launch_rb<KT, 3, C, BF>(p, batch, s);
+        case 5: return launch_rb<KT, 5, C, BF>(p, batch, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int C, bool BF>
+static hipError_t launch_rb_kt(int kt, int dil, const RbPairParams& p, int batch, hipStream_t s) {
+    switch (kt) {
+        case 3: return launch_rb_dil<3, C, BF>(dil, p, batch, s);
+        case 7: return launch_rb_dil<7, C, BF>(dil, p, batch, s);
+        case 11: return launch_rb_dil<11, C, BF>(dil, p, batch, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool rbpair16_supported(int channels, int kt, int dil) {
+    return (channels == 32 || channels == 64) && (kt == 3 || kt == 7 || kt == 11) && (dil == 1 || dil == 3 || dil == 5);
+}
+
+hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s) {
+    if (!c1.wp16 || !c2.wp16 || c1.cin != c1.cout || c2.cin != c1.cout || c2.cout != c1.cout || c1.kt != c2.kt || !rbpair16_supported(c1.cin, c1.kt, c.dil))
+        return hipErrorInvalidValue;
+    RbPairParams p;
+    p.x = c.x.p;
+    p.x_bs = c.x.bs;
+    p.x_ts = c.x.ts;
+    p.w1 = c1.wp16;
+    p.w2 = c2.wp16;
+    p.b1 = c1.bias;
+    p.b2 = c2.bias;
+    if (!p.b1 || !p.b2) return hipErrorInvalidValue;
+    p.lens = c.lens;
+    p.tmax = c.tmax;
+    p.slope = c.slope;
+    p.yg = c.yg;
+    p.resg = c.resg;
+    p.accg = c.accg;
+    p.g_bs = c.g_bs;
+    p.g_ts = c.g_ts;
+    p.y16 = c.y16.p;
+    p.y16_bs = c.y16.bs;
+    p.y16_ts = c.y16.ts;
+    p.y16_slope = c.y16_slope;
+    p.scale = c.scale;
+    p.scale_div = c.scale_div;
+    const bool bf = arith == VITS_ARITH_BF16;
+    if (c1.cin == 32) return bf ? launch_rb_kt<32, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<32, false>(c1.kt, c.dil, p, c.batch, s);
+    return bf ? launch_rb_kt<64, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<64, false>(c1.kt, c.dil, p, c.batch, s);
+}
+
+}  // namespace vits
