@@ -1,4 +1,4 @@
-// rbpair16.hip — one HiFiGAN ResBlock conv PAIR as a single kernel, 16-bit-operand modes, narrow stages (C = 32 / 64):
+// rbpair16.hip — one HiFiGAN ResBlock conv PAIR as a single kernel, 16-bit-operand modes, narrow stages (C = 32 / 64; 128 opt-in):
 //     y' = y + Conv_{k,1}( leaky_relu( Conv_{k,d}( leaky_relu(y) ) + b1 ) ) + b2        (/root/reference/src/vits.cpp:545-581)
 // The intermediate t = leaky_relu(conv1 + b1) never goes to HBM: the block computes a 256-column tile of it (the output tile
 // plus the (k-1)-column halo the second conv needs), rounds it to the arithmetic type exactly as the unfused path's epilogue
@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/vits.h"
@@ -62,13 +63,14 @@ struct RbPairParams {
     int scale_div;
 };
 
-template <int KT, int DIL, int C, bool BF>
+template <int KT, int DIL, int C, int NR, bool BF>
 __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
     constexpr int G = C / 8;         // channel groups
     constexpr int NCH = C / 32;      // 32-channel chunks
     constexpr int MR = C / 32;       // row tiles per wave (every wave owns all C output rows of its columns)
-    constexpr int NR = 2;            // 64 columns per wave, 4 waves = 256 mid columns
-    constexpr int BM = 256;          // columns of t computed per block
+    // NR 32-column tiles per wave, 4 waves: 256 mid columns for C <= 64 (NR = 2), 128 for C = 128 (NR = 1: the accumulators and
+    // the two LDS tiles of a 256-column block would leave one block per CU)
+    constexpr int BM = 4 * NR * 32;  // columns of t computed per block
     constexpr int BO = BM - (KT - 1);  // output columns per block
     constexpr int P2 = (KT - 1) / 2, P1 = (KT - 1) * DIL / 2;
     constexpr int XW = BM + (KT - 1) * DIL;
@@ -287,17 +289,19 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
 // ---- host side -----------------------------------------------------------------------------------------------------------
 template <int KT, int DIL, int C, bool BF>
 static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
-    constexpr int BO = 256 - (KT - 1);
-    constexpr int XWP = (256 + (KT - 1) * DIL + 7) / 8 * 8, TW = (256 + KT - 1 + 7) / 8 * 8;
+    constexpr int NR = C <= 64 ? 2 : 1;
+    constexpr int BM = 4 * NR * 32;
+    constexpr int BO = BM - (KT - 1);
+    constexpr int XWP = (BM + (KT - 1) * DIL + 7) / 8 * 8, TW = (BM + KT - 1 + 7) / 8 * 8;
     const size_t lds = (size_t)(C / 8) * (XWP + TW) * 16;
     static std::atomic<bool> big_lds_set{false};
     if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, NR, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, BF>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -306,7 +310,9 @@ static hipError_t launch_rb_dil(int dil, const RbPairParams& p, int batch, hipSt
     switch (dil) {
         case 1: return launch_rb<KT, 1, C, BF>(p, batch, s);
         case 3: return launch_rb<KT, 3, C, BF>(p, batch, s);
-        case 5: return launch_rb<KT, 5, C, BF>(p, batch, s);
+        case 5:
+            if constexpr (C <= 64) return launch_rb<KT, 5, C, BF>(p, batch, s);
+            else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -322,7 +328,14 @@ static hipError_t launch_rb_kt(int kt, int dil, const RbPairParams& p, int batch
 }
 
 bool rbpair16_supported(int channels, int kt, int dil) {
-    return (channels == 32 || channels == 64) && (kt == 3 || kt == 7 || kt == 11) && (dil == 1 || dil == 3 || dil == 5);
+    // C = 128 fused (128-column blocks, every A fragment feeds ONE MFMA) measured slower than two kernels (1.01 vs 0.90 ms per
+    // k = 11 pair): off unless VITS_FUSE16_MAXC=128
+    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 64;
+    if (!(kt == 3 || kt == 7 || kt == 11) || channels > maxc) return false;
+    if (channels == 32 || channels == 64) return dil == 1 || dil == 3 || dil == 5;
+    // C = 128: the two LDS tiles of a dilation-5 pair (84 KB) would leave one block per CU: those pairs stay two kernels
+    if (channels == 128) return dil == 1 || dil == 3;
+    return false;
 }
 
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s) {
@@ -353,7 +366,8 @@ hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbP
     p.scale_div = c.scale_div;
     const bool bf = arith == VITS_ARITH_BF16;
     if (c1.cin == 32) return bf ? launch_rb_kt<32, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<32, false>(c1.kt, c.dil, p, c.batch, s);
-    return bf ? launch_rb_kt<64, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<64, false>(c1.kt, c.dil, p, c.batch, s);
+    if (c1.cin == 64) return bf ? launch_rb_kt<64, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<64, false>(c1.kt, c.dil, p, c.batch, s);
+    return bf ? launch_rb_kt<128, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<128, false>(c1.kt, c.dil, p, c.batch, s);
 }
 
 }  // namespace vits
