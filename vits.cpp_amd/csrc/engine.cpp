@@ -1443,7 +1443,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                             f.scale_div = c2.scale_div;
                             if (prof.on) {
                                 char full[160];
-                                std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|F|e0g|c%dx%d", R.k, R.dil[d], C, C);
+                                std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|F%d|e0g|c%dx%d", R.k, R.dil[d], C, C, C);
                                 prof.begin(full, 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], bytes2 - 2.0 * n_out + (double)R.c1[d].bytes16 + 2.0 * n_out, sj, true);
                             }
                             HIP_OK(launch_rbpair16(R.c1[d], R.c2[d], f, arith, sj));
