@@ -1370,9 +1370,18 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
                     const int q = par ? (int)j : 0;
                     const Ref16 byl16 = R16(s2.byl[q], C, sts[st_out]), bt16 = R16(s2.bt[q], C, sts[st_out]);
+                    // narrow stages: each pair runs as ONE kernel and t stays in LDS (rbpair16.hip; bit-identical to the two-kernel path).
+                    // A fused block reads a halo of its neighbours' input columns while other blocks already write their output, so a fused
+                    // pair must never write the 16-bit stream it reads: the pairs of a resblock ping-pong between the two 16-bit buffers
+                    // the two-kernel path uses for the stream and for t. (All pairs of the resblock fuse, or none: a two-kernel pair needs
+                    // the second buffer for its t.)
+                    bool fuse_rb = fuse16;
+                    for (size_t d = 0; d < nd; ++d) fuse_rb = fuse_rb && rbpair16_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
                     for (size_t d = 0; d < nd; ++d) {
+                        const Ref16 in16 = d == 0 ? bul16 : (fuse_rb && (d & 1) == 0 ? bt16 : byl16);
+                        const Ref16 out16 = fuse_rb && (d & 1) ? bt16 : byl16;  // the stream buffer this pair writes
                         Conv16Call c1;
-                        c1.x = d == 0 ? bul16 : byl16;
+                        c1.x = in16;
                         c1.len_in = c1.len_out = d_len[st_out];
                         c1.batch = B;
                         c1.t_in = c1.t_out = smax[st_out];
@@ -1381,8 +1390,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;
                         c1.y16 = bt16;  // t = leaky_relu(conv1(...)), rounded: what the second conv consumes (vits.cpp:556-567)
                         c1.y16_slope = hp.lrelu;
-                        // narrow stages: the pair runs as ONE kernel and t stays in LDS (rbpair16.hip; bit-identical to the two-kernel path)
-                        const bool fuse = fuse16 && rbpair16_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
+                        const bool fuse = fuse_rb;
                         if (!fuse) HIP_OK(conv16("hifigan_resblock_conv1", R.c1[d], c1, sj, 4.0 * n_out + (double)R.c1[d].bytes16));
                         Conv16Call c2 = c1;
                         c2.x = bt16;
@@ -1396,7 +1404,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                         double bytes2 = 2.0 * n_out + 4.0 * n_out + 4.0 * n_out + (double)R.c2[d].bytes16;
                         if (d + 1 < nd) {
                             c2.yg = s2.by[q];
-                            c2.y16 = byl16;  // next pair's input
+                            c2.y16 = out16;  // next pair's input
                             c2.y16_slope = hp.lrelu;
                             bytes2 += 2.0 * n_out;
                         } else {
