@@ -176,6 +176,7 @@ def test_fused_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, full_b
     for b, T in enumerate(Ts):
         ids[b, :T] = _ids(T, 90 + b)
     outs = {}
+    long_ids = pkg.synth_ids(2, 700, ids_seed=4242)  # 1400 frames: several times more blocks per launch than the GPU holds at once
     for fused in (True, False):
         if not fused:
             monkeypatch.setenv("VITS_NO_FUSE16", "1")
@@ -184,6 +185,11 @@ def test_fused_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, full_b
             for mode in (0, 1):
                 outs[(fused, mode, 0)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33)
                 outs[(fused, mode, 1)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33, vocoder_chunk_frames=24)
+            outs[(fused, "long", 0)] = m.process_batch(long_ids, noise_seed=34, fixed_duration=2)
+    # long utterances: blocks of one launch start after others have finished — what exposes a block reading data another block of the
+    # same launch has already overwritten (the fused pairs must not write the 16-bit stream they read)
+    for x, y in zip(outs[(True, "long", 0)][0], outs[(False, "long", 0)][0]):
+        assert np.array_equal(x, y), "long utterance"
     for mode in (0, 1):
         for w in (0, 1):
             a, b_ = outs[(True, mode, w)], outs[(False, mode, w)]
