@@ -227,3 +227,33 @@ def test_long_form_1024_ids_in_f16_mode(pkg, oracle, full_bytes):
         tiled_b, _, _ = m.process_batch(ids, noise_seed=12, fixed_duration=2, vocoder_chunk_frames=300)
         assert np.array_equal(tiled_b[0], whole_b[0])
         assert 1e-4 < rel_err(whole_b[0], whole[0]) < 0.3
+
+
+@pytest.mark.parametrize("name,arith", [("f32", 0)] + [(n, a) for n, a, _ in ARITHS])
+def test_fused_dds_layer_is_bit_identical_to_the_three_kernel_path(pkg, full_bytes, monkeypatch, name, arith):
+    """misc_kernels.hip dds_layer_kernel (depthwise + LN + gelu + 1x1 conv + LN + gelu + residual of one DDS layer, vits.cpp:655-691,
+    as one kernel) takes every sum in the order of the three launches it replaces: the log-durations and everything behind them must
+    not move by a bit — ragged batch with very short and long members (more 32-column tiles than one launch runs at once), both
+    semantics modes, all arithmetic modes."""
+    Ts = [30, 1, 40, 3, 33]
+    ids = np.zeros((5, 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = _ids(T, 70 + b)
+    long_ids = pkg.synth_ids(3, 900, ids_seed=77)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("VITS_NO_DDS_FUSE", "1")
+        with pkg.Model(full_bytes) as m:
+            m.set_arith(arith)
+            for mode in (0, 1):
+                pcm, lengths, _ = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=12, collect_taps=True)
+                outs[(fused, mode)] = (pcm, lengths, m.tap("log_duration").copy())
+            outs[(fused, "long")] = m.process_batch(long_ids, noise_seed=13, frames_only=True)
+    assert np.array_equal(outs[(True, "long")][1], outs[(False, "long")][1])
+    for mode in (0, 1):
+        a, b_ = outs[(True, mode)], outs[(False, mode)]
+        assert np.array_equal(a[2], b_[2]), "log_duration"
+        assert np.array_equal(a[1], b_[1])
+        for x, y in zip(a[0], b_[0]):
+            assert np.array_equal(x, y), mode

@@ -665,6 +665,25 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
     const int H = hp.hidden;
     TensorRef none;
     int dil = 1;
+    // Each layer as ONE kernel (misc_kernels.hip dds_layer_kernel; bit-identical to the three launches below). A fused block reads a
+    // halo of its neighbours' columns, so a layer never writes the buffer it reads: x -> y -> p -> ... -> x.
+    const int n = hp.dds_layers;
+    bool fuse = n >= 2 && std::getenv("VITS_NO_DDS_FUSE") == nullptr;
+    for (int i = 0, dl = 1; i < n && fuse; ++i, dl *= hp.dp_k) fuse = dds_layer_supported(d.pw[i], H, hp.dp_k, dl, arith);
+    if (fuse) {
+        TensorRef src = x;
+        for (int i = 0; i < n; ++i) {
+            TensorRef dst = i == n - 1 ? x : (src.p == y.p ? p : y);
+            prof.begin("dds_layer_fused", 2.0 * H * H * (double)sum_t, 8.0 * H * (double)sum_t + (double)(arith == VITS_ARITH_F32 ? d.pw[i].bytes : d.pw[i].bytes16), stream);
+            hipError_t e = launch_dds_layer(src, dst, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], d.pw[i], d.n2_g[i], d.n2_b[i], lens, batch, H, tmax, hp.dp_k, dil, 1e-5f,
+                                            arith, stream);
+            prof.end(stream);
+            if (e != hipSuccess) return e;
+            src = dst;
+            dil *= hp.dp_k;
+        }
+        return hipSuccess;
+    }
     for (int i = 0; i < hp.dds_layers; ++i) {
         KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream, arith));
         ConvCall c;

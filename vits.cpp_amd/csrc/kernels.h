@@ -135,6 +135,10 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
                                  int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s);
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
                                 const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith = 0);
+// one DDS layer (depthwise + LN + gelu + 1x1 conv + LN + gelu + residual) as one kernel; y must not alias x
+bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int arith);
+hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
+                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s);
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch,
                                   int channels, int tmax, hipStream_t s, int arith = 0);
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode,

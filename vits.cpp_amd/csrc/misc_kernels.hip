@@ -2,6 +2,7 @@
 // Each kernel cites the reference lines it replaces (/root/reference/src/...).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 
 #include "../../include/vits.h"
@@ -334,6 +335,246 @@ hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const 
     dim3 grid((tmax + 63) / 64, batch);
     hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
                        k, dil, eps, arith);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One whole DDS layer as ONE kernel (vits.cpp:655-691):
+//     x_out = x + gelu(LN2(pointwise(gelu(LN1(depthwise_k,dil(x))))))
+// i.e. dds_depthwise_kernel + the 1x1 conv (conv_mfma.hip / conv16.hip) + add_layer_norm_kernel(gelu, add_to) of the
+// three-launch path, with the two intermediates kept in LDS. Block = 32 time steps x all channels, 16 channel groups of 32
+// threads. Every sum is taken in the order of the three-launch path (the LayerNorm partial sums per channel group and
+// their fixed-order combination; the MFMA chain over the packed weight fragments, chunk by chunk), so the result is
+// bit-identical to it — tests/test_gpu_round2.py compares the two. At batch 1 the three launches are 45-50 us of
+// latency per layer (12 layers per utterance); this one is ~10.
+// The block reads a halo of its neighbours' columns: x_out must not be x (Engine::run_dds rotates three buffers).
+// ---------------------------------------------------------------------------------------------------------
+typedef float dds_floatx16 __attribute__((ext_vector_type(16)));
+typedef int dds_int4v __attribute__((ext_vector_type(4)));
+typedef _Float16 dds_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dds_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct DdsLayerParams {
+    const float* x;
+    int64_t x_bs;
+    int x_cs;
+    float* y;
+    int64_t y_bs;
+    int y_cs;
+    const float *dw_w, *dw_b, *g1, *b1, *pw_b, *g2, *b2;
+    const float* wp;      // fp32 A fragments (pack_conv_weights)
+    const uint16_t* wp16;  // 16-bit A fragments (pack_conv_weights16)
+    const int* lens;
+    int channels, tmax, k, dil, nchunks;
+    float eps;
+};
+
+template <int ARITH>
+__global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NT = 32;
+    const int H = p.channels;
+    const int pad = (p.k * p.dil - p.dil) / 2;  // vits.cpp:660
+    const int xw = NT + 2 * pad;
+    float* xt = sm;                        // [H][xw]   input tile with halo (also the residual)
+    float* ht = xt + ((H * xw + 3) & ~3);  // [H][NT]   depthwise output -> gelu(LN1) -> pointwise output
+    float* red = ht + H * NT;              // [2][LN_GROUPS][NT]
+    dds_int4v* h16 = reinterpret_cast<dds_int4v*>(red + 2 * LN_GROUPS * NT);  // [H/8][NT] 16-bit operand slots (ARITH != 0)
+    const int b = blockIdx.y, t0 = blockIdx.x * NT;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    if (t0 >= len) return;
+    const int tid = threadIdx.x, tl = tid & 31, gq = tid >> 5;
+    const int lane = tid & 63, wid = tid >> 6;
+    {
+        const float* xb = p.x + (int64_t)b * p.x_bs;
+        for (int c = gq; c < H; c += LN_GROUPS)
+            for (int i = tl; i < xw; i += 32) {
+                const int t = t0 - pad + i;
+                xt[c * xw + i] = (t >= 0 && t < len) ? xb[(int64_t)c * p.x_cs + t] : 0.f;
+            }
+    }
+    __syncthreads();
+    // ---- depthwise conv + LayerNorm 1 + gelu (dds_depthwise_kernel, same expressions) ----
+    {
+        float s = 0.f;
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            float a = p.dw_b[c];
+            for (int j = 0; j < p.k; ++j) a += round_arith(p.dw_w[c * p.k + j], ARITH) * round_arith(xt[c * xw + tl + j * p.dil], ARITH);
+            ht[c * NT + tl] = a;
+            s += a;
+        }
+        red[gq * NT + tl] = s;
+        __syncthreads();
+        float msum = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * NT + tl];
+        const float mean = msum / (float)H;
+        float vs = 0.f;
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            const float d = ht[c * NT + tl] - mean;
+            vs += d * d;
+        }
+        red[(LN_GROUPS + gq) * NT + tl] = vs;
+        __syncthreads();
+        float vsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * NT + tl];
+        const float var = vsum / (float)H;
+        const float inv = 1.0f / sqrtf(var + p.eps);
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            const float v = gelu_erf((ht[c * NT + tl] - mean) * inv * p.g1[c] + p.b1[c]);
+            if constexpr (ARITH == 0) {
+                ht[c * NT + tl] = v;
+            } else {
+                uint16_t* slot = reinterpret_cast<uint16_t*>(h16 + (c >> 3) * NT + tl);
+                if constexpr (ARITH == 2) {
+                    const _Float16 hv = (_Float16)v;
+                    slot[c & 7] = __builtin_bit_cast(uint16_t, hv);
+                } else {
+                    const __bf16 hv = (__bf16)v;
+                    slot[c & 7] = __builtin_bit_cast(uint16_t, hv);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pointwise conv on the matrix cores: wave w owns output rows 32w..32w+31 (the MFMA chain of conv_mfma.hip / conv16.hip) ----
+    const int nmt = H >> 5;
+    dds_floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (wid < nmt) {
+        if constexpr (ARITH == 0) {
+            const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (size_t)wid * p.nchunks * 4 * 64 + lane;
+            const float* bcol = ht + (lane >> 5) * NT + (lane & 31);
+            for (int c = 0; c < p.nchunks; ++c) {
+                float4 a[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a[g] = wp4[(c * 4 + g) * 64];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* bb = bcol + (c * 32 + 8 * g) * NT;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bb[0 * NT], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bb[2 * NT], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bb[4 * NT], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bb[6 * NT], acc, 0, 0, 0);
+                }
+            }
+        } else {
+            const dds_int4v* wq = reinterpret_cast<const dds_int4v*>(p.wp16) + (size_t)wid * p.nchunks * 2 * 64 + lane;
+            const dds_int4v* bcol = h16 + (lane >> 5) * NT + (lane & 31);
+            for (int c = 0; c < p.nchunks; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const dds_int4v a = wq[(c * 2 + kk) * 64];
+                    const dds_int4v bq = bcol[(c * 4 + 2 * kk) * NT];
+                    if constexpr (ARITH == 1)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dds_bf16x8, a), __builtin_bit_cast(dds_bf16x8, bq), acc, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dds_half8, a), __builtin_bit_cast(dds_half8, bq), acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // (fp32: every wave is done reading ht)
+    if (wid < nmt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wid * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+            ht[row * NT + (lane & 31)] = acc[r] + p.pw_b[row];
+        }
+    }
+    __syncthreads();
+    // ---- LayerNorm 2 + gelu + residual (add_layer_norm_kernel with post_gelu and add_to, same expressions) ----
+    {
+        float s = 0.f;
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            const float v = ht[c * NT + tl];
+            s += v;
+        }
+        red[gq * NT + tl] = s;
+        __syncthreads();
+        float msum = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * NT + tl];
+        const float mean = msum / (float)H;
+        float vs = 0.f;
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            const float d = ht[c * NT + tl] - mean;
+            vs += d * d;
+        }
+        red[(LN_GROUPS + gq) * NT + tl] = vs;
+        __syncthreads();
+        float vsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * NT + tl];
+        const float var = vsum / (float)H;
+        const float inv = 1.0f / sqrtf(var + p.eps);
+        const int t = t0 + tl;
+        if (t >= len) return;
+        float* yb = p.y + (int64_t)b * p.y_bs + t;
+        for (int c = gq; c < H; c += LN_GROUPS) {
+            float v = (ht[c * NT + tl] - mean) * inv * p.g2[c] + p.b2[c];
+            v = gelu_erf(v);
+            asm volatile("" : "+v"(v));  // (the three-launch path adds in a separate statement behind a branch: no fma of gelu's last product with this add)
+            yb[(int64_t)c * p.y_cs] = xt[c * xw + pad + tl] + v;
+        }
+    }
+}
+
+bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int arith) {
+    if (channels <= 0 || (channels & 31) || channels > 32 * (LN_GROUPS / 2)) return false;  // one wave per 32 output rows, 8 waves
+    if (pw.cin != channels || pw.cout != channels || pw.kt != 1 || pw.epi != EPI_STD || !pw.bias) return false;
+    if (arith == VITS_ARITH_F32 ? !pw.wp : !pw.wp16) return false;
+    if (k < 1 || dil < 1 || ((k * dil - dil) & 1)) return false;
+    const int xw = 32 + (k * dil - dil);
+    const size_t lds = sizeof(float) * (((size_t)channels * xw + 3) / 4 * 4 + (size_t)channels * 32 + 2 * 32 * LN_GROUPS) + (size_t)channels * 64;
+    return lds <= 150 * 1024;
+}
+
+hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
+                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s) {
+    if (!dds_layer_supported(pw, channels, k, dil, arith) || x.p == y.p) return hipErrorInvalidValue;
+    DdsLayerParams p;
+    p.x = x.p;
+    p.x_bs = x.bs;
+    p.x_cs = x.cs;
+    p.y = y.p;
+    p.y_bs = y.bs;
+    p.y_cs = y.cs;
+    p.dw_w = dw_w;
+    p.dw_b = dw_b;
+    p.g1 = g1;
+    p.b1 = b1;
+    p.pw_b = pw.bias;
+    p.g2 = g2;
+    p.b2 = b2;
+    p.wp = pw.wp;
+    p.wp16 = pw.wp16;
+    p.lens = lens;
+    p.channels = channels;
+    p.tmax = tmax;
+    p.k = k;
+    p.dil = dil;
+    p.nchunks = pw.nchunks;
+    p.eps = eps;
+    const int xw = 32 + (k * dil - dil);
+    const size_t lds = sizeof(float) * (((size_t)channels * xw + 3) / 4 * 4 + (size_t)channels * 32 + 2 * 32 * LN_GROUPS) + (size_t)channels * 64;
+    dim3 grid((tmax + 31) / 32, batch);
+#define VITS_DDS_LAUNCH(A)                                                                                                             \
+    do {                                                                                                                               \
+        static std::atomic<bool> big{false};                                                                                          \
+        if (lds > 64 * 1024 && !big.load(std::memory_order_acquire)) {                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dds_layer_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                                             \
+            big.store(true, std::memory_order_release);                                                                                \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(dds_layer_kernel<A>, grid, dim3(32 * LN_GROUPS), lds, s, p);                                                \
+    } while (0)
+    if (arith == VITS_ARITH_F32) VITS_DDS_LAUNCH(0);
+    else if (arith == VITS_ARITH_BF16) VITS_DDS_LAUNCH(1);
+    else VITS_DDS_LAUNCH(2);
+#undef VITS_DDS_LAUNCH
     return hipGetLastError();
 }
 
