@@ -52,10 +52,12 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
 // One block = (utterance, head, 16 queries); scores for the 16 queries x T keys live in LDS.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATT_Q = 16;
+constexpr int ATT_THREADS = 1024;  // 16 waves: at batch 1 a launch has ~34 blocks, and every phase is a chain of LDS / memory latencies
+constexpr int ATT_PASSES = 1;      // (d, 4-query group) items per thread: head_dim <= 256
 
-__global__ __launch_bounds__(256) void rel_attention_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+__global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                             int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
-                                                            int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale) {
+                                                            int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
     const int len = lens ? lens[b] : tmax;
@@ -69,73 +71,110 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* q, int6
     const float* qb = q + (int64_t)b * q_bs + (int64_t)h * hd * q_cs;
     const float* kb = k + (int64_t)b * k_bs + (int64_t)h * hd * k_cs;
     const float* vb = v + (int64_t)b * v_bs + (int64_t)h * hd * v_cs;
-    for (int idx = tid; idx < ATT_Q * hd; idx += 256) {
+    for (int idx = tid; idx < ATT_Q * hd; idx += ATT_THREADS) {
         const int d = idx / ATT_Q, qi = idx % ATT_Q;
         const int i = i0 + qi;
         qs[qi * hd + d] = i < len ? qb[(int64_t)d * q_cs + i] * q_scale : 0.f;  // scaling: vits.cpp:296-297
     }
     __syncthreads();
-    for (int idx = tid; idx < ATT_Q * nrel; idx += 256) {
+    for (int idx = tid; idx < ATT_Q * nrel; idx += ATT_THREADS) {
         const int qi = idx / nrel, r = idx % nrel;
         float a = 0.f;
         for (int d = 0; d < hd; ++d) a += qs[qi * hd + d] * rel_k[r * hd + d];
         qe[idx] = a;
     }
     __syncthreads();
-    // scores: thread -> key j (coalesced along time), loops over the 16 queries
-    for (int j = tid; j < len; j += 256) {
-        float a[ATT_Q];
+    // scores: thread -> (key j, half of the 16 queries): lanes run along time (coalesced), 8 running dot products per thread. (One
+    // thread per key left 255 of 256 threads idle in a second pass for T = 257 = 128 interspersed ids.)
+    constexpr int QH = ATT_Q / 2;
+    for (int idx = tid; idx < 2 * len; idx += ATT_THREADS) {
+        const int half = idx >= len ? 1 : 0, j = idx - half * len;
+        const float* qh = qs + half * QH * hd;
+        float a[QH];
 #pragma unroll
-        for (int qi = 0; qi < ATT_Q; ++qi) a[qi] = 0.f;
+        for (int qi = 0; qi < QH; ++qi) a[qi] = 0.f;
         for (int d = 0; d < hd; ++d) {
             const float kv = kb[(int64_t)d * k_cs + j];
 #pragma unroll
-            for (int qi = 0; qi < ATT_Q; ++qi) a[qi] += qs[qi * hd + d] * kv;
+            for (int qi = 0; qi < QH; ++qi) a[qi] += qh[qi * hd + d] * kv;
         }
 #pragma unroll
-        for (int qi = 0; qi < ATT_Q; ++qi) {
-            const int r = j - (i0 + qi) + window;
+        for (int qi = 0; qi < QH; ++qi) {
+            const int qa = half * QH + qi;
+            const int r = j - (i0 + qa) + window;
             float s = a[qi];
-            if (r >= 0 && r < nrel) s += qe[qi * nrel + r];
-            sc[qi * lp + j] = s;
+            if (r >= 0 && r < nrel) s += qe[qa * nrel + r];
+            sc[qa * lp + j] = s;
         }
     }
     __syncthreads();
-    // softmax per query: 16 lanes per query
+    // softmax per query: one wave per query
     {
-        const int qi = tid >> 4, l16 = tid & 15;
+        const int qi = tid >> 6, l64 = tid & 63;
         float mx = -INFINITY;
-        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        for (int j = l64; j < len; j += 64) mx = fmaxf(mx, sc[qi * lp + j]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float sum = 0.f;
-        for (int j = l16; j < len; j += 16) {
+        for (int j = l64; j < len; j += 64) {
             const float e = expf(sc[qi * lp + j] - mx);
             sc[qi * lp + j] = e;
             sum += e;
         }
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const float inv = 1.0f / sum;
-        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
+        for (int j = l64; j < len; j += 64) sc[qi * lp + j] *= inv;
     }
     __syncthreads();
-    // o[qi][d] = sum_j p[qi][j] v[d][j] + windowed relative-value term; thread -> (d, 4-query group)
+    // o[qi][d] = sum_j p[qi][j] v[d][j] + windowed relative-value term; thread -> (d, 4-query group), up to ATT_PASSES items per thread.
+    // V goes through LDS in 64-key chunks (rows of v are time-major: lanes that differ in d would each touch their own cache line
+    // per key — 2/3 of this kernel's time at batch 1); the sums still run over j in ascending order.
     float* ob = out + (int64_t)b * o_bs + (int64_t)h * hd * o_cs;
-    for (int idx = tid; idx < hd * (ATT_Q / 4); idx += 256) {
-        const int d = idx % hd, qg = idx / hd;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const float* p0 = sc + (qg * 4 + 0) * lp;
-        const float* p1 = sc + (qg * 4 + 1) * lp;
-        const float* p2 = sc + (qg * 4 + 2) * lp;
-        const float* p3 = sc + (qg * 4 + 3) * lp;
-        const float* vr = vb + (int64_t)d * v_cs;
-        for (int j = 0; j < len; ++j) {
-            const float vv = vr[j];
-            a0 += p0[j] * vv;
-            a1 += p1[j] * vv;
-            a2 += p2[j] * vv;
-            a3 += p3[j] * vv;
+    const int vc = 1 << vshift, vp = vc + 1;  // keys per chunk (64 unless a long utterance's scores leave less LDS); odd pitch: lanes differ in d
+    float* vt = sc + ATT_Q * lp;       // [hd][vp]
+    float acc[ATT_PASSES][4];
+#pragma unroll
+    for (int ps = 0; ps < ATT_PASSES; ++ps)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[ps][u] = 0.f;
+    const int nitems = hd * (ATT_Q / 4);
+    for (int j0 = 0; j0 < len; j0 += vc) {
+        const int nj = len - j0 < vc ? len - j0 : vc;
+        for (int idx = tid; idx < (hd << vshift); idx += ATT_THREADS) {
+            const int d = idx >> vshift, jj = idx & (vc - 1);
+            vt[d * vp + jj] = jj < nj ? vb[(int64_t)d * v_cs + j0 + jj] : 0.f;
         }
-        float acc[4] = {a0, a1, a2, a3};
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < ATT_PASSES; ++ps) {
+            const int idx = tid + ps * ATT_THREADS;
+            if (idx < nitems) {
+                const int d = idx % hd, qg = idx / hd;
+                const float* p0 = sc + (qg * 4 + 0) * lp + j0;
+                const float* p1 = sc + (qg * 4 + 1) * lp + j0;
+                const float* p2 = sc + (qg * 4 + 2) * lp + j0;
+                const float* p3 = sc + (qg * 4 + 3) * lp + j0;
+                const float* vr = vt + d * vp;
+                float a0 = acc[ps][0], a1 = acc[ps][1], a2 = acc[ps][2], a3 = acc[ps][3];
+                for (int j = 0; j < nj; ++j) {
+                    const float vv = vr[j];
+                    a0 += p0[j] * vv;
+                    a1 += p1[j] * vv;
+                    a2 += p2[j] * vv;
+                    a3 += p3[j] * vv;
+                }
+                acc[ps][0] = a0;
+                acc[ps][1] = a1;
+                acc[ps][2] = a2;
+                acc[ps][3] = a3;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ps = 0; ps < ATT_PASSES; ++ps) {
+        const int idx = tid + ps * ATT_THREADS;
+        if (idx >= nitems) continue;
+        const int d = idx % hd, qg = idx / hd;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int qi = qg * 4 + u, i = i0 + qi;
@@ -145,7 +184,7 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* q, int6
                 const int j = i + r - window;
                 if (j >= 0 && j < len) rsum += sc[qi * lp + j] * rel_v[r * hd + d];
             }
-            ob[(int64_t)d * o_cs + i] = acc[u] + rsum;
+            ob[(int64_t)d * o_cs + i] = acc[ps][u] + rsum;
         }
     }
 }
@@ -153,15 +192,20 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* q, int6
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
                                 int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s) {
     const int lp = (tmax + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * lp);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    size_t lds = 0;
+    int vshift = 6;
+    for (; vshift >= 3; --vshift) {
+        lds = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * lp + (size_t)head_dim * ((1 << vshift) + 1));
+        if (lds <= 150 * 1024) break;
+    }
+    if (lds > 150 * 1024 || head_dim * (ATT_Q / 4) > ATT_THREADS * ATT_PASSES) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rel_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     dim3 grid((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
-    hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(256), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
-                       lens, head_dim, tmax, window, q_scale);
+    hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(ATT_THREADS), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
+                       lens, head_dim, tmax, window, q_scale, vshift);
     return hipGetLastError();
 }
 
@@ -367,41 +411,139 @@ struct DdsLayerParams {
     const int* lens;
     int channels, tmax, k, dil, nchunks;
     float eps;
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/dds_micro.hip): per-block phase timestamps, 100 MHz clock
+    unsigned long long* dbg;
+#endif
 };
+#ifdef VITS_PHASE_TIMING
+#define DDS_STAMP(i)                                                             \
+    do {                                                                         \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define DDS_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
 
-template <int ARITH>
+// MAXCH: upper bound of nchunks = channels / 32 — the wave's whole set of weight fragments is fetched into registers at the START
+// of the kernel (at batch 1 they come from HBM: six dependent round trips inside the MFMA loop were 1/3 of the kernel), and the
+// per-channel parameters go to LDS with the input tile, so that every later phase runs out of LDS and registers.
+template <int ARITH, int MAXCH>
 __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NT = 32;
+    constexpr int UB = 12;  // channels a thread works on at once (192 channels / 16 groups: one step)
     const int H = p.channels;
     const int pad = (p.k * p.dil - p.dil) / 2;  // vits.cpp:660
     const int xw = NT + 2 * pad;
     float* xt = sm;                        // [H][xw]   input tile with halo (also the residual)
     float* ht = xt + ((H * xw + 3) & ~3);  // [H][NT]   depthwise output -> gelu(LN1) -> pointwise output
     float* red = ht + H * NT;              // [2][LN_GROUPS][NT]
-    dds_int4v* h16 = reinterpret_cast<dds_int4v*>(red + 2 * LN_GROUPS * NT);  // [H/8][NT] 16-bit operand slots (ARITH != 0)
+    float* prm = red + 2 * LN_GROUPS * NT;  // [6][H] dw_b, g1, b1, pw_b, g2, b2; then [H][k] dw_w
+    dds_int4v* h16 = reinterpret_cast<dds_int4v*>(prm + ((6 * H + H * p.k + 3) & ~3));  // [H/8][NT] 16-bit operand slots (ARITH != 0)
     const int b = blockIdx.y, t0 = blockIdx.x * NT;
+    DDS_STAMP(0);
     const int len = p.lens ? p.lens[b] : p.tmax;
     if (t0 >= len) return;
     const int tid = threadIdx.x, tl = tid & 31, gq = tid >> 5;
     const int lane = tid & 63, wid = tid >> 6;
+    const int nmt = H >> 5;
+    DDS_STAMP(1);
+    // ---- everything this block reads from memory, issued at once: parameters and the input tile first, the weight fragments behind
+    // them (147 KB per block in fp32: they may still be in flight while the depthwise phase runs — memory returns in order) ----
+    float pv[2][7];
     {
+        constexpr int NTH = 32 * LN_GROUPS;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = tid + r * NTH < H ? tid + r * NTH : 0;
+            pv[r][0] = p.dw_b[c];
+            pv[r][1] = p.g1[c];
+            pv[r][2] = p.b1[c];
+            pv[r][3] = p.pw_b[c];
+            pv[r][4] = p.g2[c];
+            pv[r][5] = p.b2[c];
+        }
+    }
+    float4 af[ARITH == 0 ? MAXCH * 4 : 1];
+    dds_int4v ah[ARITH != 0 ? MAXCH * 2 : 1];
+    {
+        // flat index over [H][xw], up to 24 loads in flight per thread (a load-then-store loop exposed one memory latency per element)
         const float* xb = p.x + (int64_t)b * p.x_bs;
-        for (int c = gq; c < H; c += LN_GROUPS)
-            for (int i = tl; i < xw; i += 32) {
+        constexpr int NTH = 32 * LN_GROUPS, XB = 24;
+        const int total = H * xw, dq = NTH / xw, dr = NTH % xw;
+        int c = tid / xw, i = tid - c * xw;
+        for (int base = tid; base < total || base == tid; base += XB * NTH) {
+            float v[XB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
                 const int t = t0 - pad + i;
-                xt[c * xw + i] = (t >= 0 && t < len) ? xb[(int64_t)c * p.x_cs + t] : 0.f;
+                v[u] = (base + u * NTH < total && t >= 0 && t < len) ? xb[(int64_t)c * p.x_cs + t] : 0.f;
+                c += dq;
+                i += dr;
+                if (i >= xw) {
+                    i -= xw;
+                    ++c;
+                }
             }
+            if (base == tid) {
+                float wv[2] = {0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (tid + r * NTH < H * p.k) wv[r] = p.dw_w[tid + r * NTH];
+                if (wid < nmt) {
+                    if constexpr (ARITH == 0) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (size_t)wid * p.nchunks * 4 * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < MAXCH * 4; ++q) af[q] = wp4[(q < p.nchunks * 4 ? q : 0) * 64];
+                    } else {
+                        const dds_int4v* wq = reinterpret_cast<const dds_int4v*>(p.wp16) + (size_t)wid * p.nchunks * 2 * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < MAXCH * 2; ++q) ah[q] = wq[(q < p.nchunks * 2 ? q : 0) * 64];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (tid + r * NTH < H) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) prm[q * H + tid + r * NTH] = pv[r][q];
+                    }
+                    if (tid + r * NTH < H * p.k) prm[6 * H + tid + r * NTH] = wv[r];
+                }
+                for (int q = tid + 2 * NTH; q < H * p.k; q += NTH) prm[6 * H + q] = p.dw_w[q];  // (k > 5 at 192 channels)
+            }
+#pragma unroll
+            for (int u = 0; u < XB; ++u)
+                if (base + u * NTH < total) xt[base + u * NTH] = v[u];
+        }
     }
     __syncthreads();
+    DDS_STAMP(2);
+    const float *dw_b = prm, *g1 = prm + H, *b1 = prm + 2 * H, *pw_b = prm + 3 * H, *g2 = prm + 4 * H, *b2 = prm + 5 * H, *dw_w = prm + 6 * H;
     // ---- depthwise conv + LayerNorm 1 + gelu (dds_depthwise_kernel, same expressions) ----
     {
+        // (UB channels per step: the LDS reads of the chains overlap; every chain and the order of s are those of the one-channel loop)
+        constexpr int CS = LN_GROUPS;
         float s = 0.f;
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            float a = p.dw_b[c];
-            for (int j = 0; j < p.k; ++j) a += round_arith(p.dw_w[c * p.k + j], ARITH) * round_arith(xt[c * xw + tl + j * p.dil], ARITH);
-            ht[c * NT + tl] = a;
-            s += a;
+        for (int c0 = gq; c0 < H; c0 += UB * CS) {
+            float a[UB];
+            int cc[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                cc[u] = c0 + u * CS < H ? c0 + u * CS : c0;
+                a[u] = dw_b[cc[u]];
+            }
+            for (int j = 0; j < p.k; ++j) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) a[u] += round_arith(dw_w[cc[u] * p.k + j], ARITH) * round_arith(xt[cc[u] * xw + tl + j * p.dil], ARITH);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (c0 + u * CS < H) {
+                    ht[cc[u] * NT + tl] = a[u];
+                    s += a[u];
+                }
         }
         red[gq * NT + tl] = s;
         __syncthreads();
@@ -410,9 +552,16 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
         for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * NT + tl];
         const float mean = msum / (float)H;
         float vs = 0.f;
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            const float d = ht[c * NT + tl] - mean;
-            vs += d * d;
+        for (int c0 = gq; c0 < H; c0 += UB * LN_GROUPS) {
+            float hv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) hv[u] = ht[(c0 + u * LN_GROUPS < H ? c0 + u * LN_GROUPS : c0) * NT + tl];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (c0 + u * LN_GROUPS < H) {
+                    const float d = hv[u] - mean;
+                    vs += d * d;
+                }
         }
         red[(LN_GROUPS + gq) * NT + tl] = vs;
         __syncthreads();
@@ -421,76 +570,101 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
         for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * NT + tl];
         const float var = vsum / (float)H;
         const float inv = 1.0f / sqrtf(var + p.eps);
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            const float v = gelu_erf((ht[c * NT + tl] - mean) * inv * p.g1[c] + p.b1[c]);
-            if constexpr (ARITH == 0) {
-                ht[c * NT + tl] = v;
-            } else {
-                uint16_t* slot = reinterpret_cast<uint16_t*>(h16 + (c >> 3) * NT + tl);
-                if constexpr (ARITH == 2) {
-                    const _Float16 hv = (_Float16)v;
-                    slot[c & 7] = __builtin_bit_cast(uint16_t, hv);
+        for (int c0 = gq; c0 < H; c0 += UB * LN_GROUPS) {
+            float hv[UB], gg[UB], bb[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + u * LN_GROUPS < H ? c0 + u * LN_GROUPS : c0;
+                hv[u] = ht[c * NT + tl];
+                gg[u] = g1[c];
+                bb[u] = b1[c];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + u * LN_GROUPS;
+                if (c >= H) continue;
+                float v = gelu_erf((hv[u] - mean) * inv * gg[u] + bb[u]);
+                if constexpr (ARITH == 0) {
+                    ht[c * NT + tl] = v;
                 } else {
-                    const __bf16 hv = (__bf16)v;
-                    slot[c & 7] = __builtin_bit_cast(uint16_t, hv);
+                    // (the three-launch path stores the fp32 value and rounds it in another kernel; left alone, hipcc folds gelu's last
+                    // product into the conversion — v_fma_mixlo_f16, ONE rounding instead of two)
+                    asm volatile("" : "+v"(v));
+                    uint16_t* slot = reinterpret_cast<uint16_t*>(h16 + (c >> 3) * NT + tl);
+                    if constexpr (ARITH == 2) {
+                        const _Float16 h = (_Float16)v;
+                        slot[c & 7] = __builtin_bit_cast(uint16_t, h);
+                    } else {
+                        const __bf16 h = (__bf16)v;
+                        slot[c & 7] = __builtin_bit_cast(uint16_t, h);
+                    }
                 }
             }
         }
     }
     __syncthreads();
+    DDS_STAMP(3);
     // ---- pointwise conv on the matrix cores: wave w owns output rows 32w..32w+31 (the MFMA chain of conv_mfma.hip / conv16.hip) ----
-    const int nmt = H >> 5;
     dds_floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (wid < nmt) {
         if constexpr (ARITH == 0) {
-            const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (size_t)wid * p.nchunks * 4 * 64 + lane;
             const float* bcol = ht + (lane >> 5) * NT + (lane & 31);
-            for (int c = 0; c < p.nchunks; ++c) {
-                float4 a[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) a[g] = wp4[(c * 4 + g) * 64];
+            for (int c = 0; c < MAXCH; ++c) {
+                if (c < p.nchunks) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float* bb = bcol + (c * 32 + 8 * g) * NT;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bb[0 * NT], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bb[2 * NT], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bb[4 * NT], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bb[6 * NT], acc, 0, 0, 0);
+                    for (int g = 0; g < 4; ++g) {
+                        const float* bb = bcol + (c * 32 + 8 * g) * NT;
+                        const float4 a = af[c * 4 + g];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb[0 * NT], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb[2 * NT], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb[4 * NT], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb[6 * NT], acc, 0, 0, 0);
+                    }
                 }
             }
         } else {
-            const dds_int4v* wq = reinterpret_cast<const dds_int4v*>(p.wp16) + (size_t)wid * p.nchunks * 2 * 64 + lane;
             const dds_int4v* bcol = h16 + (lane >> 5) * NT + (lane & 31);
-            for (int c = 0; c < p.nchunks; ++c) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const dds_int4v a = wq[(c * 2 + kk) * 64];
-                    const dds_int4v bq = bcol[(c * 4 + 2 * kk) * NT];
-                    if constexpr (ARITH == 1)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dds_bf16x8, a), __builtin_bit_cast(dds_bf16x8, bq), acc, 0, 0, 0);
-                    else
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dds_half8, a), __builtin_bit_cast(dds_half8, bq), acc, 0, 0, 0);
+            for (int c = 0; c < MAXCH; ++c) {
+                if (c < p.nchunks) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const dds_int4v a = ah[c * 2 + kk];
+                        const dds_int4v bq = bcol[(c * 4 + 2 * kk) * NT];
+                        if constexpr (ARITH == 1)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dds_bf16x8, a), __builtin_bit_cast(dds_bf16x8, bq), acc, 0, 0, 0);
+                        else
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dds_half8, a), __builtin_bit_cast(dds_half8, bq), acc, 0, 0, 0);
+                    }
                 }
             }
         }
     }
+    DDS_STAMP(4);
     __syncthreads();  // (fp32: every wave is done reading ht)
+    DDS_STAMP(5);
     if (wid < nmt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wid * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-            ht[row * NT + (lane & 31)] = acc[r] + p.pw_b[row];
+            ht[row * NT + (lane & 31)] = acc[r] + pw_b[row];
         }
     }
     __syncthreads();
+    DDS_STAMP(6);
     // ---- LayerNorm 2 + gelu + residual (add_layer_norm_kernel with post_gelu and add_to, same expressions) ----
     {
         float s = 0.f;
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            const float v = ht[c * NT + tl];
-            s += v;
+        for (int c0 = gq; c0 < H; c0 += UB * LN_GROUPS) {
+            float hv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) hv[u] = ht[(c0 + u * LN_GROUPS < H ? c0 + u * LN_GROUPS : c0) * NT + tl];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (c0 + u * LN_GROUPS < H) s += hv[u];
         }
         red[gq * NT + tl] = s;
         __syncthreads();
@@ -499,9 +673,16 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
         for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * NT + tl];
         const float mean = msum / (float)H;
         float vs = 0.f;
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            const float d = ht[c * NT + tl] - mean;
-            vs += d * d;
+        for (int c0 = gq; c0 < H; c0 += UB * LN_GROUPS) {
+            float hv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) hv[u] = ht[(c0 + u * LN_GROUPS < H ? c0 + u * LN_GROUPS : c0) * NT + tl];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (c0 + u * LN_GROUPS < H) {
+                    const float d = hv[u] - mean;
+                    vs += d * d;
+                }
         }
         red[(LN_GROUPS + gq) * NT + tl] = vs;
         __syncthreads();
@@ -513,13 +694,36 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
         const int t = t0 + tl;
         if (t >= len) return;
         float* yb = p.y + (int64_t)b * p.y_bs + t;
-        for (int c = gq; c < H; c += LN_GROUPS) {
-            float v = (ht[c * NT + tl] - mean) * inv * p.g2[c] + p.b2[c];
-            v = gelu_erf(v);
-            asm volatile("" : "+v"(v));  // (the three-launch path adds in a separate statement behind a branch: no fma of gelu's last product with this add)
-            yb[(int64_t)c * p.y_cs] = xt[c * xw + pad + tl] + v;
+        for (int c0 = gq; c0 < H; c0 += UB * LN_GROUPS) {
+            float hv[UB], gg[UB], bb[UB], xr[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + u * LN_GROUPS < H ? c0 + u * LN_GROUPS : c0;
+                hv[u] = ht[c * NT + tl];
+                gg[u] = g2[c];
+                bb[u] = b2[c];
+                xr[u] = xt[c * xw + pad + tl];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + u * LN_GROUPS;
+                if (c >= H) continue;
+                float v = (hv[u] - mean) * inv * gg[u] + bb[u];
+                v = gelu_erf(v);
+                asm volatile("" : "+v"(v));  // (the three-launch path adds in a separate statement behind a branch: no fma of gelu's last product with this add)
+                yb[(int64_t)c * p.y_cs] = xr[u] + v;
+            }
         }
+        DDS_STAMP(7);
     }
+}
+
+#ifdef VITS_PHASE_TIMING
+unsigned long long* g_dds_dbg = nullptr;
+#endif
+static size_t dds_layer_lds(int channels, int k, int dil) {
+    const int xw = 32 + (k * dil - dil);
+    return sizeof(float) * (((size_t)channels * xw + 3) / 4 * 4 + (size_t)channels * 32 + 2 * 32 * LN_GROUPS + ((size_t)channels * (6 + k) + 3) / 4 * 4) + (size_t)channels * 64;
 }
 
 bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int arith) {
@@ -527,9 +731,7 @@ bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int
     if (pw.cin != channels || pw.cout != channels || pw.kt != 1 || pw.epi != EPI_STD || !pw.bias) return false;
     if (arith == VITS_ARITH_F32 ? !pw.wp : !pw.wp16) return false;
     if (k < 1 || dil < 1 || ((k * dil - dil) & 1)) return false;
-    const int xw = 32 + (k * dil - dil);
-    const size_t lds = sizeof(float) * (((size_t)channels * xw + 3) / 4 * 4 + (size_t)channels * 32 + 2 * 32 * LN_GROUPS) + (size_t)channels * 64;
-    return lds <= 150 * 1024;
+    return dds_layer_lds(channels, k, dil) <= 150 * 1024;
 }
 
 hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
@@ -558,22 +760,32 @@ hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const f
     p.dil = dil;
     p.nchunks = pw.nchunks;
     p.eps = eps;
-    const int xw = 32 + (k * dil - dil);
-    const size_t lds = sizeof(float) * (((size_t)channels * xw + 3) / 4 * 4 + (size_t)channels * 32 + 2 * 32 * LN_GROUPS) + (size_t)channels * 64;
+#ifdef VITS_PHASE_TIMING
+    p.dbg = g_dds_dbg;
+#endif
+    const size_t lds = dds_layer_lds(channels, k, dil);
     dim3 grid((tmax + 31) / 32, batch);
-#define VITS_DDS_LAUNCH(A)                                                                                                             \
+#define VITS_DDS_LAUNCH1(A, M)                                                                                                         \
     do {                                                                                                                               \
         static std::atomic<bool> big{false};                                                                                          \
         if (lds > 64 * 1024 && !big.load(std::memory_order_acquire)) {                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dds_layer_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dds_layer_kernel<A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return e;                                                                                             \
             big.store(true, std::memory_order_release);                                                                                \
         }                                                                                                                              \
-        hipLaunchKernelGGL(dds_layer_kernel<A>, grid, dim3(32 * LN_GROUPS), lds, s, p);                                                \
+        hipLaunchKernelGGL((dds_layer_kernel<A, M>), grid, dim3(32 * LN_GROUPS), lds, s, p);                                           \
+    } while (0)
+#define VITS_DDS_LAUNCH(A)                       \
+    do {                                         \
+        if (pw.nchunks <= 2) VITS_DDS_LAUNCH1(A, 2);      \
+        else if (pw.nchunks <= 4) VITS_DDS_LAUNCH1(A, 4); \
+        else if (pw.nchunks <= 6) VITS_DDS_LAUNCH1(A, 6); \
+        else VITS_DDS_LAUNCH1(A, 8);             \
     } while (0)
     if (arith == VITS_ARITH_F32) VITS_DDS_LAUNCH(0);
     else if (arith == VITS_ARITH_BF16) VITS_DDS_LAUNCH(1);
     else VITS_DDS_LAUNCH(2);
+#undef VITS_DDS_LAUNCH1
 #undef VITS_DDS_LAUNCH
     return hipGetLastError();
 }
