@@ -66,6 +66,7 @@ struct ConvParams {
     int cin, cout, rows, nchunks;
     int dil, pad_l, xw, lds_off;
     int nbuf;  // LDS input buffers of the wave-specialised path: 2, or 3 when a chunk of MFMA work is shorter than the DMA latency
+    int oneshot;  // small tiles on latency-bound launches: one buffer per chunk, filled by ALL five waves at once (see the kernel)
     int pre_act;
     float slope;
     int post_act;
@@ -157,9 +158,16 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     // 4-aligned time below tile_start; the compute waves then read their B operands `shift` floats further right
     const bool x4 = DB && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0) && ((p.x_cs & 3) == 0);
     const int shift = x4 ? (tile_start & 3) : 0;
+    // Latency-bound launches (batch 1 / short inputs: at most ~2 blocks per CU, on the small tiles). Phase timing of the 1x1 convs
+    // there: the compute waves wait ~2.4 us at EVERY chunk barrier for 0.5 us of MFMA work — one wave's LDS-DMA stream delivers a
+    // 16 KB fill in about that time however many are queued. In this mode there is one LDS buffer per chunk, all five waves issue
+    // the fills (chunk c by wave c mod 5) and post-process their own chunks, and the block meets at ONE barrier; the compute waves
+    // then run the whole K range unsynchronised. Same accumulation order.
+    constexpr bool COOP = DB && MR * NR <= 2;
+    const bool oneshot = COOP && p.oneshot;
     if constexpr (DB) {
-        if (wid == 4) {
-            // ------------------------------- producer wave -------------------------------------------------------
+        if (wid == 4 || oneshot) {
+            // ------------------------------- producer wave (every wave in the one-shot mode) ----------------------
             // barrier protocol (n = nchunks, both sides execute n+1 barriers):
             //   producer: fill(0); B0; for c: { fill(c+1) into buffer (c+1)&1; B(c+1) }
             //   compute : B0; for c: { MFMA on buffer c&1; B(c+1) }
@@ -258,7 +266,16 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
             // (no barrier after the LAST chunk: nothing reuses its buffer. The producer therefore retires a whole chunk
             // before the block does, and with it the fifth wave that keeps a second block from being placed on this CU —
             // the next block's launch and prologue overlap this block's last chunk instead of following its K loop)
-            if (p.nbuf == 2) {
+            if (oneshot) {
+                for (int c = wid; c < p.nchunks; c += 5) issue(c, c);
+                if (wid == 4) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int c = wid; c < p.nchunks; c += 5) finish(c, c);
+                    __syncthreads();
+                }
+                // (compute waves: bias and weight-fragment prologue first, so that its memory latency overlaps the DMA; then the
+                // same wait + post-processing and the barrier — "one-shot, compute side" below)
+            } else if (p.nbuf == 2) {
                 issue(0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 finish(0, 0);
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     b2 = b2 == 2 ? 0 : b2 + 1;
                 }
             }
-            return;
+            if (wid == 4) return;
         }
     }
 
@@ -469,6 +486,47 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     };
     if constexpr (DB) {
         // compute waves of the wave-specialised path (see the producer above)
+        if constexpr (COOP) {
+            if (oneshot) {
+                // one-shot, compute side: what the producer's finish() does, for this wave's chunks
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int ts = tile_start - shift;
+                const bool interior = ts >= 0 && ts + XWP <= len_in;
+                constexpr int NMP = (XWP + 63) / 64;
+                bool oob[NMP];
+#pragma unroll
+                for (int m = 0; m < NMP; ++m) {
+                    const int t = ts + lane + 64 * m;
+                    oob[m] = t < 0 || t >= len_in;
+                }
+                for (int c = wid; c < p.nchunks; c += 5) {
+                    float* lbase = xs + c * (CK * XWP);
+                    if (!LRELU_AT_READ && p.pre_act) {
+                        float4* l4 = reinterpret_cast<float4*>(lbase);
+                        constexpr int N4 = CK * XWP / 4;
+#pragma unroll 4
+                        for (int i = lane; i < N4; i += 64) {
+                            float4 v = l4[i];
+                            v.x = fmaxf(v.x, v.x * p.slope);
+                            v.y = fmaxf(v.y, v.y * p.slope);
+                            v.z = fmaxf(v.z, v.z * p.slope);
+                            v.w = fmaxf(v.w, v.w * p.slope);
+                            l4[i] = v;
+                        }
+                    }
+                    if (!interior || (c + 1) * CK > p.cin) {
+#pragma unroll 4
+                        for (int r = 0; r < CK; ++r) {
+                            const bool chbad = c * CK + r >= p.cin;
+#pragma unroll
+                            for (int m = 0; m < NMP; ++m)
+                                if ((oob[m] || chbad) && (XWP % 64 == 0 || 64 * m + lane < XWP)) lbase[r * XWP + 64 * m + lane] = 0.f;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
         __syncthreads();
         VITS_STAMP(1);
         auto k_loop = [&](auto lr) __attribute__((always_inline)) {
@@ -482,7 +540,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                     if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
                 }
 #endif
-                if (c + 1 < p.nchunks) __syncthreads();  // (see the producer: the last chunk needs no barrier)
+                if (c + 1 < p.nchunks && !oneshot) __syncthreads();  // (see the producer: the last chunk needs no barrier)
 #ifdef VITS_PHASE_TIMING
                 if (tid == 0 && c < 4) {
                     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -980,6 +1038,15 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
         const bool short_chunk = w.kt * t3.mr * t3.nr * 1024 < 8000 && w.nchunks >= 3 && bn == 128;
         p.nbuf = nbuf_env == 2 || nbuf_env == 3 ? nbuf_env : (short_chunk ? 3 : 2);
         if (w.nchunks < 2 || (size_t)p.nbuf * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * 4 > 150 * 1024) p.nbuf = 2;
+        // latency-bound launch on a small tile whose whole input fits in LDS: cooperative one-shot fill (see the kernel)
+        static const bool no_oneshot = getenv("VITS_NO_ONESHOT") != nullptr;
+        const int64_t nblocks = (int64_t)((ncols_max + bn - 1) / bn) * ((w.mtiles_used + t3.wm * t3.mr - 1) / (t3.wm * t3.mr)) * c.batch;
+        p.oneshot = 0;
+        if (!no_oneshot && t3.mr * t3.nr <= 2 && nblocks <= 512 && w.nchunks >= 2 &&
+            (size_t)w.nchunks * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * 4 <= 150 * 1024) {
+            p.oneshot = 1;
+            p.nbuf = w.nchunks;
+        }
     }
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
