@@ -64,6 +64,7 @@ struct ConvParams {
     const int* len_out;
     int t_in, t_out;
     int cin, cout, rows, nchunks;
+    int mtiles;  // 32-row tiles in the packed weight array (a block may own row tiles past it: their fragments are read from the last one)
     int dil, pad_l, xw, lds_off;
     int nbuf;  // LDS input buffers of the wave-specialised path: 2, or 3 when a chunk of MFMA work is shorter than the DMA latency
     int oneshot;  // small tiles on latency-bound launches: one buffer per chunk, filled by ALL five waves at once (see the kernel)
@@ -348,10 +349,10 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
     int wvoff[MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)(mt0 + mr) * tile4 + lane) * 16);
+    for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)(mt0 + mr < p.mtiles ? mt0 + mr : p.mtiles - 1) * tile4 + lane) * 16);
     typedef float vfloat4 __attribute__((ext_vector_type(4)));
     // (the small single-buffer kernels run 3-5 blocks per CU and are not MFMA-issue bound: plain loads measured 3-6 % faster there)
-    const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.wp) + (size_t)mt0 * tile4 + lane;
+    const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.wp) + (size_t)(mt0 + MR <= p.mtiles ? mt0 : 0) * tile4 + lane;
     auto load_a = [&](int mr, int step) __attribute__((always_inline)) -> float4 {
         if constexpr (DB) {
             const vfloat4 v = __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
@@ -818,6 +819,7 @@ static TileShape tile_shape(int tile) {
         case TILE_64x256: return {1, 4, 2, 2};
         case TILE_32x256: return {1, 4, 1, 2};
         case TILE_64x64: return {1, 4, 2, 1};  // 64 x 128
+        case TILE_NARROW: return {4, 1, 1, 1};  // 128 x 32: four row tiles of ONE 32-column strip (gate: {4, 1, 2, 1})
         default: return {1, 4, 1, 1};          // TILE_32x64: 32 x 128
     }
 }
@@ -892,7 +894,8 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
 
 template <int KT, int DIL, bool DB, int EPI>
 static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
-    const TileShape ts = tile_shape(tile);
+    TileShape ts = tile_shape(tile);
+    if (tile == TILE_NARROW && EPI == EPI_GATE) ts.mr = 2;
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
@@ -919,6 +922,15 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
             if (EPI == EPI_GATE) return hipErrorInvalidValue;
             VITS_LAUNCH(1, 4, 1, 2);
             break;
+        case TILE_NARROW:
+            // (only where launch_conv chooses it: encoder / flow convs on the producer-wave path)
+            if constexpr (DB && DIL == 1 && ((EPI == EPI_STD && KT <= 3) || (EPI == EPI_GATE && KT == 5))) {
+                if constexpr (EPI == EPI_GATE) VITS_LAUNCH(4, 1, 2, 1);
+                else VITS_LAUNCH(4, 1, 1, 1);
+                break;
+            } else {
+                return hipErrorInvalidValue;
+            }
         default:
             if (EPI == EPI_GATE) return hipErrorInvalidValue;
             VITS_LAUNCH(1, 4, 1, 1);
@@ -988,6 +1000,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.cout = w.cout;
     p.rows = w.rows;
     p.nchunks = w.nchunks;
+    p.mtiles = w.mtiles;
     p.pre_act = c.pre_act;
     p.slope = c.slope;
     p.post_act = c.post_act;
@@ -1017,7 +1030,20 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
         if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
         if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
     }
-    const TileShape ts = tile_shape(tile);
+    if (c.tile < 0 && w.epi != EPI_CONVT) {
+        // tiny grids (the encoder / duration predictor / flow at batch 1: 6-18 blocks of the 128-column tiles): every block of a
+        // 128-column tile streams the WHOLE input in through its one producer wave, and that stream, not the MFMA chain, is the
+        // launch time (768 -> 192 FFN conv, k = 3, 128 tokens: 78 us for a 31 us chain). Blocks of four row tiles x ONE 32-column
+        // strip need a quarter of the input each. Same per-output accumulation order (the tile shape never changes it).
+        static const bool no_narrow = getenv("VITS_NO_NARROW") != nullptr;
+        const int dil_eff = w.kt == 1 ? 1 : c.dil;
+        const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
+        const TileShape t2 = tile_shape(tile);
+        const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
+        if (!no_narrow && shape_ok && nb <= 128) tile = TILE_NARROW;
+    }
+    TileShape ts = tile_shape(tile);
+    if (tile == TILE_NARROW && w.epi == EPI_GATE) ts.mr = 2;
     const int bn = ts.wn * ts.nr * 32;
     if (w.epi == EPI_CONVT) {
         p.dil = -1;  // tap m reads x[q - m]
@@ -1034,7 +1060,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
         // third LDS buffer (DMA two chunks ahead) where a chunk is less MFMA work than a DMA round trip (~2.5 us = 6k cycles):
         // taps x (MFMAs per k-step) x 16 k-steps x 64 cycles
         static const int nbuf_env = getenv("VITS_NBUF") ? atoi(getenv("VITS_NBUF")) : 0;
-        const TileShape t3 = tile_shape(tile);
+        const TileShape t3 = ts;
         const bool short_chunk = w.kt * t3.mr * t3.nr * 1024 < 8000 && w.nchunks >= 3 && bn == 128;
         p.nbuf = nbuf_env == 2 || nbuf_env == 3 ? nbuf_env : (short_chunk ? 3 : 2);
         if (w.nchunks < 2 || (size_t)p.nbuf * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * 4 > 150 * 1024) p.nbuf = 2;

@@ -21,7 +21,14 @@ struct TensorRef {
 
 // ---- MFMA convolution ---------------------------------------------------------------------------------
 enum ConvEpilogue : int { EPI_STD = 0, EPI_GATE = 1, EPI_CONVT = 2 };
-enum ConvTile : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x64 = 3, TILE_32x64 = 4 };
+enum ConvTile : int {
+    TILE_128x128 = 0,
+    TILE_64x256 = 1,
+    TILE_32x256 = 2,
+    TILE_64x64 = 3,
+    TILE_32x64 = 4,
+    TILE_NARROW = 5  // 128 rows x 32 columns (256 x 32 for the gated conv): tiny grids only, see choose in launch_conv
+};
 
 // Weights pre-packed at load time in exact MFMA A-fragment order (see conv_mfma.hip), resident in HBM.
 struct PackedConv {
