@@ -338,6 +338,16 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
             else idx = (mt0 + mr) * 4 + g;  // stride-8 transposed conv: 8 phases = 8 GEMM rows per output channel
             bias_w[mr][g] = p.bias ? p.bias[idx < p.cout ? idx : p.cout - 1] : 0.f;
         }
+    // gated conv on MR = 1 tiles (the 128 x 32 tile): the tanh rows and the sigmoid rows of a channel group are two WAVES (even / odd
+    // row tile); the even wave also needs the sigmoid rows' bias
+    float bias_s[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_GATE && MR == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int idx = (mt0 / 2) * 32 + 8 * g + (lane & 3) + 4 * (lane >> 5) + p.cout / 2;
+            bias_s[g] = p.bias ? p.bias[idx < p.cout ? idx : p.cout - 1] : 0.f;
+        }
+    }
 
     const float slope_eff = p.pre_act ? p.slope : 1.0f;  // leaky_relu(x) = max(x, slope*x); slope 1 = identity
     const int krow = lane >> 5;
@@ -696,7 +706,27 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
             }
         }
     } else if (EPI == EPI_GATE) {
-        // packed tile 2i = tanh rows (channels 32i..), tile 2i+1 = sigmoid rows (half + 32i..): MR == 2
+        // packed tile 2i = tanh rows (channels 32i..), tile 2i+1 = sigmoid rows (half + 32i..). MR == 2: both in this wave.
+        // MR == 1 (128 x 32 tile, tiny grids: half the MFMA chain per wave): the odd wave hands its accumulators to the even wave
+        // of the pair through LDS, lane for lane (both hold the same (row, column) positions), and retires.
+        float sreg[NR][16];
+        if constexpr (MR == 1 && NR == 1 && WN == 1 && (WM & 1) == 0) {  // (other MR == 1 shapes are never launched for the gated conv)
+            float* ex = xs + (wm >> 1) * (16 * 64);
+            __syncthreads();  // every compute wave has left the K loop: the input buffers are free
+            if (wm & 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[r * 64 + lane] = acc[0][0][r];
+            }
+            __syncthreads();
+            if (wm & 1) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sreg[0][r] = ex[r * 64 + lane];
+        } else {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sreg[nr][r] = acc[MR - 1][nr][r];
+        }
         float* yb = p.y + (int64_t)b * p.y_bs;
         const int half = p.cout / 2;
         const int chbase = (mt0 / 2) * 32;
@@ -721,11 +751,11 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float a0 = acc[0][nr][4 * g], a1 = acc[0][nr][4 * g + 1], a2 = acc[0][nr][4 * g + 2], a3 = acc[0][nr][4 * g + 3];
-                    float s0 = acc[MR - 1][nr][4 * g], s1 = acc[MR - 1][nr][4 * g + 1], s2 = acc[MR - 1][nr][4 * g + 2], s3 = acc[MR - 1][nr][4 * g + 3];
+                    float s0 = sreg[nr][4 * g], s1 = sreg[nr][4 * g + 1], s2 = sreg[nr][4 * g + 2], s3 = sreg[nr][4 * g + 3];
                     xpose(a0, a1, a2, a3);
                     xpose(s0, s1, s2, s3);
                     const int ch = chbase + 8 * g + qi + rowoff;
-                    const float b0 = bias_w[0][g], b1 = bias_w[MR - 1][g];
+                    const float b0 = bias_w[0][g], b1 = MR == 1 ? bias_s[g] : bias_w[MR - 1][g];
                     float4 o;
                     o.x = tanhf(a0 + b0) * (1.0f / (1.0f + expf(-(s0 + b1))));
                     o.y = tanhf(a1 + b0) * (1.0f / (1.0f + expf(-(s1 + b1))));
@@ -745,7 +775,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                 const int t = colbase + nr * 32;
                 if (t >= ncols) continue;
                 const float ta = tanhf(acc[0][nr][r] + b0);
-                const float sg = 1.0f / (1.0f + expf(-(acc[MR - 1][nr][r] + b1)));
+                const float sg = 1.0f / (1.0f + expf(-(sreg[nr][r] + b1)));
                 yb[(int64_t)ch * p.y_cs + t] = ta * sg;
             }
         }
@@ -819,7 +849,7 @@ static TileShape tile_shape(int tile) {
         case TILE_64x256: return {1, 4, 2, 2};
         case TILE_32x256: return {1, 4, 1, 2};
         case TILE_64x64: return {1, 4, 2, 1};  // 64 x 128
-        case TILE_NARROW: return {4, 1, 1, 1};  // 128 x 32: four row tiles of ONE 32-column strip (gate: {4, 1, 2, 1})
+        case TILE_NARROW: return {4, 1, 1, 1};  // 128 x 32: four row tiles of ONE 32-column strip
         default: return {1, 4, 1, 1};          // TILE_32x64: 32 x 128
     }
 }
@@ -894,8 +924,7 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
 
 template <int KT, int DIL, bool DB, int EPI>
 static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p, int ncols_max, int batch, hipStream_t s) {
-    TileShape ts = tile_shape(tile);
-    if (tile == TILE_NARROW && EPI == EPI_GATE) ts.mr = 2;
+    const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     const int bm_tiles = ts.wm * ts.mr;
     dim3 grid((ncols_max + bn - 1) / bn, (w.mtiles_used + bm_tiles - 1) / bm_tiles, batch);
@@ -925,8 +954,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
         case TILE_NARROW:
             // (only where launch_conv chooses it: encoder / flow convs on the producer-wave path)
             if constexpr (DB && DIL == 1 && ((EPI == EPI_STD && KT <= 3) || (EPI == EPI_GATE && KT == 5))) {
-                if constexpr (EPI == EPI_GATE) VITS_LAUNCH(4, 1, 2, 1);
-                else VITS_LAUNCH(4, 1, 1, 1);
+                VITS_LAUNCH(4, 1, 1, 1);  // (gated conv: tanh / sigmoid row tiles on wave pairs, see the epilogue)
                 break;
             } else {
                 return hipErrorInvalidValue;
@@ -1042,8 +1070,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
         const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
         if (!no_narrow && shape_ok && nb <= 128) tile = TILE_NARROW;
     }
-    TileShape ts = tile_shape(tile);
-    if (tile == TILE_NARROW && w.epi == EPI_GATE) ts.mr = 2;
+    const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     if (w.epi == EPI_CONVT) {
         p.dil = -1;  // tap m reads x[q - m]
