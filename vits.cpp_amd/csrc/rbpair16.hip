@@ -63,23 +63,29 @@ struct RbPairParams {
     int scale_div;
 };
 
-template <int KT, int DIL, int C, int NR, bool BF>
-__global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
+// ROWS = false: every wave owns all C output rows of its own 32 * NR columns (C <= 64: few rows, wide column strips).
+// ROWS = true (C = 128): every wave owns ONE 32-row tile for ALL 32 * NR columns of the block, as conv16's 128 x 128 tile does — a wave
+// then streams a quarter of the weights instead of all of them (the column split at C = 128 read every A fragment for one MFMA and
+// lost to two kernels), and the t tile takes the place of the x tile in LDS (nothing reads x after the first conv: the residual is
+// the fp32 stream), which keeps three blocks on a CU.
+template <int KT, int DIL, int C, int NR, bool BF, bool ROWS = false>
+__global__ __launch_bounds__(256, C >= 64 ? 3 : 1) void rbpair16_kernel(const RbPairParams p) {
     constexpr int G = C / 8;         // channel groups
     constexpr int NCH = C / 32;      // 32-channel chunks
-    constexpr int MR = C / 32;       // row tiles per wave (every wave owns all C output rows of its columns)
-    // NR 32-column tiles per wave, 4 waves: 256 mid columns for C <= 64 (NR = 2), 128 for C = 128 (NR = 1: the accumulators and
-    // the two LDS tiles of a 256-column block would leave one block per CU)
-    constexpr int BM = 4 * NR * 32;  // columns of t computed per block
+    constexpr int MR = ROWS ? 1 : C / 32;  // row tiles per wave
+    static_assert(!ROWS || C == 128, "row split: four waves = four row tiles");
+    // NR 32-column tiles per wave. Column split: 4 waves x NR tiles = 256 mid columns for C <= 64 (NR = 2). Row split: NR = 4 tiles = 128.
+    constexpr int BM = (ROWS ? 1 : 4) * NR * 32;  // columns of t computed per block
     constexpr int BO = BM - (KT - 1);  // output columns per block
     constexpr int P2 = (KT - 1) / 2, P1 = (KT - 1) * DIL / 2;
     constexpr int XW = BM + (KT - 1) * DIL;
     constexpr int XWP = (XW + 7) / 8 * 8;
     constexpr int TW = (BM + KT - 1 + 7) / 8 * 8;
     constexpr int STEPS = 2 * KT;
-    extern __shared__ __attribute__((aligned(16))) int4v lds[];  // x tile [G][XWP] | t tile [G][TW]
+    extern __shared__ __attribute__((aligned(16))) int4v lds[];  // x tile [G][XWP] | t tile [G][TW]  (C >= 64: the t tile REPLACES the x tile)
     int4v* xs = lds;
-    int4v* ts = lds + G * XWP;
+    constexpr bool ALIAS = C >= 64;  // the t tile takes the x tile's place (one more barrier; C = 64: 75 -> 40 KB, three blocks per CU)
+    int4v* ts = ALIAS ? lds : lds + G * XWP;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.y;
@@ -87,6 +93,8 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
     const int t0 = blockIdx.x * BO;
     if (t0 >= len) return;
     const int h = lane >> 5;
+    const int rt0 = ROWS ? wid : 0;               // first 32-row tile of this wave
+    const int cb = ROWS ? 0 : wid * (NR * 32);    // first mid column of this wave
     typedef const __attribute__((address_space(3))) int4v* LdsV;
 
     // ---- phase 0: the input tile, all groups, straight into LDS (slot s <-> global time t0 - P2 - P1 + s) -------------------
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
         constexpr int TOTAL = NCH * STEPS;
         int wvoff[MR];
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)mr * TOTAL * 64 + lane) * 16);
+        for (int mr = 0; mr < MR; ++mr) wvoff[mr] = (int)(((size_t)(rt0 + mr) * TOTAL * 64 + lane) * 16);
         auto load_a = [&](int mr, int step) __attribute__((always_inline)) -> int4v {
             return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
         };
@@ -187,7 +195,8 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
 
     __syncthreads();
     // ---- phase 1: conv1 over the x tile: mid column i reads x slots i + j*DIL ------------------------------------------------
-    conv(p.w1, (LdsV)(xs + h * XWP + wid * (NR * 32) + (lane & 31)), XWP, DIL);
+    conv(p.w1, (LdsV)(xs + h * XWP + cb + (lane & 31)), XWP, DIL);
+    if constexpr (ALIAS) __syncthreads();  // every wave is done with the x tile: t takes its place
 
     // ---- phase 2: t = round(leaky_relu(conv1 + b1)), zero outside the sequence, into LDS (group layout) -------------------
     {
@@ -196,11 +205,11 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ch0 = mr * 32 + 8 * g + 4 * h;
+                const int ch0 = (rt0 + mr) * 32 + 8 * g + 4 * h;
                 const float4v bias = *reinterpret_cast<const float4v*>(p.b1 + ch0);
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    const int i = wid * (NR * 32) + nr * 32 + (lane & 31);
+                    const int i = cb + nr * 32 + (lane & 31);
                     const int tm = t0 - P2 + i;
                     float v[4];
 #pragma unroll
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
                     int2v w2;
                     w2.x = (int)rb_pack16<BF>(v[0], v[1]);
                     w2.y = (int)rb_pack16<BF>(v[2], v[3]);
-                    *((LdsW)(ts + (mr * 4 + g) * TW + i) + h) = w2;
+                    *((LdsW)(ts + ((rt0 + mr) * 4 + g) * TW + i) + h) = w2;
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
     __syncthreads();
 
     // ---- phase 3: conv2 over the t tile: output column o reads t slots o + j -------------------------------------------------
-    conv(p.w2, (LdsV)(ts + h * TW + wid * (NR * 32) + (lane & 31)), TW, 1);
+    conv(p.w2, (LdsV)(ts + h * TW + cb + (lane & 31)), TW, 1);
 
     // ---- phase 4: epilogue (as conv16's group epilogue): + b2, + residual, resblock sum / scale, fp32 stream + 16-bit copy ----
     {
@@ -229,14 +238,15 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
         constexpr int NGR = MR * 4;
-        float4v rv[3][NR];
+        constexpr int RD = ROWS ? 2 : 3;  // residual look-ahead ring (row split: NR = 4 float4 per entry, and 208 VGPRs with three of them)
+        float4v rv[RD][NR];
         auto col_ok = [&](int nr, int& t) __attribute__((always_inline)) -> bool {
-            const int o = wid * (NR * 32) + nr * 32 + (lane & 31);
+            const int o = cb + nr * 32 + (lane & 31);
             t = t0 + o;
             return o < BO && t < len;
         };
         auto load_res = [&](int it, float4v* dst) __attribute__((always_inline)) {
-            const int ch0 = (it / 4) * 32 + 8 * (it & 3) + 4 * h;
+            const int ch0 = (rt0 + it / 4) * 32 + 8 * (it & 3) + 4 * h;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 int t;
@@ -244,14 +254,15 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
                 if (rg && col_ok(nr, t)) dst[nr] = *reinterpret_cast<const float4v*>(rg + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
             }
         };
-        load_res(0, rv[0]);
-        load_res(1, rv[1]);
+#pragma unroll
+        for (int i = 0; i < RD - 1; ++i)
+            if (i < NGR) load_res(i, rv[i]);
 #pragma unroll
         for (int it = 0; it < NGR; ++it) {
             const int mr = it / 4, g = it & 3;
-            if (it + 2 < NGR) load_res(it + 2, rv[(it + 2) % 3]);
+            if (it + RD - 1 < NGR) load_res(it + RD - 1, rv[(it + RD - 1) % RD]);
             __builtin_amdgcn_sched_barrier(0);
-            const int ch0 = mr * 32 + 8 * g + 4 * h;
+            const int ch0 = (rt0 + mr) * 32 + 8 * g + 4 * h;
             const float4v bias = *reinterpret_cast<const float4v*>(p.b2 + ch0);
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[mr][nr][4 * g + e] + bias[e];
-                    if (rg) v[e] = rv[it % 3][nr][e] + v[e];
+                    if (rg) v[e] = rv[it % RD][nr][e] + v[e];
                 }
                 if (ag) {
                     const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
@@ -289,19 +300,20 @@ __global__ __launch_bounds__(256) void rbpair16_kernel(const RbPairParams p) {
 // ---- host side -----------------------------------------------------------------------------------------------------------
 template <int KT, int DIL, int C, bool BF>
 static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
-    constexpr int NR = C <= 64 ? 2 : 1;
-    constexpr int BM = 4 * NR * 32;
+    constexpr bool ROWS = C == 128;
+    constexpr int NR = ROWS ? 4 : 2;
+    constexpr int BM = (ROWS ? 1 : 4) * NR * 32;
     constexpr int BO = BM - (KT - 1);
     constexpr int XWP = (BM + (KT - 1) * DIL + 7) / 8 * 8, TW = (BM + KT - 1 + 7) / 8 * 8;
-    const size_t lds = (size_t)(C / 8) * (XWP + TW) * 16;
+    const size_t lds = C >= 64 ? (size_t)(C / 8) * (XWP > TW ? XWP : TW) * 16 : (size_t)(C / 8) * (XWP + TW) * 16;
     static std::atomic<bool> big_lds_set{false};
     if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, NR, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -310,9 +322,7 @@ static hipError_t launch_rb_dil(int dil, const RbPairParams& p, int batch, hipSt
     switch (dil) {
         case 1: return launch_rb<KT, 1, C, BF>(p, batch, s);
         case 3: return launch_rb<KT, 3, C, BF>(p, batch, s);
-        case 5:
-            if constexpr (C <= 64) return launch_rb<KT, 5, C, BF>(p, batch, s);
-            else return hipErrorInvalidValue;
+        case 5: return launch_rb<KT, 5, C, BF>(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -328,13 +338,10 @@ static hipError_t launch_rb_kt(int kt, int dil, const RbPairParams& p, int batch
 }
 
 bool rbpair16_supported(int channels, int kt, int dil) {
-    // C = 128 fused (128-column blocks, every A fragment feeds ONE MFMA) measured slower than two kernels (1.01 vs 0.90 ms per
-    // k = 11 pair): off unless VITS_FUSE16_MAXC=128
-    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 64;
+    // VITS_FUSE16_MAXC=64 keeps the C = 128 pairs on two kernels
+    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 128;
     if (!(kt == 3 || kt == 7 || kt == 11) || channels > maxc) return false;
-    if (channels == 32 || channels == 64) return dil == 1 || dil == 3 || dil == 5;
-    // C = 128: the two LDS tiles of a dilation-5 pair (84 KB) would leave one block per CU: those pairs stay two kernels
-    if (channels == 128) return dil == 1 || dil == 3;
+    if (channels == 32 || channels == 64 || channels == 128) return dil == 1 || dil == 3 || dil == 5;
     return false;
 }
 
