@@ -69,11 +69,11 @@ struct RbPairParams {
 // lost to two kernels), and the t tile takes the place of the x tile in LDS (nothing reads x after the first conv: the residual is
 // the fp32 stream), which keeps three blocks on a CU.
 template <int KT, int DIL, int C, int NR, bool BF, bool ROWS = false>
-__global__ __launch_bounds__(256, C >= 64 ? 3 : 1) void rbpair16_kernel(const RbPairParams p) {
+__global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? 4 : (C >= 64 ? 3 : 1)) void rbpair16_kernel(const RbPairParams p) {
     constexpr int G = C / 8;         // channel groups
     constexpr int NCH = C / 32;      // 32-channel chunks
     constexpr int MR = ROWS ? 1 : C / 32;  // row tiles per wave
-    static_assert(!ROWS || C == 128, "row split: four waves = four row tiles");
+    constexpr int NW = ROWS ? C / 32 : 4;  // waves per block (row split: one per 32-row tile: 4 at C = 128, 8 at C = 256)
     // NR 32-column tiles per wave. Column split: 4 waves x NR tiles = 256 mid columns for C <= 64 (NR = 2). Row split: NR = 4 tiles = 128.
     constexpr int BM = (ROWS ? 1 : 4) * NR * 32;  // columns of t computed per block
     constexpr int BO = BM - (KT - 1);  // output columns per block
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256, C >= 64 ? 3 : 1) void rbpair16_kernel(const Rb
         const int tx0 = t0 - P2 - P1;
         constexpr int NP = (XWP + 63) / 64;
 #pragma unroll
-        for (int gi = 0; gi < G / 4; ++gi) {
-            const int g = wid + 4 * gi;
+        for (int gi = 0; gi < G / NW; ++gi) {
+            const int g = wid + NW * gi;
             const unsigned soff = (unsigned)g * (unsigned)p.x_ts * 16u;
 #pragma unroll
             for (int m = 0; m < NP; ++m) {
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256, C >= 64 ? 3 : 1) void rbpair16_kernel(const Rb
         if (tx0 < 0 || tx0 + XWP > len) {  // sequence ends: zero padding
             const int4v z = {0, 0, 0, 0};
 #pragma unroll
-            for (int gi = 0; gi < G / 4; ++gi) {
-                const int g = wid + 4 * gi;
+            for (int gi = 0; gi < G / NW; ++gi) {
+                const int g = wid + NW * gi;
 #pragma unroll
                 for (int m = 0; m < NP; ++m) {
                     const int t = tx0 + lane + 64 * m;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, C >= 64 ? 3 : 1) void rbpair16_kernel(const Rb
 // ---- host side -----------------------------------------------------------------------------------------------------------
 template <int KT, int DIL, int C, bool BF>
 static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
-    constexpr bool ROWS = C == 128;
+    constexpr bool ROWS = C >= 128;
     constexpr int NR = ROWS ? 4 : 2;
     constexpr int BM = (ROWS ? 1 : 4) * NR * 32;
     constexpr int BO = BM - (KT - 1);
@@ -313,7 +313,7 @@ static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(ROWS ? 2 * C : 256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -339,9 +339,9 @@ static hipError_t launch_rb_kt(int kt, int dil, const RbPairParams& p, int batch
 
 bool rbpair16_supported(int channels, int kt, int dil) {
     // VITS_FUSE16_MAXC=64 keeps the C = 128 pairs on two kernels
-    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 128;
+    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 256;
     if (!(kt == 3 || kt == 7 || kt == 11) || channels > maxc) return false;
-    if (channels == 32 || channels == 64 || channels == 128) return dil == 1 || dil == 3 || dil == 5;
+    if (channels == 32 || channels == 64 || channels == 128 || channels == 256) return dil == 1 || dil == 3 || dil == 5;
     return false;
 }
 
@@ -374,7 +374,8 @@ hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbP
     const bool bf = arith == VITS_ARITH_BF16;
     if (c1.cin == 32) return bf ? launch_rb_kt<32, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<32, false>(c1.kt, c.dil, p, c.batch, s);
     if (c1.cin == 64) return bf ? launch_rb_kt<64, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<64, false>(c1.kt, c.dil, p, c.batch, s);
-    return bf ? launch_rb_kt<128, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<128, false>(c1.kt, c.dil, p, c.batch, s);
+    if (c1.cin == 128) return bf ? launch_rb_kt<128, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<128, false>(c1.kt, c.dil, p, c.batch, s);
+    return bf ? launch_rb_kt<256, true>(c1.kt, c.dil, p, c.batch, s) : launch_rb_kt<256, false>(c1.kt, c.dil, p, c.batch, s);
 }
 
 }  // namespace vits
