@@ -52,13 +52,16 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
 // One block = (utterance, head, 16 queries); scores for the 16 queries x T keys live in LDS.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATT_Q = 16;
-constexpr int ATT_THREADS = 1024;  // 16 waves: at batch 1 a launch has ~34 blocks, and every phase is a chain of LDS / memory latencies
-constexpr int ATT_PASSES = 1;      // (d, 4-query group) items per thread: head_dim <= 256
+// Threads per block: 1024 (16 waves) on small grids — at batch 1 a launch has ~34 blocks and every phase is a chain of LDS / memory
+// latencies that only more waves hide — and 256 on large ones (16-wave blocks pack worse: 73 -> 107 us per launch at batch 64).
+// Both give the same bits: scores and outputs are per-element sums in a fixed order, and the softmax always runs on 16 lanes per query.
 
+template <int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                             int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
                                                             int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ATT_PASSES = 512 / ATT_THREADS < 1 ? 1 : 512 / ATT_THREADS;  // (d, 4-query group) items per thread: head_dim <= 128 (256 threads) / 256
     const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
     const int len = lens ? lens[b] : tmax;
     if (i0 >= len) return;
@@ -84,51 +87,105 @@ __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float*
         qe[idx] = a;
     }
     __syncthreads();
-    // scores: thread -> (key j, half of the 16 queries): lanes run along time (coalesced), 8 running dot products per thread. (One
-    // thread per key left 255 of 256 threads idle in a second pass for T = 257 = 128 interspersed ids.)
-    constexpr int QH = ATT_Q / 2;
-    for (int idx = tid; idx < 2 * len; idx += ATT_THREADS) {
-        const int half = idx >= len ? 1 : 0, j = idx - half * len;
-        const float* qh = qs + half * QH * hd;
-        float a[QH];
+    if constexpr (ATT_THREADS == 256) {
+        // large grids: thread -> key j (coalesced along time), 16 running dot products per thread (half the K loads of the split below)
+        for (int j = tid; j < len; j += ATT_THREADS) {
+            float a[ATT_Q];
 #pragma unroll
-        for (int qi = 0; qi < QH; ++qi) a[qi] = 0.f;
-        for (int d = 0; d < hd; ++d) {
-            const float kv = kb[(int64_t)d * k_cs + j];
+            for (int qi = 0; qi < ATT_Q; ++qi) a[qi] = 0.f;
+            for (int d = 0; d < hd; ++d) {
+                const float kv = kb[(int64_t)d * k_cs + j];
 #pragma unroll
-            for (int qi = 0; qi < QH; ++qi) a[qi] += qh[qi * hd + d] * kv;
+                for (int qi = 0; qi < ATT_Q; ++qi) a[qi] += qs[qi * hd + d] * kv;
+            }
+#pragma unroll
+            for (int qi = 0; qi < ATT_Q; ++qi) {
+                const int r = j - (i0 + qi) + window;
+                float s = a[qi];
+                if (r >= 0 && r < nrel) s += qe[qi * nrel + r];
+                sc[qi * lp + j] = s;
+            }
         }
-#pragma unroll
-        for (int qi = 0; qi < QH; ++qi) {
-            const int qa = half * QH + qi;
-            const int r = j - (i0 + qa) + window;
-            float s = a[qi];
-            if (r >= 0 && r < nrel) s += qe[qa * nrel + r];
-            sc[qa * lp + j] = s;
+    } else {
+        // scores: thread -> (key j, half of the 16 queries): lanes run along time (coalesced), 8 running dot products per thread. (One
+        // thread per key left 255 of 256 threads idle in a second pass for T = 257 = 128 interspersed ids.)
+        constexpr int QH = ATT_Q / 2;
+        for (int idx = tid; idx < 2 * len; idx += ATT_THREADS) {
+            const int half = idx >= len ? 1 : 0, j = idx - half * len;
+            const float* qh = qs + half * QH * hd;
+            float a[QH];
+    #pragma unroll
+            for (int qi = 0; qi < QH; ++qi) a[qi] = 0.f;
+            for (int d = 0; d < hd; ++d) {
+                const float kv = kb[(int64_t)d * k_cs + j];
+    #pragma unroll
+                for (int qi = 0; qi < QH; ++qi) a[qi] += qh[qi * hd + d] * kv;
+            }
+    #pragma unroll
+            for (int qi = 0; qi < QH; ++qi) {
+                const int qa = half * QH + qi;
+                const int r = j - (i0 + qa) + window;
+                float s = a[qi];
+                if (r >= 0 && r < nrel) s += qe[qa * nrel + r];
+                sc[qa * lp + j] = s;
+            }
         }
     }
     __syncthreads();
-    // softmax per query: one wave per query
-    {
-        const int qi = tid >> 6, l64 = tid & 63;
+    // softmax per query: 16 lanes per query (the first 256 threads)
+    if (tid < 256) {
+        const int qi = tid >> 4, l16 = tid & 15;
         float mx = -INFINITY;
-        for (int j = l64; j < len; j += 64) mx = fmaxf(mx, sc[qi * lp + j]);
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
         float sum = 0.f;
-        for (int j = l64; j < len; j += 64) {
+        for (int j = l16; j < len; j += 16) {
             const float e = expf(sc[qi * lp + j] - mx);
             sc[qi * lp + j] = e;
             sum += e;
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
         const float inv = 1.0f / sum;
-        for (int j = l64; j < len; j += 64) sc[qi * lp + j] *= inv;
+        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
     }
     __syncthreads();
     // o[qi][d] = sum_j p[qi][j] v[d][j] + windowed relative-value term; thread -> (d, 4-query group), up to ATT_PASSES items per thread.
     // V goes through LDS in 64-key chunks (rows of v are time-major: lanes that differ in d would each touch their own cache line
     // per key — 2/3 of this kernel's time at batch 1); the sums still run over j in ascending order.
     float* ob = out + (int64_t)b * o_bs + (int64_t)h * hd * o_cs;
+    if constexpr (ATT_THREADS == 256) {
+        // large grids: V straight from memory (rows of v are time-major, lanes differ in d: one cache line per lane and key — other
+        // resident blocks hide it, and the LDS staging below costs two barriers per 64 keys: 73 vs 94 us per launch at batch 64)
+        for (int idx = tid; idx < hd * (ATT_Q / 4); idx += ATT_THREADS) {
+            const int d = idx % hd, qg = idx / hd;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const float* p0 = sc + (qg * 4 + 0) * lp;
+            const float* p1 = sc + (qg * 4 + 1) * lp;
+            const float* p2 = sc + (qg * 4 + 2) * lp;
+            const float* p3 = sc + (qg * 4 + 3) * lp;
+            const float* vr = vb + (int64_t)d * v_cs;
+            for (int j = 0; j < len; ++j) {
+                const float vv = vr[j];
+                a0 += p0[j] * vv;
+                a1 += p1[j] * vv;
+                a2 += p2[j] * vv;
+                a3 += p3[j] * vv;
+            }
+            float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qi = qg * 4 + u, i = i0 + qi;
+                if (i >= len) continue;
+                float rsum = 0.f;
+                for (int r = 0; r < nrel; ++r) {
+                    const int j = i + r - window;
+                    if (j >= 0 && j < len) rsum += sc[qi * lp + j] * rel_v[r * hd + d];
+                }
+                ob[(int64_t)d * o_cs + i] = acc[u] + rsum;
+            }
+        }
+        return;
+    }
     const int vc = 1 << vshift, vp = vc + 1;  // keys per chunk (64 unless a long utterance's scores leave less LDS); odd pitch: lanes differ in d
     float* vt = sc + ATT_Q * lp;       // [hd][vp]
     float acc[ATT_PASSES][4];
@@ -198,14 +255,21 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
         lds = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * lp + (size_t)head_dim * ((1 << vshift) + 1));
         if (lds <= 150 * 1024) break;
     }
-    if (lds > 150 * 1024 || head_dim * (ATT_Q / 4) > ATT_THREADS * ATT_PASSES) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rel_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 150 * 1024 || head_dim * (ATT_Q / 4) > 512) return hipErrorInvalidValue;
     dim3 grid((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
-    hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(ATT_THREADS), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
-                       lens, head_dim, tmax, window, q_scale, vshift);
+    const bool small_grid = (int64_t)grid.x * grid.y * grid.z <= 512;
+#define VITS_ATT_LAUNCH(T)                                                                                                                  \
+    do {                                                                                                                                    \
+        if (lds > 64 * 1024) {                                                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                                  \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL(rel_attention_kernel<T>, grid, dim3(T), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, \
+                           out.cs, lens, head_dim, tmax, window, q_scale, vshift);                                                         \
+    } while (0)
+    if (small_grid) VITS_ATT_LAUNCH(1024);
+    else VITS_ATT_LAUNCH(256);
+#undef VITS_ATT_LAUNCH
     return hipGetLastError();
 }
 
