@@ -69,7 +69,8 @@ struct RbPairParams {
 // lost to two kernels), and the t tile takes the place of the x tile in LDS (nothing reads x after the first conv: the residual is
 // the fp32 stream), which keeps three blocks on a CU.
 template <int KT, int DIL, int C, int NR, bool BF, bool ROWS = false>
-__global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? 4 : (C >= 64 ? 3 : 1)) void rbpair16_kernel(const RbPairParams p) {
+// (waves per SIMD asked of the compiler = what the LDS tile lets a CU hold: C = 256 blocks are eight waves and 74-94 KB)
+__global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 32 ? 4 : 2) : (C >= 64 ? 3 : 1)) void rbpair16_kernel(const RbPairParams p) {
     constexpr int G = C / 8;         // channel groups
     constexpr int NCH = C / 32;      // 32-channel chunks
     constexpr int MR = ROWS ? 1 : C / 32;  // row tiles per wave
