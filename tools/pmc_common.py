@@ -6,10 +6,10 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (WM, WN, MR, NR) of conv_mfma_kernel -> ConvTile index (kernels.h)
-TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4}
+TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4, (4, 1, 1, 1): 5}
 _CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
 _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
-_RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)>")
+_RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)(?:, \w+)?>")
 # conv16.hip: (WM, WN, MR, NR) -> tile index; Epi16 -> the epilogue tag the engine prints
 TILES16 = {(2, 2, 2, 4): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4, (2, 2, 2, 2): 5, (4, 1, 1, 4): 6}
 EPI16 = {0: "e0", 1: "e1", 2: "e2", 3: "e0g", 4: "e2g"}
@@ -24,7 +24,7 @@ def bench_key(kernel_name):
         return None if tile is None else f"k{kt}|d{dil}|T{tile}|{EPI16.get(int(epi), 'e?')}"
     m = _RBPAIR16.search(kernel_name)
     if m:  # `rbpair16_kernel<11, 1, 64, 2, false>` -> `k11|d1|F64|e0g`
-        kt, dil, c, _, _ = m.groups()
+        kt, dil, c = m.groups()[:3]
         return f"k{kt}|d{dil}|F{c}|e0g"
     m = _CONV.search(kernel_name)
     if not m:

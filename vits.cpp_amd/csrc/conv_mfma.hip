@@ -1004,6 +1004,43 @@ VITS_LAUNCHER(11) {
 #endif
 
 #if VITS_CONV_PART == 0
+// The tile a launch will run on: shape rule (choose_conv_tile), then the small-grid steps. Also what the engine's profiler prints.
+int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
+    const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
+    int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
+    if (c.tile < 0 && w.epi == EPI_GATE) {
+        const TileShape t2 = tile_shape(tile);
+        const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
+        if (nb * ((w.mtiles_used + 1) / 2) * c.batch < 512) tile = TILE_64x64;  // 64 x 128 keeps the tanh/sigmoid row pairing
+    }
+    if (c.tile < 0 && w.epi != EPI_GATE) {
+        // small grids (batch 1, short inputs): fewer than ~2 blocks per CU leaves matrix pipes idle -> step down to
+        // smaller tiles until the launch has >= 512 blocks (latency case, BASELINE.json config 2)
+        auto blocks = [&](int tl) {
+            const TileShape t2 = tile_shape(tl);
+            const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
+            const int64_t mb = (w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
+            return nb * mb * c.batch;
+        };
+        static const int64_t min_blocks = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 512;
+        if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
+        if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
+    }
+    if (c.tile < 0 && w.epi != EPI_CONVT) {
+        // tiny grids (the encoder / duration predictor / flow at batch 1: 6-18 blocks of the 128-column tiles): every block of a
+        // 128-column tile streams the WHOLE input in through its one producer wave, and that stream, not the MFMA chain, is the
+        // launch time (768 -> 192 FFN conv, k = 3, 128 tokens: 78 us for a 31 us chain). Blocks of four row tiles x ONE 32-column
+        // strip need a quarter of the input each. Same per-output accumulation order (the tile shape never changes it).
+        static const bool no_narrow = getenv("VITS_NO_NARROW") != nullptr;
+        const int dil_eff = w.kt == 1 ? 1 : c.dil;
+        const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
+        const TileShape t2 = tile_shape(tile);
+        const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
+        if (!no_narrow && shape_ok && nb <= 128) tile = TILE_NARROW;
+    }
+    return tile;
+}
+
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     ConvParams p;
     p.x = c.x.p;
@@ -1038,38 +1075,8 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.scale_div = c.scale_div;
     p.ct_stride = w.ct_stride;
     p.ct_crop = c.ct_crop;
-    int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
-    int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols_max);
-    if (c.tile < 0 && w.epi == EPI_GATE) {
-        const TileShape t2 = tile_shape(tile);
-        const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
-        if (nb * ((w.mtiles_used + 1) / 2) * c.batch < 512) tile = TILE_64x64;  // 64 x 128 keeps the tanh/sigmoid row pairing
-    }
-    if (c.tile < 0 && w.epi != EPI_GATE) {
-        // small grids (batch 1, short inputs): fewer than ~2 blocks per CU leaves matrix pipes idle -> step down to
-        // smaller tiles until the launch has >= 512 blocks (latency case, BASELINE.json config 2)
-        auto blocks = [&](int tl) {
-            const TileShape t2 = tile_shape(tl);
-            const int64_t nb = (ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32);
-            const int64_t mb = (w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
-            return nb * mb * c.batch;
-        };
-        static const int64_t min_blocks = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 512;
-        if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
-        if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
-    }
-    if (c.tile < 0 && w.epi != EPI_CONVT) {
-        // tiny grids (the encoder / duration predictor / flow at batch 1: 6-18 blocks of the 128-column tiles): every block of a
-        // 128-column tile streams the WHOLE input in through its one producer wave, and that stream, not the MFMA chain, is the
-        // launch time (768 -> 192 FFN conv, k = 3, 128 tokens: 78 us for a 31 us chain). Blocks of four row tiles x ONE 32-column
-        // strip need a quarter of the input each. Same per-output accumulation order (the tile shape never changes it).
-        static const bool no_narrow = getenv("VITS_NO_NARROW") != nullptr;
-        const int dil_eff = w.kt == 1 ? 1 : c.dil;
-        const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
-        const TileShape t2 = tile_shape(tile);
-        const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
-        if (!no_narrow && shape_ok && nb <= 128) tile = TILE_NARROW;
-    }
+    const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
+    const int tile = resolve_conv_tile(w, c);
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     if (w.epi == EPI_CONVT) {

@@ -633,8 +633,7 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
     if (prof.on) {
         // name = label|k<taps>|d<dilation>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
         // bench can line entries up with rocprofv3's per-kernel-name statistics
-        const int ncols = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
-        const int tile = c.tile >= 0 ? c.tile : choose_conv_tile(w.rows, w.epi, ncols);
+        const int tile = resolve_conv_tile(w, c);
         char full[160];
         std::snprintf(full, sizeof(full), "%s|k%d|d%d|t%d|e%d|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, w.cin,
                       w.cout);

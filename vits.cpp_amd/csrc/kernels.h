@@ -78,6 +78,7 @@ struct ConvCall {
 std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, int epi, int ct_stride, int* rows, int* mtiles_used, int* mtiles,
                                      int* nchunks);
 int choose_conv_tile(int rows, int epi, int t_hint);
+int resolve_conv_tile(const PackedConv& w, const ConvCall& c);  // the tile launch_conv will use (small-grid rules included)
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s);
 double conv_flops(const PackedConv& w, const ConvCall& c, int64_t total_cols);
 
