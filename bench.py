@@ -108,10 +108,11 @@ def cpu_baseline(jobs, mode_name, with_one_thread=True, budget_s=9.0):
     return res
 
 
-def find_profile_artifact(pkg, suffix, key):
+def find_profile_artifact(pkg, suffix, key, tag):
     """Newest profiles/*<suffix> that (a) records the source hash of the library sources of THIS run and (b) has an entry for the
-    kernel `key` (the PMC passes are separate rocprofv3 runs over this same command; a file collected for another build would be
-    stale, so it is ignored — the fields then stay null)."""
+    kernel `key` and (c) was collected on this workload (`tag` = workload|batch|arith: a kernel instantiation's bytes per launch and busy
+    fraction depend on the shapes it ran on). The PMC passes are separate rocprofv3 runs over this same command; a file collected for
+    another build or another workload is ignored — the fields then stay null."""
     want = pkg.source_sha16()
     best = None
     for path in glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)):
@@ -120,7 +121,7 @@ def find_profile_artifact(pkg, suffix, key):
                 d = json.load(fh)
         except Exception:
             continue
-        if d.get("source_sha16") == want and key in d.get("by_bench_key", {}) and (best is None or os.path.getmtime(path) > os.path.getmtime(best[0])):
+        if d.get("source_sha16") == want and d.get("workload_tag") == tag and key in d.get("by_bench_key", {}) and (best is None or os.path.getmtime(path) > os.path.getmtime(best[0])):
             best = (path, d)
     return best
 
@@ -414,14 +415,15 @@ def main():
             # HBM bytes per launch of that kernel and MFMA-busy fraction from the PMC passes (separate rocprofv3 --pmc runs over
             # this same command, reduced by tools/pmc_traffic.py / tools/pmc_summary.py): only a file collected for THIS
             # build (same source hash) is used, otherwise the fields stay null
-            art = find_profile_artifact(pkg, "_pmc_traffic.json", dom_key)
+            pmc_tag = "%s|b%d|%s" % (args.workload, B, args.arith)
+            art = find_profile_artifact(pkg, "_pmc_traffic.json", dom_key, pmc_tag)
             if art:
                 ent = art[1].get("by_bench_key", {}).get(dom_key)
                 if ent:
                     res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
                     res["roofline"]["traffic_unit"] = "bytes per launch (" + art[1].get("calibration", "PMC") + "; " + os.path.relpath(art[0], ROOT) + ")"
                     res["roofline"]["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
-            art = find_profile_artifact(pkg, "_pmc_mfma.json", dom_key)
+            art = find_profile_artifact(pkg, "_pmc_mfma.json", dom_key, pmc_tag)
             if art:
                 ent = art[1].get("by_bench_key", {}).get(dom_key)
                 if ent:

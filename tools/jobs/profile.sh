@@ -1,7 +1,9 @@
 #!/bin/bash
 # Profile job: rocprofv3 kernel stats + PMC passes (HBM traffic, MFMA busy, LDS conflicts) over the bench workload, reduced into
-# profiles-ready files under gpurun_out/$TAG/. usage: bash tools/jobs/profile.sh TAG [extra bench args]
+# profiles-ready files under gpurun_out/$TAG/. usage: bash tools/jobs/profile.sh TAG WORKLOAD_TAG [extra bench args]
+# (WORKLOAD_TAG = workload|batch|arith of the bench command, e.g. "c3|b64|f32": recorded in the artefacts, matched by bench.py)
 TAG=${1:-prof}; shift
+WTAG=${1:-c3|b64|f32}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -15,8 +17,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLE
 done
 cd $GRAFT_REPO_ROOT
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
-python3 tools/pmc_traffic.py $O/pmc_traffic.json --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
-python3 tools/pmc_mfma.py $O/pmc_mfma.json $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
+python3 tools/pmc_traffic.py $O/pmc_traffic.json --workload "$WTAG" --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
+python3 tools/pmc_mfma.py $O/pmc_mfma.json --workload "$WTAG" $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
 # keep the merged payload small: drop the raw traces
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
 head -12 $O/kernel_stats.csv | cut -c1-150

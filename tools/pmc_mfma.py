@@ -15,6 +15,14 @@ import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_common import bench_key, source_sha16
 
+# --workload TAG: which bench workload the passes ran (bench.py only uses an artefact whose tag equals its own: the bytes and
+# busy fractions of a kernel instantiation depend on the shapes it was launched with)
+WORKLOAD_TAG = "c3|b64|f32"
+if "--workload" in sys.argv:
+    i = sys.argv.index("--workload")
+    WORKLOAD_TAG = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+
 out = sys.argv[1]
 ctr = collections.defaultdict(lambda: collections.defaultdict(float))   # kernel -> counter -> sum
 ndisp = collections.defaultdict(lambda: collections.defaultdict(set))   # kernel -> counter -> dispatch ids
@@ -56,7 +64,7 @@ for name, c in ctr.items():
     if key and (key not in by_key or e["launches_sampled"] > by_key[key]["launches_sampled"]):
         by_key[key] = dict(e, kernel_name=name)
 json.dump({"note": "rocprofv3 --kernel-trace --pmc passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-pass`; formulas in tools/pmc_mfma.py",
-           "source_sha16": source_sha16(), "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+           "source_sha16": source_sha16(), "workload_tag": WORKLOAD_TAG, "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 top = sorted(by_key.items(), key=lambda kv: -kv[1]["counters_per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["launches_sampled"])[:12]
 for k, e in top:
     print(f"{k:18s} mfma_busy {e.get('mfma_busy_frac', float('nan')):.3f}  of-launch@2.4GHz {e.get('mfma_busy_frac_of_launch_at_2p4ghz', float('nan')):.3f}  "

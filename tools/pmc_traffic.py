@@ -9,6 +9,14 @@ import collections, csv, glob, json, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 from pmc_common import bench_key, source_sha16
 
+# --workload TAG: which bench workload the passes ran (bench.py only uses an artefact whose tag equals its own: the bytes and
+# busy fractions of a kernel instantiation depend on the shapes it was launched with)
+WORKLOAD_TAG = "c3|b64|f32"
+if "--workload" in sys.argv:
+    i = sys.argv.index("--workload")
+    WORKLOAD_TAG = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+
 argv = sys.argv[1:]
 out = argv.pop(0)
 FETCH_CAL, WRITE_CAL = 2.0, 1.0
@@ -41,5 +49,5 @@ for name in set(fetch) | set(write):
         by_key[key] = dict(res[name], kernel_name=name)
 cal = f"rocprofv3 --pmc FETCH_SIZE x {FETCH_CAL:g} + WRITE_SIZE x {WRITE_CAL:g} (KiB -> bytes; factors calibrated with tools/fetch_calib.hip)"
 json.dump({"note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-pass`",
-           "calibration": cal, "source_sha16": source_sha16(), "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+           "calibration": cal, "source_sha16": source_sha16(), "workload_tag": WORKLOAD_TAG, "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 print(len(res), "kernels ->", out)
