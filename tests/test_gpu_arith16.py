@@ -257,3 +257,34 @@ def test_fused_dds_layer_is_bit_identical_to_the_three_kernel_path(pkg, full_byt
         assert np.array_equal(a[1], b_[1])
         for x, y in zip(a[0], b_[0]):
             assert np.array_equal(x, y), mode
+
+
+def test_fused_fp32_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, full_bytes, monkeypatch):
+    """rbpair32.hip (fp32, C = 32 / 64: conv1 -> LDS -> conv2 in one kernel) runs the MFMA chain and the epilogue expressions of two
+    conv_mfma launches: the PCM must not move by a bit — ragged batch with very short members, windowed vocoder, both semantics modes,
+    and utterances long enough that blocks of one launch start after others have finished (a fused block that read data another
+    block had already overwritten would show up there)."""
+    Ts = [30, 11, 40, 1, 2]
+    ids = np.zeros((5, 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = _ids(T, 90 + b)
+    long_ids = pkg.synth_ids(2, 700, ids_seed=4242)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("VITS_NO_FUSE32", "1")
+        with pkg.Model(full_bytes) as m:
+            for mode in (0, 1):
+                outs[(fused, mode, 0)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33)
+                outs[(fused, mode, 1)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33, vocoder_chunk_frames=24)
+            outs[(fused, "long", 0)] = m.process_batch(long_ids, noise_seed=34, fixed_duration=2)
+    for x, y in zip(outs[(True, "long", 0)][0], outs[(False, "long", 0)][0]):
+        assert np.array_equal(x, y), "long utterance"
+    for mode in (0, 1):
+        for w in (0, 1):
+            a, b_ = outs[(True, mode, w)], outs[(False, mode, w)]
+            assert np.array_equal(a[1], b_[1])
+            for x, y in zip(a[0], b_[0]):
+                assert np.array_equal(x, y), (mode, w)
+        for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
+            assert np.array_equal(x, y)

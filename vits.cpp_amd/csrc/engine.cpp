@@ -1547,6 +1547,59 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
                     const bool lcopy = C >= lrelu_copy_minc_;
                     TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]), bul = TR(s2.bul, C, sts[st_out]);
+                    // narrow stages: each pair as ONE kernel, t stays in LDS (rbpair32.hip; bit-identical to the two launches below).
+                    // A fused block reads a halo of its neighbours' input columns while other blocks store their output, so the
+                    // resblock's stream ping-pongs between `by` and the buffer the two-launch path uses for t. All pairs or none.
+                    bool fuse_rb = !lcopy && std::getenv("VITS_NO_FUSE32") == nullptr;
+                    for (size_t d = 0; d < nd && fuse_rb; ++d)
+                        fuse_rb = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias && (sts[st_out] & 3) == 0;
+                    if (fuse_rb) {
+                        TensorRef src = bu;
+                        for (size_t d = 0; d < nd; ++d) {
+                            const bool last = d + 1 == nd;
+                            RbPair32Call f;
+                            f.x = src;
+                            f.lens = d_len[st_out];
+                            f.batch = B;
+                            f.tmax = smax[st_out];
+                            f.dil = R.dil[d];
+                            f.slope = hp.lrelu;
+                            if (!last) {
+                                f.y = src.p == by.p ? bt : by;
+                            } else {
+                                f.y = bsum;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635), as below
+                                if (j > 0) f.acc = bsum;
+                                if (j + 1 == nk) {
+                                    if (refmode) {
+                                        f.scale = (float)(1.0 / (double)nk);
+                                        f.scale_div = 0;
+                                    } else {
+                                        f.scale = (float)nk;
+                                        f.scale_div = 1;
+                                    }
+                                    if (i + 1 < n_up) {
+                                        f.post_act = 2;
+                                        f.post_slope = hp.lrelu;
+                                    }
+                                } else {
+                                    f.scale = 1.f;
+                                }
+                            }
+                            if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                            if (prof.on) {
+                                char full[160];
+                                std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|f%d|e0|c%dx%d", R.k, R.dil[d], C, C, C);
+                                const double n_out = (double)C * (double)ssum[st_out];
+                                prof.begin(full, 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out],
+                                           4.0 * n_out * (3 + (f.acc.p ? 1 : 0)) + (double)R.c1[d].bytes + (double)R.c2[d].bytes, sj, true);
+                            }
+                            HIP_OK(launch_rbpair32(R.c1[d], R.c2[d], f, sj));
+                            prof.end(sj);
+                            if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
+                            src = f.y;
+                        }
+                        continue;
+                    }
                     for (size_t d = 0; d < nd; ++d) {
                         TensorRef resid = d == 0 ? bu : by;
                         ConvCall c1;

@@ -125,6 +125,19 @@ struct RbPair16Call {
     int scale_div = 0;
 };
 bool rbpair16_supported(int channels, int kt, int dil);
+// fp32 ResBlock conv pair as one kernel (rbpair32.hip): y = x + conv2(leaky_relu(conv1(leaky_relu(x)) + b1)) + b2; y must not alias x
+struct RbPair32Call {
+    TensorRef x, y, acc;
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0, dil = 1;
+    float slope = 0.1f;
+    float scale = 1.f;
+    int scale_div = 0;
+    int post_act = 0;
+    float post_slope = 0.f;
+};
+bool rbpair32_supported(int channels, int kt, int dil);
+hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbPair32Call& c, hipStream_t s);
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);
 int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch);
