@@ -1550,7 +1550,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     // narrow stages: each pair as ONE kernel, t stays in LDS (rbpair32.hip; bit-identical to the two launches below).
                     // A fused block reads a halo of its neighbours' input columns while other blocks store their output, so the
                     // resblock's stream ping-pongs between `by` and the buffer the two-launch path uses for t. All pairs or none.
-                    bool fuse_rb = !lcopy && std::getenv("VITS_NO_FUSE32") == nullptr;
+                    bool fuse_rb = std::getenv("VITS_NO_FUSE32") == nullptr;  // (the fused kernel reads the RAW stream: the activated copies of wide stages are for the other resblocks)
                     for (size_t d = 0; d < nd && fuse_rb; ++d)
                         fuse_rb = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias && (sts[st_out] & 3) == 0;
                     if (fuse_rb) {

@@ -50,9 +50,9 @@ struct RbPair32Params {
 };
 
 template <int KT, int DIL, int C>
-__global__ __launch_bounds__(256, 3) void rbpair32_kernel(const RbPair32Params p) {
+__global__ __launch_bounds__(256, C >= 128 ? 2 : 3) void rbpair32_kernel(const RbPair32Params p) {
     constexpr int NCH = C / 32;  // 32-channel chunks
-    constexpr int WM = C / 32, WN = 4 / WM, NR = 2;
+    constexpr int WM = C / 32, WN = 4 / WM, NR = C >= 128 ? 4 : 2;  // (C = 128: four row tiles, every wave all 128 mid columns)
     constexpr int BM = WN * NR * 32;   // mid columns (t) per block
     constexpr int BO = BM - (KT - 1);  // output columns per block
     constexpr int P2 = (KT - 1) / 2, P1 = (KT - 1) * DIL / 2;
@@ -226,9 +226,15 @@ __global__ __launch_bounds__(256, 3) void rbpair32_kernel(const RbPair32Params p
 // ---- host side -----------------------------------------------------------------------------------------------------------
 template <int KT, int DIL, int C>
 static hipError_t launch_rb32(const RbPair32Params& p, int batch, hipStream_t s) {
-    constexpr int WN = 4 / (C / 32), BM = WN * 2 * 32, BO = BM - (KT - 1);
+    constexpr int WN = 4 / (C / 32), BM = WN * (C >= 128 ? 4 : 2) * 32, BO = BM - (KT - 1);
     constexpr int XWP = (BM + (KT - 1) * DIL + 3 + 3) / 4 * 4;
     const size_t ldsz = ((size_t)C * XWP * sizeof(float) + 1023) / 1024 * 1024;  // (the last 1 KB DMA instruction may overhang the tile)
+    static std::atomic<bool> big_lds_set{false};
+    if (ldsz > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair32_kernel<KT, DIL, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        big_lds_set.store(true, std::memory_order_release);
+    }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
     hipLaunchKernelGGL((rbpair32_kernel<KT, DIL, C>), grid, dim3(256), ldsz, s, p);
     return hipGetLastError();
@@ -256,8 +262,11 @@ static hipError_t launch_rb32_kt(int kt, int dil, const RbPair32Params& p, int b
 
 bool rbpair32_supported(int channels, int kt, int dil) {
     if (!(kt == 3 || kt == 7 || kt == 11)) return false;
-    if (!(channels == 32 || channels == 64)) return false;
-    return dil == 1 || dil == 3 || dil == 5;
+    if (!(dil == 1 || dil == 3 || dil == 5)) return false;
+    if (channels == 32 || channels == 64) return true;
+    // C = 128: only the k = 3 pairs — their 128-column tile with its small halo is 74 KB (two blocks per CU); k = 7 / 11 would be 84-94 KB
+    static const bool c128 = getenv("VITS_FUSE32_C128") ? atoi(getenv("VITS_FUSE32_C128")) != 0 : true;
+    return channels == 128 && kt == 3 && c128;
 }
 
 hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbPair32Call& c, hipStream_t s) {
@@ -288,7 +297,8 @@ hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbP
     p.post_act = c.post_act;
     p.post_slope = c.post_slope;
     if (c1.cin == 32) return launch_rb32_kt<32>(c1.kt, c.dil, p, c.batch, s);
-    return launch_rb32_kt<64>(c1.kt, c.dil, p, c.batch, s);
+    if (c1.cin == 64) return launch_rb32_kt<64>(c1.kt, c.dil, p, c.batch, s);
+    return launch_rb32_dil<3, 128>(c.dil, p, c.batch, s);
 }
 
 }  // namespace vits
