@@ -1551,8 +1551,10 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     // A fused block reads a halo of its neighbours' input columns while other blocks store their output, so the
                     // resblock's stream ping-pongs between `by` and the buffer the two-launch path uses for t. All pairs or none.
                     bool fuse_rb = std::getenv("VITS_NO_FUSE32") == nullptr;  // (the fused kernel reads the RAW stream: the activated copies of wide stages are for the other resblocks)
-                    for (size_t d = 0; d < nd && fuse_rb; ++d)
-                        fuse_rb = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias && (sts[st_out] & 3) == 0;
+                    // (16-byte LDS-DMA rows: every buffer a pair may read has to be 16-byte aligned with strides that are multiples of 4)
+                    auto al16 = [](const TensorRef& t) { return (reinterpret_cast<uintptr_t>(t.p) & 15) == 0 && (t.cs & 3) == 0 && (t.bs & 3) == 0; };
+                    fuse_rb = fuse_rb && al16(bu) && al16(by) && al16(bt);
+                    for (size_t d = 0; d < nd && fuse_rb; ++d) fuse_rb = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
                     if (fuse_rb) {
                         TensorRef src = bu;
                         for (size_t d = 0; d < nd; ++d) {
