@@ -82,7 +82,7 @@ def test_conv_transpose_matches_oracle(pkg, oracle, cin, cout, k, s, T, crop_mod
         assert rel_err(yg[i, :, :lo], yr[i, :, :lo]) < TOL
 
 
-@pytest.mark.parametrize("T", [3, 5, 16, 128, 300])
+@pytest.mark.parametrize("T", [3, 5, 16, 17, 128, 257, 300, 1100, 2049])
 def test_rel_attention_matches_oracle(pkg, oracle, T):
     rng = np.random.default_rng(T)
     heads, hd, w = 2, 96, 4

@@ -246,8 +246,231 @@ __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same attention core on the matrix cores (head_dim a multiple of 16): scores S = Q K^T and O = P V as 16 x 16 x 4 fp32 MFMAs
+// (v_mfma_f32_16x16x4_f32: the 16 queries of a block are M), softmax and the 2w+1 relative terms as above. The VALU kernel does
+// one LDS read per FMA and, for 1024-id inputs (2049 tokens), was the longest single entry of a 16-bit step.
+//   operand layouts (lane l): A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16], D[m = 4 * (l / 16) + r][n = l % 16], r = 0..3
+// Block = (utterance, head, 16 queries), 4 waves. Scores: wave w owns key tiles w, w + 4, ...; P V: wave w owns d tiles w, w + 4.
+// Every sum has ONE order for every grid (key tiles of 16, k-steps of 4 ascending), so results do not depend on the batch.
+// LDS: Q^T [hd][16] | q.Ek [16][nrel] | scores [16][lp], lp = 4 mod 64 (conflict-free A reads of P) | V chunk [hd][vc + 4].
+// ---------------------------------------------------------------------------------------------------------
+typedef float att_float4v __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int att_lp(int len) { return (len + 63) / 64 * 64 + 4; }  // >= len + 4, = 4 (mod 64)
+
+__global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+                                                                 int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
+                                                                 int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
+    const int len = lens ? lens[b] : tmax;
+    if (i0 >= len) return;
+    const int hd = head_dim, nrel = 2 * window + 1;
+    const int lp = att_lp(len);
+    float* qt = sm;                      // [hd][16]  (scaled)
+    float* qe = qt + hd * ATT_Q;         // [16][nrel]
+    float* sc = qe + ATT_Q * nrel;       // [16][lp]
+    const int vc = 1 << vshift, vp = vc + 4;
+    float* vt = sc + ATT_Q * att_lp(tmax);  // [hd][vp]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ln = lane & 15, lk = lane >> 4;
+    const float* qb = q + (int64_t)b * q_bs + (int64_t)h * hd * q_cs;
+    const float* kb = k + (int64_t)b * k_bs + (int64_t)h * hd * k_cs;
+    const float* vb = v + (int64_t)b * v_bs + (int64_t)h * hd * v_cs;
+    {
+        float tq[8];  // (head_dim <= 128: at most 8 elements per thread, all loads in flight)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * 256;
+            const int d = idx / ATT_Q, i = i0 + idx % ATT_Q;
+            tq[u] = (idx < ATT_Q * hd && i < len) ? qb[(int64_t)d * q_cs + i] * q_scale : 0.f;  // scaling: vits.cpp:296-297
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (tid + u * 256 < ATT_Q * hd) qt[tid + u * 256] = tq[u];  // (idx = d * 16 + qi is the Q^T index)
+    }
+    __syncthreads();
+    const int nsteps = hd >> 2;
+    const int ntiles = (len + 15) >> 4;
+    // this lane's Q operands for every k-step (A[m = ln][k = 4s + lk]): the same for every key tile and for the relative-key product
+    constexpr int MAXS = 32;  // head_dim <= 128
+    float qa[MAXS];
+#pragma unroll
+    for (int s2 = 0; s2 < MAXS; ++s2) qa[s2] = s2 < nsteps ? qt[(4 * s2 + lk) * ATT_Q + ln] : 0.f;
+    // q_i . Ek[r] for the 2w+1 relative positions: one more 16 x 16 product (columns r < nrel of the table), wave 0
+    if (wid == 0) {
+        att_float4v acc = {0.f, 0.f, 0.f, 0.f};
+        const float* rp = rel_k + (int64_t)(ln < nrel ? ln : 0) * hd + lk;
+#pragma unroll
+        for (int s0 = 0; s0 < MAXS; s0 += 8) {
+            float bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = (s0 + u < nsteps && ln < nrel) ? rp[4 * (s0 + u)] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s0 + u], bv[u], acc, 0, 0, 0);
+        }
+        if (ln < nrel) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qe[(4 * lk + r) * nrel + ln] = acc[r];
+        }
+    }
+    __syncthreads();
+    // ---- scores: S[16 q][16 keys] per key tile, K = hd ----
+    // (k-steps in groups of 8 with the operands of a group fetched before its first MFMA: a rolled load -> MFMA loop exposes one
+    // memory latency per step, and a block of a 2049-token utterance is alone on its CU)
+    for (int n = wid; n < ntiles; n += 4) {
+        const int key = n * 16 + ln;
+        const int keyc = key < len ? key : len - 1;
+        att_float4v acc = {0.f, 0.f, 0.f, 0.f};
+        const float* kp = kb + (int64_t)lk * k_cs + keyc;
+#pragma unroll
+        for (int s0 = 0; s0 < MAXS; s0 += 8) {
+            if (s0 < nsteps) {
+                float bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
+                    bv[u] = kp[(int64_t)(4 * s) * k_cs];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s0 + u], bv[u], acc, 0, 0, 0);
+            }
+        }
+        if (key < len) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = 4 * lk + r;
+                const int rr = key - (i0 + qi) + window;
+                float sv = acc[r];
+                if (rr >= 0 && rr < nrel) sv += qe[qi * nrel + rr];
+                sc[qi * lp + key] = sv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole chunks) ----
+    {
+        const int qi = tid >> 4, l16 = tid & 15;
+        float mx = -INFINITY;
+        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        for (int j = l16; j < len; j += 16) {
+            const float e = expf(sc[qi * lp + j] - mx);
+            sc[qi * lp + j] = e;
+            sum += e;
+        }
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
+        for (int j = len + l16; j < lp; j += 16) sc[qi * lp + j] = 0.f;
+    }
+    __syncthreads();
+    // ---- O[16 q][hd] = P V: d tiles of 16, K = keys, V staged through LDS in chunks of vc keys ----
+    const int ndt = hd >> 4;
+    att_float4v oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d tiles wid and wid + 4 (head_dim <= 128)
+    for (int j0 = 0; j0 < len; j0 += vc) {
+        const int nj = len - j0 < vc ? len - j0 : vc;
+        for (int base = tid; base < (hd << vshift); base += 8 * 256) {  // eight loads in flight per thread
+            float tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256;
+                const int d = idx >> vshift, jj = idx & (vc - 1);
+                tv[u] = (idx < (hd << vshift) && jj < nj) ? vb[(int64_t)d * v_cs + j0 + jj] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256;
+                if (idx < (hd << vshift)) vt[(idx >> vshift) * vp + (idx & (vc - 1))] = tv[u];
+            }
+        }
+        __syncthreads();
+        const int ks = (nj + 3) >> 2;  // k-steps of this chunk (P is zero beyond len, V is zero beyond nj)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int dt = wid + 4 * u;
+            if (dt < ndt) {
+                const float* pa = sc + ln * lp + j0 + lk;
+                const float* pb = vt + (dt * 16 + ln) * vp + lk;
+                att_float4v a4 = oacc[u];
+                for (int s0 = 0; s0 < ks; s0 += 8) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8) {
+                        const int sx = s0 + w8 < ks ? s0 + w8 : ks - 1;
+                        av[w8] = pa[4 * sx];
+                        bv[w8] = pb[4 * sx];
+                    }
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8)
+                        if (s0 + w8 < ks) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[w8], bv[w8], a4, 0, 0, 0);
+                }
+                oacc[u] = a4;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- + windowed relative-value term: O += Pwin[16 q][r] . Ev[r][d] with Pwin[q][r] = P[q][i_q + r - w] (zero outside the sequence
+    // and for r >= 2w+1): (2w+1+3)/4 more k-steps per d tile ----
+    {
+        const int rsteps = (nrel + 3) >> 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int dt = wid + 4 * u;
+            if (dt < ndt) {
+                att_float4v a4 = oacc[u];
+                for (int s = 0; s < rsteps; ++s) {
+                    const int r = 4 * s + lk;
+                    const int j = i0 + ln + r - window;
+                    const float pw = (r < nrel && j >= 0 && j < len && i0 + ln < len) ? sc[ln * lp + j] : 0.f;
+                    const float ev = r < nrel ? rel_v[(int64_t)r * hd + dt * 16 + ln] : 0.f;
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw, ev, a4, 0, 0, 0);
+                }
+                oacc[u] = a4;
+            }
+        }
+    }
+    // ---- store: lane holds queries 4*lk .. 4*lk+3 of channel dt*16 + ln ----
+    float* ob = out + (int64_t)b * o_bs + (int64_t)h * hd * o_cs;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int dt = wid + 4 * u;
+        if (dt >= ndt) continue;
+        const int d = dt * 16 + ln;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * lk + r;
+            if (i < len) ob[(int64_t)d * o_cs + i] = oacc[u][r];
+        }
+    }
+}
+
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
                                 int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s) {
+    static const bool valu_only = getenv("VITS_ATT_VALU") != nullptr;
+    if (!valu_only && (head_dim & 15) == 0 && head_dim <= 128) {
+        // matrix-core version (same kernel for every grid: results do not depend on the batch)
+        size_t ldsm = 0;
+        int vsh = 6;
+        for (; vsh >= 3; --vsh) {
+            ldsm = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * att_lp(tmax) + (size_t)head_dim * ((1 << vsh) + 4));
+            if (ldsm <= 150 * 1024) break;
+        }
+        if (ldsm <= 150 * 1024) {
+            if (ldsm > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+                if (e != hipSuccess) return e;
+            }
+            dim3 gridm((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
+            hipLaunchKernelGGL(rel_attention_mfma_kernel, gridm, dim3(256), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
+                               lens, head_dim, tmax, window, q_scale, vsh);
+            return hipGetLastError();
+        }
+    }
     const int lp = (tmax + 3) & ~3;
     size_t lds = 0;
     int vshift = 6;
