@@ -522,14 +522,30 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const fl
     const int t = t0 + tl;
     const bool ok = t < len;
     float s = 0.f;
-    for (int c = g; c < channels; c += LN_GROUPS) {
-        float v = 0.f;
-        if (ok) {
-            v = x[(int64_t)b * x_bs + (int64_t)c * x_cs + t];
-            if (res) v += res[(int64_t)b * r_bs + (int64_t)c * r_cs + t];
+    // (twelve channels per step, their loads issued before the first LDS store: a load -> store loop exposes one memory latency per
+    // channel, and at batch 1 a launch has two blocks. Same values, same order of s.)
+    constexpr int UB = 12;
+    for (int c0 = g; c0 < channels; c0 += UB * LN_GROUPS) {
+        float xv[UB], rv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * LN_GROUPS;
+            const bool live = ok && c < channels;
+            xv[u] = live ? x[(int64_t)b * x_bs + (int64_t)c * x_cs + t] : 0.f;
+            rv[u] = (live && res) ? res[(int64_t)b * r_bs + (int64_t)c * r_cs + t] : 0.f;
         }
-        tile[c * 64 + tl] = v;
-        s += v;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * LN_GROUPS;
+            if (c >= channels) continue;
+            float v = 0.f;
+            if (ok) {
+                v = xv[u];
+                if (res) v += rv[u];
+            }
+            tile[c * 64 + tl] = v;
+            s += v;
+        }
     }
     red[g * 64 + tl] = s;
     __syncthreads();
