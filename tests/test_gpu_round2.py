@@ -240,3 +240,37 @@ int main(int argc, char** argv) {
         ref = om.process_ids(ids, mode=oracle.MODE_REFERENCE, noise_kind=oracle.NOISE_REFERENCE)["waveform"].astype(np.float64)
         assert int(rows[rep][0]) == ref.size
         assert abs(float(rows[rep][2]) - np.abs(ref).sum()) <= 2e-4 * np.abs(ref).sum()
+
+
+def test_fused_wavenet_layer_is_bit_identical_to_the_two_kernel_path(pkg, full_bytes, monkeypatch):
+    """wavenet32.hip (one flow WaveNet layer — gated conv, gate, 1x1 res/skip conv and both adds — as one fp32 kernel) runs the MFMA
+    chains and the epilogue expressions of the two conv_mfma launches it replaces: z_flow and the PCM must not move by a bit. Ragged
+    batch with very short members (one frame block and less), both semantics modes, and utterances long enough for several hundred
+    32-frame blocks per launch (a block that read h columns another block had already overwritten would show up there)."""
+    Ts = [30, 11, 40, 1, 2, 17]
+    ids = np.zeros((6, 40), np.int32)
+    rng = np.random.default_rng(5)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = rng.integers(1, 38, size=T)
+    long_ids = pkg.synth_ids(5, 900, ids_seed=99)  # 5 x 2700 frames = 5 x 85 blocks of 32 frames: the fused path (>= 384 blocks per launch)
+    big = pkg.synth_ids(160, 40, ids_seed=7)       # 160 short ragged utterances (~3-4 blocks each): fused as well
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("VITS_NO_WN_FUSE", "1")
+        with pkg.Model(full_bytes) as m:
+            for mode in (0, 1):
+                pcm, lengths, _ = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=21, collect_taps=True)
+                outs[(fused, mode)] = (pcm, lengths, [m.tap("z_flow", u).copy() for u in range(len(Ts))])
+            outs[(fused, "long")] = m.process_batch(long_ids, noise_seed=22, fixed_duration=3)
+            outs[(fused, "big")] = m.process_batch(big, noise_seed=23)
+    for key in ("long", "big"):
+        assert np.array_equal(outs[(True, key)][1], outs[(False, key)][1])
+        for x, y in zip(outs[(True, key)][0], outs[(False, key)][0]):
+            assert np.array_equal(x, y), key
+    for mode in (0, 1):
+        a, b_ = outs[(True, mode)], outs[(False, mode)]
+        assert np.array_equal(a[1], b_[1])
+        for u in range(len(Ts)):
+            assert np.array_equal(a[2][u], b_[2][u]), ("z_flow", mode, u)
+            assert np.array_equal(a[0][u], b_[0][u]), ("pcm", mode, u)

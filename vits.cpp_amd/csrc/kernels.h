@@ -137,6 +137,14 @@ struct RbPair32Call {
     float post_slope = 0.f;
 };
 bool rbpair32_supported(int channels, int kt, int dil);
+// one WaveNet layer of the flow (gated conv + 1x1 res/skip conv + the two adds) as one fp32 kernel (wavenet32.hip); h_out must not alias h
+struct WaveNet32Call {
+    TensorRef h, h_out, outputs;
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0, hidden = 0, dil = 1;
+};
+bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs);
+hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, hipStream_t s);
 hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbPair32Call& c, hipStream_t s);
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);

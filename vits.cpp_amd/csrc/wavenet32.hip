@@ -1,0 +1,253 @@
+// wavenet32.hip — one WaveNet layer of the residual-coupling flow as a single kernel, exact-fp32 arithmetic:
+//     acts = tanh(in[0:H]) * sigmoid(in[H:2H]),  in = Conv_{k,1}(h) + b_in                 (/root/reference/src/vits.cpp:470-483)
+//     rs   = Conv_{1x1}(acts) + b_rs;  h' = h + rs[0:H];  outputs += rs[H:2H]                (vits.cpp:484-491; last layer: outputs += rs)
+// As two launches (gated conv, then the 1x1 res/skip conv) a layer is 0.18 ms at batch 64 x 225 frames for 12.7 GFLOP (0.08 ms at the
+// fp32 MFMA peak): few hundred columns per utterance, 64- and 128-column tiles a quarter empty, two prologues / epilogues. Here a block
+// owns 32 frames: the h tile goes into LDS once, the six waves run the gated conv (wave w: the tanh and the sigmoid row tile of
+// channels 32w..32w+31), the gate is applied in registers, acts take the h tile's place in LDS, the same six waves run the 1x1 conv
+// from there and the epilogue adds into h / outputs. Same MFMA chain per output as conv_mfma.hip (chunk, tap, channel pair) and the
+// same epilogue expressions: bit-identical to the two-launch path (GPU test), which stays for other shapes, for the 16-bit modes
+// and behind VITS_NO_WN_FUSE=1.
+// A block reads a 2-frame halo of its neighbours' h columns while other blocks already store h': h' goes to ANOTHER buffer
+// (Engine::run_batch alternates two); `outputs` has no halo and is updated in place.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../../include/vits.h"
+#include "kernels.h"
+
+namespace vits {
+
+typedef float wn_floatx16 __attribute__((ext_vector_type(16)));
+typedef float wn_float4v __attribute__((ext_vector_type(4)));
+
+struct WaveNet32Params {
+    const float* h;  // [b][H][t]
+    int64_t h_bs;
+    int h_cs;
+    float* h_out;  // h' (null on the last layer)
+    int64_t ho_bs;
+    int ho_cs;
+    float* outputs;  // skip accumulator [b][H][t]
+    int64_t o_bs;
+    int o_cs;
+    const float *w_in, *b_in;  // gated conv: packed EPI_GATE fragments (tile 2i = tanh rows of channels 32i.., 2i+1 = sigmoid rows)
+    const float *w_rs, *b_rs;  // 1x1 res/skip conv: packed EPI_STD fragments, rs_rows = 2H (H on the last layer)
+    int rs_rows;
+    const int* lens;
+    int tmax;
+};
+
+template <int H, int KT>
+__global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Params p) {
+    constexpr int NW = H / 32;   // waves = channel groups of 32
+    constexpr int NCH = H / 32;  // 32-channel chunks of K
+    constexpr int NR = 1;        // 32-frame column tiles per wave (NR = 2: 64-frame blocks, one per CU at batch 64 x 225 frames — six waves
+                                 // on four SIMDs then run as (2, 2, 1, 1): 2.72 ms per step against 2.55; two co-resident blocks balance)
+    constexpr int BM = NR * 32;  // frames per block
+    constexpr int P = (KT - 1) / 2;
+    constexpr int XWP = (BM + KT - 1 + 3 + 3) / 4 * 4;  // h tile row pitch (floats): + up to 3 columns of alignment shift
+    constexpr int XW4 = XWP / 4;
+    constexpr int TWP = BM;              // acts tile row pitch
+    constexpr int TOTAL1 = NCH * KT * 4;  // A-fragment steps of the gated conv per row tile
+    constexpr int TOTAL2 = NCH * 4;       // ... of the 1x1 conv
+    static_assert(TWP <= XWP, "acts take the h tile's place");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;
+    float* ts = lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    const int t0 = blockIdx.x * BM;
+    if (t0 >= len) return;
+    const int krow = lane >> 5, col = lane & 31;
+
+    // ---- the h tile, all channels, straight into LDS; LDS column 0 = global frame ts0 (16-byte aligned source) ----
+    const int tx0 = t0 - P;
+    const int ts0 = tx0 & ~3;
+    const int shift = tx0 - ts0;
+    const float* hb = p.h + (int64_t)b * p.h_bs;
+    {
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, 0x7fffffff, 0x00020000);
+        const int tlast = (len - 1) & ~3;
+        constexpr int N4 = H * XW4;
+        constexpr int NI = (N4 + 63) / 64;
+#pragma unroll
+        for (int n0 = 0; n0 < NI; n0 += NW) {
+            const int n = n0 + wid;
+            if (n < NI) {
+                int g = n * 64 + lane;
+                g = g < N4 ? g : N4 - 1;
+                const int r = g / XW4, c4 = g - r * XW4;
+                int t = ts0 + 4 * c4;
+                t = t < 0 ? 0 : (t > tlast ? tlast : t);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xs + n * 256), 16, (r * p.h_cs + t) * 4, 0, 0, 0);
+            }
+        }
+    }
+    // biases of this lane's rows (accumulator register r <-> channel 32*wid + 8*(r/4) + 4*krow + r%4)
+    float bt[16], bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = wid * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+        bt[r] = p.b_in[ch];
+        bs[r] = p.b_in[H + ch];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {  // zero padding outside the sequence
+        wn_float4v* x4 = reinterpret_cast<wn_float4v*>(xs);
+        constexpr int N4 = H * XW4;
+        if (ts0 < 0 || ts0 + XWP > len) {
+            for (int g = tid; g < N4; g += 2 * H) {
+                const int r = g / XW4, c4 = g - r * XW4;
+                const int t = ts0 + 4 * c4;
+                wn_float4v v = x4[g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < 0 || t + e >= len) v[e] = 0.f;
+                x4[g] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    typedef const __attribute__((address_space(3))) float* LdsF;
+    wn_floatx16 acc[2][NR];
+
+    // one conv over the LDS tile for this wave's TWO row tiles mt0, mt0 + 1 (order per output: chunk, tap, channel pair)
+    auto conv = [&](const float* wp, int mt0, auto total_c, auto taps_c, LdsF base, const int pitch) __attribute__((always_inline)) {
+        constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nr][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
+        int wvoff[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wvoff[m] = (int)(((size_t)(mt0 + m) * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_float4v {
+            return __builtin_bit_cast(wn_float4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
+        };
+        wn_float4v ring[4][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ring[0][m] = load_a(m, 0);
+            ring[1][m] = load_a(m, 1 < TOTAL ? 1 : 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int j = 0; j < TAPS; ++j) {
+                LdsF xj = base + (c * 32) * pitch + j;
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int s = (c * TAPS + j) * 4 + p4;  // compile time after unrolling
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ring[(s + 2) & 3][m] = load_a(m, s + 2 < TOTAL ? s + 2 : TOTAL - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float bv[NR];
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) bv[nr] = xj[(2 * (p4 * 4 + q)) * pitch + nr * 32];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int nr = 0; nr < NR; ++nr) acc[m][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[s & 3][m][q], bv[nr], acc[m][nr], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- gated conv: packed tiles 2*wid (tanh rows) and 2*wid + 1 (sigmoid rows) ----
+    conv(p.w_in, 2 * wid, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsF)(xs + krow * XWP + shift + col), XWP);
+    __syncthreads();  // every wave is done with the h tile: acts take its place
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const bool inside = t0 + nr * 32 + col < len;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = wid * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+            const float v = tanhf(acc[0][nr][r] + bt[r]) * (1.0f / (1.0f + expf(-(acc[1][nr][r] + bs[r]))));
+            ts[ch * TWP + nr * 32 + col] = inside ? v : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- 1x1 res/skip conv: row tiles 2*wid, 2*wid + 1 of rs_rows / 32 ----
+    const int ntiles2 = p.rs_rows >> 5;
+    if (2 * wid >= ntiles2) return;  // (last layer: H rows = NW tiles: the upper half of the waves has none)
+    conv(p.w_rs, 2 * wid, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsF)(ts + krow * TWP + col), TWP);
+
+    // ---- epilogue: rows < H of a 2H-row layer -> h' = h + rs; the other rows -> outputs += rs ----
+    const bool two = p.rs_rows > H;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int t = t0 + nr * 32 + col;
+        if (t >= len) continue;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (2 * wid + m >= ntiles2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (2 * wid + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                float v = acc[m][nr][r] + p.b_rs[row];
+                if (two && row < H) {
+                    v = hb[(int64_t)row * p.h_cs + t] + v;
+                    p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
+                } else {
+                    float* op = p.outputs + (int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t;
+                    *op = *op + v;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs) {
+    if (hidden != 192 || kt != 5 || dil != 1) return false;
+    if (!in.wp || !rs.wp || !in.bias || !rs.bias || in.epi != EPI_GATE || rs.epi != EPI_STD) return false;
+    if (in.cin != hidden || in.cout != 2 * hidden || in.kt != kt || rs.cin != hidden || rs.kt != 1) return false;
+    return rs.cout == 2 * hidden || rs.cout == hidden;
+}
+
+hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, hipStream_t s) {
+    constexpr int H = 192, KT = 5;
+    if (!wavenet32_supported(c.hidden, in.kt, c.dil, in, rs)) return hipErrorInvalidValue;
+    if ((c.h.cs & 3) || (c.h.bs & 3) || (reinterpret_cast<uintptr_t>(c.h.p) & 15)) return hipErrorInvalidValue;
+    if (rs.cout == 2 * H && (!c.h_out.p || c.h_out.p == c.h.p)) return hipErrorInvalidValue;
+    WaveNet32Params p;
+    p.h = c.h.p;
+    p.h_bs = c.h.bs;
+    p.h_cs = c.h.cs;
+    p.h_out = c.h_out.p;
+    p.ho_bs = c.h_out.bs;
+    p.ho_cs = c.h_out.cs;
+    p.outputs = c.outputs.p;
+    p.o_bs = c.outputs.bs;
+    p.o_cs = c.outputs.cs;
+    p.w_in = in.wp;
+    p.b_in = in.bias;
+    p.w_rs = rs.wp;
+    p.b_rs = rs.bias;
+    p.rs_rows = rs.cout;
+    p.lens = c.lens;
+    p.tmax = c.tmax;
+    constexpr int XWP = (32 + KT - 1 + 3 + 3) / 4 * 4;
+    const size_t ldsz = ((size_t)H * XWP * sizeof(float) + 1023) / 1024 * 1024;
+    dim3 grid((c.tmax + 31) / 32, c.batch);
+    hipLaunchKernelGGL((wavenet32_kernel<H, KT>), grid, dim3(2 * H), ldsz, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace vits
