@@ -3,8 +3,8 @@
 //     rs   = Conv_{1x1}(acts) + b_rs;  h' = h + rs[0:H];  outputs += rs[H:2H]                (vits.cpp:484-491; last layer: outputs += rs)
 // As two launches (gated conv, then the 1x1 res/skip conv) a layer is 0.18 ms at batch 64 x 225 frames for 12.7 GFLOP (0.08 ms at the
 // fp32 MFMA peak): few hundred columns per utterance, 64- and 128-column tiles a quarter empty, two prologues / epilogues. Here a block
-// owns 32 frames: the h tile goes into LDS once, the six waves run the gated conv (wave w: the tanh and the sigmoid row tile of
-// channels 32w..32w+31), the gate is applied in registers, acts take the h tile's place in LDS, the same six waves run the 1x1 conv
+// owns 64 frames: the h tile goes into LDS once, twelve waves — one per (32-channel group, 32-frame column tile) — run the gated conv
+// (the tanh and the sigmoid row tile of the group), the gate is applied in registers, acts take the h tile's place in LDS, the same waves run the 1x1 conv
 // from there and the epilogue adds into h / outputs. Same MFMA chain per output as conv_mfma.hip (chunk, tap, channel pair) and the
 // same epilogue expressions: bit-identical to the two-launch path (GPU test), which stays for other shapes, for the 16-bit modes
 // and behind VITS_NO_WN_FUSE=1.
@@ -43,12 +43,13 @@ struct WaveNet32Params {
 };
 
 template <int H, int KT>
-__global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Params p) {
-    constexpr int NW = H / 32;   // waves = channel groups of 32
+__global__ __launch_bounds__(4 * H, 1) void wavenet32_kernel(const WaveNet32Params p) {
+    constexpr int NG = H / 32;   // channel groups of 32 = gate row-tile pairs
+    constexpr int NC = 2;        // 32-frame column tiles per block: one wave per (channel group, column tile)
+    constexpr int NW = NG * NC;  // 12 waves at H = 192: three per SIMD (six waves on four SIMDs ran (2, 2, 1, 1): 160 us per layer against 110)
     constexpr int NCH = H / 32;  // 32-channel chunks of K
-    constexpr int NR = 1;        // 32-frame column tiles per wave (NR = 2: 64-frame blocks, one per CU at batch 64 x 225 frames — six waves
-                                 // on four SIMDs then run as (2, 2, 1, 1): 2.72 ms per step against 2.55; two co-resident blocks balance)
-    constexpr int BM = NR * 32;  // frames per block
+    constexpr int NR = 1;        // 32-frame column tiles per wave
+    constexpr int BM = NC * 32;  // frames per block
     constexpr int P = (KT - 1) / 2;
     constexpr int XWP = (BM + KT - 1 + 3 + 3) / 4 * 4;  // h tile row pitch (floats): + up to 3 columns of alignment shift
     constexpr int XW4 = XWP / 4;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
     const int len = p.lens ? p.lens[b] : p.tmax;
     const int t0 = blockIdx.x * BM;
     if (t0 >= len) return;
-    const int krow = lane >> 5, col = lane & 31;
+    const int krow = lane >> 5;
+    const int gw = wid % NG, col = (wid / NG) * 32 + (lane & 31);  // this wave's channel group and (block-local) frame
 
     // ---- the h tile, all channels, straight into LDS; LDS column 0 = global frame ts0 (16-byte aligned source) ----
     const int tx0 = t0 - P;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
     float bt[16], bs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int ch = wid * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+        const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
         bt[r] = p.b_in[ch];
         bs[r] = p.b_in[H + ch];
     }
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
         wn_float4v* x4 = reinterpret_cast<wn_float4v*>(xs);
         constexpr int N4 = H * XW4;
         if (ts0 < 0 || ts0 + XWP > len) {
-            for (int g = tid; g < N4; g += 2 * H) {
+            for (int g = tid; g < N4; g += 64 * NW) {
                 const int r = g / XW4, c4 = g - r * XW4;
                 const int t = ts0 + 4 * c4;
                 wn_float4v v = x4[g];
@@ -169,14 +171,14 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
     };
 
     // ---- gated conv: packed tiles 2*wid (tanh rows) and 2*wid + 1 (sigmoid rows) ----
-    conv(p.w_in, 2 * wid, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsF)(xs + krow * XWP + shift + col), XWP);
+    conv(p.w_in, 2 * gw, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsF)(xs + krow * XWP + shift + col), XWP);
     __syncthreads();  // every wave is done with the h tile: acts take its place
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const bool inside = t0 + nr * 32 + col < len;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ch = wid * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+            const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
             const float v = tanhf(acc[0][nr][r] + bt[r]) * (1.0f / (1.0f + expf(-(acc[1][nr][r] + bs[r]))));
             ts[ch * TWP + nr * 32 + col] = inside ? v : 0.f;
         }
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
 
     // ---- 1x1 res/skip conv: row tiles 2*wid, 2*wid + 1 of rs_rows / 32 ----
     const int ntiles2 = p.rs_rows >> 5;
-    if (2 * wid >= ntiles2) return;  // (last layer: H rows = NW tiles: the upper half of the waves has none)
-    conv(p.w_rs, 2 * wid, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsF)(ts + krow * TWP + col), TWP);
+    if (2 * gw >= ntiles2) return;  // (last layer: H rows = NW tiles: the upper half of the waves has none)
+    conv(p.w_rs, 2 * gw, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsF)(ts + krow * TWP + col), TWP);
 
     // ---- epilogue: rows < H of a 2H-row layer -> h' = h + rs; the other rows -> outputs += rs ----
     const bool two = p.rs_rows > H;
@@ -196,10 +198,10 @@ __global__ __launch_bounds__(2 * H, 3) void wavenet32_kernel(const WaveNet32Para
         if (t >= len) continue;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            if (2 * wid + m >= ntiles2) continue;
+            if (2 * gw + m >= ntiles2) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (2 * wid + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
                 float v = acc[m][nr][r] + p.b_rs[row];
                 if (two && row < H) {
                     v = hb[(int64_t)row * p.h_cs + t] + v;
@@ -243,10 +245,10 @@ hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const Wa
     p.rs_rows = rs.cout;
     p.lens = c.lens;
     p.tmax = c.tmax;
-    constexpr int XWP = (32 + KT - 1 + 3 + 3) / 4 * 4;
+    constexpr int XWP = (64 + KT - 1 + 3 + 3) / 4 * 4;
     const size_t ldsz = ((size_t)H * XWP * sizeof(float) + 1023) / 1024 * 1024;
-    dim3 grid((c.tmax + 31) / 32, c.batch);
-    hipLaunchKernelGGL((wavenet32_kernel<H, KT>), grid, dim3(2 * H), ldsz, s, p);
+    dim3 grid((c.tmax + 63) / 64, c.batch);
+    hipLaunchKernelGGL((wavenet32_kernel<H, KT>), grid, dim3(4 * H), ldsz, s, p);
     return hipGetLastError();
 }
 
