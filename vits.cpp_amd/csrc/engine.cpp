@@ -9,7 +9,61 @@
 #include <random>
 #include <sstream>
 
+#include <dlfcn.h>
+
 namespace vits {
+
+// ---- roctx ranges (VITS_ROCTX=1): the phases of a call as marker ranges for `rocprofv3 --marker-trace --kernel-trace` ---------
+// The marker library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so): no link-time dependency, and
+// nothing at all happens unless the variable is set. Host-side ranges: they bracket the ENQUEUE of a phase's kernels (the call
+// is asynchronous up to the one frame-count read-back), which is what a timeline viewer lines up with the kernel trace.
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        if (!std::getenv("VITS_ROCTX")) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const RoctxApi& roctx_api() {
+    static const RoctxApi api;
+    return api;
+}
+// consecutive phases of one call: phase(n) closes the previous range and opens the next; the destructor closes the last
+struct RoctxPhases {
+    bool open = false;
+    void phase(const char* name) {
+        const RoctxApi& a = roctx_api();
+        if (!a.push) return;
+        if (open) a.pop();
+        a.push(name);
+        open = true;
+    }
+    ~RoctxPhases() {
+        if (open) roctx_api().pop();
+    }
+};
+// a nested range (one vocoder stage)
+struct RoctxRange {
+    bool open = false;
+    explicit RoctxRange(const char* name) {
+        const RoctxApi& a = roctx_api();
+        if (a.push) {
+            a.push(name);
+            open = true;
+        }
+    }
+    ~RoctxRange() {
+        if (open) roctx_api().pop();
+    }
+};
+}  // namespace
 
 #define HIP_OK(expr)                                                                      \
     do {                                                                                  \
@@ -924,6 +978,8 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     };
 
     // ---- text encoder (vits.cpp:244-440) ---------------------------------------------------------------------
+    RoctxPhases rx;
+    rx.phase("vits.text_encoder");
     prof.begin("embed", 0, 0, stream);
     HIP_OK(launch_embed(s1.ids, id_stride, dl, emb_, H, (float)std::sqrt((double)H), x, B, Tmax, stream));
     prof.end(stream);
@@ -967,6 +1023,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     }
 
     // ---- stochastic duration predictor, reverse (vits.cpp:927-972) ----------------------------------------
+    rx.phase("vits.duration_predictor");
     TensorRef dpx = TR(s1.dpx, H, ts), dpy = TR(s1.dpy, H, ts), dpp = TR(s1.dpp, H, ts), cond = TR(s1.cond, H, ts), z = TR(s1.z, 2, ts), u = TR(s1.u, 32, ts);
     HIP_OK(conv("conv1x1_dp", dp_pre_, mk(x, dpx, Tmax)));
     HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax, sum_t));
@@ -1025,6 +1082,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     prof.end(stream);
 
     // ---- the one data-dependent shape (vits.cpp:1133): frames per utterance ---------------------------------
+    rx.phase("vits.frame_count_sync");
     std::vector<int> frames(B);
     if (o.fixed_duration > 0) {
         for (int b = 0; b < B; ++b) frames[b] = std::max(1, o.fixed_duration * tlen[b]);
@@ -1152,6 +1210,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     const int* const* d_len = d_len_full;  // (the vocoder loop below shadows this with window-local lengths)
 
     // ---- prior sampling through the alignment (vits.cpp:1028-1064) -------------------------------------------
+    rx.phase("vits.prior_sampling");
     TensorRef zp = TR(s2.zp, F, ls), noise = TR(s2.noise, F, ls);
     if (need_noise_buf) {
         std::vector<float> hn((size_t)B * F * ls, 0.f);
@@ -1182,6 +1241,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     if (o.collect_taps) snapshot("z_p", zp, F, Lmax, B, frames);
 
     // ---- residual coupling flow, reverse (vits.cpp:519-538,500-517,452-498) ------------------------------------
+    rx.phase("vits.flow");
     {
         const int* ll = d_len[0];
         int64_t sum_frames = 0;
@@ -1269,6 +1329,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     }
 
     // ---- HiFiGAN (vits.cpp:583-644) -----------------------------------------------------------------------------
+    rx.phase("vits.hifigan");
     float* wave_dst = s2.wave;
     int64_t wave_stride = S_stride;
     if (o.out_device) {
@@ -1391,6 +1452,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             }
             for (int i = 0; i < n_up; ++i) {
                 const UpStageW& U = ups_[i];
+                char rx_stage[32];
+                std::snprintf(rx_stage, sizeof(rx_stage), "vits.hifigan.stage%d", i);
+                RoctxRange rx_stage_range(rx_stage);
                 const int C = U.channels, st_in = i, st_out = i + 1;
                 const int64_t g_bs = (int64_t)C * sts[st_out];
                 const int g_ts = sts[st_out];
@@ -1543,6 +1607,9 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             const size_t nk = hp.rb_k.size();
             for (int i = 0; i < n_up; ++i) {
                 const UpStageW& U = ups_[i];
+                char rx_stage[32];
+                std::snprintf(rx_stage, sizeof(rx_stage), "vits.hifigan.stage%d", i);
+                RoctxRange rx_stage_range(rx_stage);
                 const int C = U.channels, st_in = i, st_out = i + 1;
                 TensorRef bu = TR(s2.bu, C, sts[st_out]), bsum = TR(s2.bs, C, sts[st_out]);
                 {
@@ -1733,6 +1800,7 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         }
 
     // ---- results ------------------------------------------------------------------------------------------------
+    rx.phase("vits.results");
     if (out) {
         out->batch = (size_t)B;
         out->stride = (size_t)smax[n_up];
