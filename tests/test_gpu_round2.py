@@ -242,9 +242,10 @@ int main(int argc, char** argv) {
         assert abs(float(rows[rep][2]) - np.abs(ref).sum()) <= 2e-4 * np.abs(ref).sum()
 
 
-def test_fused_wavenet_layer_is_bit_identical_to_the_two_kernel_path(pkg, full_bytes, monkeypatch):
-    """wavenet32.hip (one flow WaveNet layer — gated conv, gate, 1x1 res/skip conv and both adds — as one fp32 kernel) runs the MFMA
-    chains and the epilogue expressions of the two conv_mfma launches it replaces: z_flow and the PCM must not move by a bit. Ragged
+@pytest.mark.parametrize("arith", [0, 2, 1], ids=["f32", "f16", "bf16"])
+def test_fused_wavenet_layer_is_bit_identical_to_the_two_kernel_path(pkg, full_bytes, monkeypatch, arith):
+    """wavenet32.hip (one flow WaveNet layer — gated conv, gate, 1x1 res/skip conv and both adds — as one kernel, fp32 and 16-bit
+    operands) runs the MFMA chains, rounding points and epilogue expressions of the launches it replaces: z_flow and the PCM must not move by a bit. Ragged
     batch with very short members (one frame block and less), both semantics modes, and utterances long enough for several hundred
     32-frame blocks per launch (a block that read h columns another block had already overwritten would show up there)."""
     Ts = [30, 11, 40, 1, 2, 17]
@@ -259,6 +260,7 @@ def test_fused_wavenet_layer_is_bit_identical_to_the_two_kernel_path(pkg, full_b
         if not fused:
             monkeypatch.setenv("VITS_NO_WN_FUSE", "1")
         with pkg.Model(full_bytes) as m:
+            m.set_arith(arith)
             for mode in (0, 1):
                 pcm, lengths, _ = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=21, collect_taps=True)
                 outs[(fused, mode)] = (pcm, lengths, [m.tap("z_flow", u).copy() for u in range(len(Ts))])

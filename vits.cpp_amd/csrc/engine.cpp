@@ -1273,12 +1273,13 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
             // gate output; `outputs` (hout[H,2H)) is updated in place.
             // (large grids only: at batch 1 a layer is four blocks, and a block's six waves on four SIMDs run two MFMA chains deep:
             // 68 us against 39 us for the two launches with their split-gate tiles)
-            bool fuse_wn = arith == VITS_ARITH_F32 && std::getenv("VITS_NO_WN_FUSE") == nullptr && (ls & 3) == 0 && (int64_t)((Lmax + 31) / 32) * B >= 384 &&
+            bool fuse_wn = std::getenv("VITS_NO_WN_FUSE") == nullptr && (ls & 3) == 0 && (int64_t)((Lmax + 31) / 32) * B >= 384 &&
                            (reinterpret_cast<uintptr_t>(hout.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(gate.p) & 15) == 0;
             for (int l = 0; l < hp.wn_layers && fuse_wn; ++l) {
                 int dl = 1;
                 for (int q = 0; q < l; ++q) dl *= hp.wn_rate;
-                fuse_wn = wavenet32_supported(H, hp.wn_k, dl, Lw.in_layers[l], Lw.res_skip[l]) &&
+                fuse_wn = (arith == VITS_ARITH_F32 ? wavenet32_supported(H, hp.wn_k, dl, Lw.in_layers[l], Lw.res_skip[l])
+                                                   : wavenet16_supported(H, hp.wn_k, dl, Lw.in_layers[l], Lw.res_skip[l])) &&
                           Lw.res_skip[l].cout == (l + 1 < hp.wn_layers ? 2 * H : H);
             }
             if (fuse_wn) {
@@ -1296,11 +1297,12 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
                     w.dil = 1;
                     if (prof.on) {
                         char full[160];
-                        std::snprintf(full, sizeof(full), "flow_wavenet_layer|k%d|d1|w%d|e1|c%dx%d", hp.wn_k, H, H, Lw.res_skip[l].cout);
+                        std::snprintf(full, sizeof(full), "flow_wavenet_layer|k%d|d1|%c%d|e1|c%dx%d", hp.wn_k, arith == VITS_ARITH_F32 ? 'w' : 'W', H, H, Lw.res_skip[l].cout);
                         prof.begin(full, 2.0 * ((double)2 * H * H * hp.wn_k + (double)Lw.res_skip[l].cout * H) * (double)sum_frames,
                                    4.0 * (double)sum_frames * (H + 2.0 * Lw.res_skip[l].cout) + (double)Lw.in_layers[l].bytes + (double)Lw.res_skip[l].bytes, stream, true);
                     }
-                    HIP_OK(launch_wavenet32(Lw.in_layers[l], Lw.res_skip[l], w, stream));
+                    if (arith == VITS_ARITH_F32) HIP_OK(launch_wavenet32(Lw.in_layers[l], Lw.res_skip[l], w, stream));
+                    else HIP_OK(launch_wavenet16(Lw.in_layers[l], Lw.res_skip[l], w, arith, stream));
                     prof.end(stream);
                     if (w.h_out.p) hcur = w.h_out;
                 }

@@ -145,6 +145,8 @@ struct WaveNet32Call {
 };
 bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs);
 hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, hipStream_t s);
+bool wavenet16_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs);  // the same layer on 16-bit operands
+hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, int arith, hipStream_t s);
 hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbPair32Call& c, hipStream_t s);
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);

@@ -215,6 +215,168 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet32_kernel(const WaveNet32Para
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same layer in the 16-bit-operand modes (VITS_ARITH_F16 / BF16): operands rounded where the two-launch path rounds them (h and
+// acts at the converter in front of each conv16 launch: here when the tile is written to LDS), v_mfma_f32_32x32x16_{f16,bf16} on the
+// packed 16-bit fragments, fp32 accumulate / bias / gate / residual. The h tile is loaded through registers (it has to be converted
+// anyway) into the group layout [c/8][frame][8] — one ds_read_b128 per MFMA operand. Saves two converter launches per layer as well.
+// Bit-identical to to_group16 + conv16 (gate) + to_group16 + conv16 (1x1) (GPU test).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef int wn_int4v __attribute__((ext_vector_type(4)));
+typedef _Float16 wn_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct WaveNet16Params {
+    WaveNet32Params f;  // h / h_out / outputs / biases / lens as in the fp32 kernel (w_in / w_rs unused)
+    const uint16_t *w_in16, *w_rs16;
+};
+
+template <bool BF>
+__device__ __forceinline__ uint16_t wn_round16(float v) {
+    if constexpr (BF) {
+        const __bf16 h = (__bf16)v;
+        return __builtin_bit_cast(uint16_t, h);
+    } else {
+        const _Float16 h = (_Float16)v;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+}
+
+template <int H, int KT, bool BF>
+__global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Params pp) {
+    const WaveNet32Params& p = pp.f;
+    constexpr int NG = H / 32, NC = 2, NW = NG * NC;
+    constexpr int NCH = H / 32;
+    constexpr int BM = NC * 32;
+    constexpr int P = (KT - 1) / 2;
+    constexpr int XS = BM + KT - 1;  // slots per group row of the h tile
+    constexpr int TOTAL1 = NCH * KT * 2, TOTAL2 = NCH * 2;  // A-fragment steps (one MFMA each) per row tile
+    extern __shared__ __attribute__((aligned(16))) wn_int4v l16[];
+    wn_int4v* xs = l16;  // [G][XS]
+    wn_int4v* ts = l16;  // [G][BM]  (acts take the h tile's place)
+    static_assert(BM <= XS, "acts take the h tile's place");
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    const int t0 = blockIdx.x * BM;
+    if (t0 >= len) return;
+    const int krow = lane >> 5;
+    const int gw = wid % NG, col = (wid / NG) * 32 + (lane & 31);
+    const float* hb = p.h + (int64_t)b * p.h_bs;
+
+    // ---- the h tile through registers: rounded, group layout; zero outside the sequence ----
+    {
+        constexpr int NTH = 64 * NW, TOTALX = H * XS, PER = (TOTALX + NTH - 1) / NTH;
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NTH;
+            const int c = idx / XS, i = idx - c * XS;
+            const int t = t0 - P + i;
+            v[u] = (idx < TOTALX && t >= 0 && t < len) ? hb[(int64_t)c * p.h_cs + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NTH;
+            if (idx < TOTALX) {
+                const int c = idx / XS, i = idx - c * XS;
+                reinterpret_cast<uint16_t*>(xs + (c >> 3) * XS + i)[c & 7] = wn_round16<BF>(v[u]);
+            }
+        }
+    }
+    float bt[16], bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+        bt[r] = p.b_in[ch];
+        bs[r] = p.b_in[H + ch];
+    }
+    __syncthreads();
+
+    typedef const __attribute__((address_space(3))) wn_int4v* LdsV;
+    wn_floatx16 acc[2];
+    auto mfma = [&](wn_int4v a, wn_int4v bq, wn_floatx16 c) __attribute__((always_inline)) -> wn_floatx16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, bq), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_half8, a), __builtin_bit_cast(wn_half8, bq), c, 0, 0, 0);
+    };
+    // one conv for this wave's two row tiles mt0, mt0 + 1: order per output = chunk, tap, k-half (conv16.hip's)
+    auto conv = [&](const uint16_t* wp, int mt0, auto total_c, auto taps_c, LdsV base, const int pitch) __attribute__((always_inline)) {
+        constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+        int wvoff[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wvoff[m] = (int)(((size_t)(mt0 + m) * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_int4v {
+            return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
+        };
+        wn_int4v ring[4][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ring[0][m] = load_a(m, 0);
+            ring[1][m] = load_a(m, 1 < TOTAL ? 1 : 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < TAPS; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int s = (c * TAPS + j) * 2 + kk;  // compile time after unrolling
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ring[(s + 2) & 3][m] = load_a(m, s + 2 < TOTAL ? s + 2 : TOTAL - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const wn_int4v bq = base[(c * 4 + 2 * kk) * pitch + j];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = mfma(ring[s & 3][m], bq, acc[m]);
+                }
+    };
+
+    // ---- gated conv ----
+    conv(pp.w_in16, 2 * gw, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsV)(xs + krow * XS + col), XS);
+    __syncthreads();
+    {
+        const bool inside = t0 + col < len;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+            float v = tanhf(acc[0][r] + bt[r]) * (1.0f / (1.0f + expf(-(acc[1][r] + bs[r]))));
+            asm volatile("" : "+v"(v));  // (two roundings, as the two-launch path: fp32 acts to memory, 16-bit at the converter)
+            reinterpret_cast<uint16_t*>(ts + (ch >> 3) * BM + col)[ch & 7] = inside ? wn_round16<BF>(v) : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+
+    // ---- 1x1 res/skip conv ----
+    const int ntiles2 = p.rs_rows >> 5;
+    if (2 * gw >= ntiles2) return;
+    conv(pp.w_rs16, 2 * gw, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col), BM);
+
+    const int t = t0 + col;
+    if (t >= len) return;
+    const bool two = p.rs_rows > H;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (2 * gw + m >= ntiles2) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+            float v = acc[m][r] + p.b_rs[row];
+            if (two && row < H) {
+                v = hb[(int64_t)row * p.h_cs + t] + v;
+                p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
+            } else {
+                float* op = p.outputs + (int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t;
+                *op = *op + v;
+            }
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs) {
     if (hidden != 192 || kt != 5 || dil != 1) return false;
@@ -249,6 +411,43 @@ hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const Wa
     const size_t ldsz = ((size_t)H * XWP * sizeof(float) + 1023) / 1024 * 1024;
     dim3 grid((c.tmax + 63) / 64, c.batch);
     hipLaunchKernelGGL((wavenet32_kernel<H, KT>), grid, dim3(4 * H), ldsz, s, p);
+    return hipGetLastError();
+}
+
+bool wavenet16_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs) {
+    if (hidden != 192 || kt != 5 || dil != 1) return false;
+    if (!in.wp16 || !rs.wp16 || !in.bias || !rs.bias || in.epi != EPI_GATE || rs.epi != EPI_STD) return false;
+    if (in.cin != hidden || in.cout != 2 * hidden || in.kt != kt || rs.cin != hidden || rs.kt != 1) return false;
+    return rs.cout == 2 * hidden || rs.cout == hidden;
+}
+
+hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, int arith, hipStream_t s) {
+    constexpr int H = 192, KT = 5;
+    if (!wavenet16_supported(c.hidden, in.kt, c.dil, in, rs) || arith == VITS_ARITH_F32) return hipErrorInvalidValue;
+    if (rs.cout == 2 * H && (!c.h_out.p || c.h_out.p == c.h.p)) return hipErrorInvalidValue;
+    WaveNet16Params p;
+    p.f.h = c.h.p;
+    p.f.h_bs = c.h.bs;
+    p.f.h_cs = c.h.cs;
+    p.f.h_out = c.h_out.p;
+    p.f.ho_bs = c.h_out.bs;
+    p.f.ho_cs = c.h_out.cs;
+    p.f.outputs = c.outputs.p;
+    p.f.o_bs = c.outputs.bs;
+    p.f.o_cs = c.outputs.cs;
+    p.f.w_in = nullptr;
+    p.f.b_in = in.bias;
+    p.f.w_rs = nullptr;
+    p.f.b_rs = rs.bias;
+    p.f.rs_rows = rs.cout;
+    p.f.lens = c.lens;
+    p.f.tmax = c.tmax;
+    p.w_in16 = in.wp16;
+    p.w_rs16 = rs.wp16;
+    const size_t ldsz = (size_t)(H / 8) * (64 + KT - 1) * 16;
+    dim3 grid((c.tmax + 63) / 64, c.batch);
+    if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true>), grid, dim3(4 * H), ldsz, s, p);
+    else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false>), grid, dim3(4 * H), ldsz, s, p);
     return hipGetLastError();
 }
 
