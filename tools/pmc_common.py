@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4, (4, 1, 1, 1): 5}
 _CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
 _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
+_WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
 _RBPAIR32 = re.compile(r"rbpair32_kernel<(-?\d+), (-?\d+), (\d+)>")
 _RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)(?:, \w+)?>")
@@ -28,6 +29,10 @@ def bench_key(kernel_name):
     if m:  # `rbpair16_kernel<11, 1, 64, 2, false>` -> `k11|d1|F64|e0g`
         kt, dil, c = m.groups()[:3]
         return f"k{kt}|d{dil}|F{c}|e0g"
+    m = _WAVENET16.search(kernel_name)
+    if m:  # `wavenet16_kernel<192, 5, false>` -> `k5|d1|W192|e1`
+        h, kt, _ = m.groups()
+        return f"k{kt}|d1|W{h}|e1"
     m = _WAVENET32.search(kernel_name)
     if m:  # `wavenet32_kernel<192, 5>` -> `k5|d1|w192|e1`
         h, kt = m.groups()

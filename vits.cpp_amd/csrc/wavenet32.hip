@@ -314,12 +314,14 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Para
         auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_int4v {
             return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
         };
-        wn_int4v ring[4][2];
+        // (a step is ONE 32-cycle MFMA per row tile: eight slots, six steps of look-ahead — two steps, as in the fp32 kernels whose
+        // steps are 16 times longer, left the loop waiting for L2)
+        constexpr int RS = 8, RD = 6;
+        wn_int4v ring[RS][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ring[0][m] = load_a(m, 0);
-            ring[1][m] = load_a(m, 1 < TOTAL ? 1 : 0);
-        }
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < RD; ++i) ring[i][m] = load_a(m, i < TOTAL ? i : TOTAL - 1);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -328,11 +330,11 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Para
                 for (int kk = 0; kk < 2; ++kk) {
                     const int s = (c * TAPS + j) * 2 + kk;  // compile time after unrolling
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) ring[(s + 2) & 3][m] = load_a(m, s + 2 < TOTAL ? s + 2 : TOTAL - 1);
+                    for (int m = 0; m < 2; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
                     __builtin_amdgcn_sched_barrier(0);
                     const wn_int4v bq = base[(c * 4 + 2 * kk) * pitch + j];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = mfma(ring[s & 3][m], bq, acc[m]);
+                    for (int m = 0; m < 2; ++m) acc[m] = mfma(ring[s % RS][m], bq, acc[m]);
                 }
     };
 
