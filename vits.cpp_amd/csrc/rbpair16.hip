@@ -154,12 +154,18 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
         auto load_a = [&](int mr, int step) __attribute__((always_inline)) -> int4v {
             return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
         };
-        int4v ring[4][MR];
+        // weight-fragment ring: RS slots, fetched RD steps ahead. A step is NR 32-cycle MFMAs per row tile (64-128 cycles): two steps of
+        // look-ahead do not cover an L2 round trip. Eight slots where the register budget of the occupancy target has room for them
+        // (C = 128: 145 of 168 VGPRs; C = 256 is capped at 128 and C <= 64 carries MR x NR = 4 accumulator tiles: both spill)
+#ifndef VITS_RB16_RING
+#define VITS_RB16_RING 8
+#endif
+        constexpr int RS = (ROWS && C == 128) ? VITS_RB16_RING : 4, RD = RS - 2;
+        int4v ring[RS][MR];
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            ring[0][mr] = load_a(mr, 0);
-            ring[1][mr] = load_a(mr, 1);
-        }
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int i = 0; i < RD; ++i) ring[i][mr] = load_a(mr, i < TOTAL ? i : TOTAL - 1);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             LdsV xb = base + c * 4 * pitch;
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
                 for (int kk = 0; kk < 2; ++kk) {
                     const int s = c * STEPS + j * 2 + kk;  // compile time after unrolling
                     {
-                        const int nstep = s + 2 < TOTAL ? s + 2 : TOTAL - 1;
+                        const int nstep = s + RD < TOTAL ? s + RD : TOTAL - 1;
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) ring[(s + 2) & 3][mr] = load_a(mr, nstep);
+                        for (int mr = 0; mr < MR; ++mr) ring[(s + RD) % RS][mr] = load_a(mr, nstep);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     int4v b_cur[NR];
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s & 3][mr], b_cur[nr], acc[mr][nr]);
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s % RS][mr], b_cur[nr], acc[mr][nr]);
                 }
         }
     };
