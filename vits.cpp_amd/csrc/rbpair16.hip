@@ -155,12 +155,12 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
             return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[mr], step * 1024, 0));
         };
         // weight-fragment ring: RS slots, fetched RD steps ahead. A step is NR 32-cycle MFMAs per row tile (64-128 cycles): two steps of
-        // look-ahead do not cover an L2 round trip. Eight slots where the register budget of the occupancy target has room for them
-        // (C = 128: 145 of 168 VGPRs; C = 256 is capped at 128 and C <= 64 carries MR x NR = 4 accumulator tiles: both spill)
+        // look-ahead do not cover an L2 round trip. Eight slots where they measured faster: C = 128 (-6 %) and C = 32 (-5 %); C = 64
+        // (144-149 VGPRs with them) came out 5-10 % slower on k = 3 / 7, and C = 256 is capped at 128 VGPRs (spills)
 #ifndef VITS_RB16_RING
 #define VITS_RB16_RING 8
 #endif
-        constexpr int RS = (ROWS && C == 128) ? VITS_RB16_RING : 4, RD = RS - 2;
+        constexpr int RS = (C == 128 || C == 32) ? VITS_RB16_RING : 4, RD = RS - 2;
         int4v ring[RS][MR];
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
