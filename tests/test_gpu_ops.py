@@ -95,6 +95,26 @@ def test_rel_attention_matches_oracle(pkg, oracle, T):
         assert rel_err(og[i, :, :lens[i]], orf[i, :, :lens[i]]) < TOL
 
 
+def test_rel_attention_does_not_depend_on_the_longest_member_of_the_batch(pkg):
+    """The attention kernel sizes its LDS by the longest utterance of the batch and, for very long ones, takes the V operands of the
+    P.V product straight from memory instead of staging them through LDS: a 300-token utterance must come out bit-identical whether it
+    runs alone or beside a 2049-token one (same MFMA sequence in both paths)."""
+    rng = np.random.default_rng(11)
+    heads, hd, w = 2, 96, 4
+    T, TL = 300, 2049
+    q, k, v = rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T)
+    rk, rv = rnd(rng, 2 * w + 1, hd, scale=0.1), rnd(rng, 2 * w + 1, hd, scale=0.1)
+    alone = pkg.op_rel_attention(q, k, v, rk, rv, heads, w, lens=np.array([T], np.int32))
+
+    def pad(a):
+        out = rnd(rng, 2, heads * hd, TL, scale=0.3)
+        out[0, :, :T] = a[0]
+        return out
+
+    both = pkg.op_rel_attention(pad(q), pad(k), pad(v), rk, rv, heads, w, lens=np.array([T, TL], np.int32))
+    assert np.array_equal(alone[0, :, :T], both[0, :, :T])
+
+
 def test_add_layer_norm_matches_oracle(pkg, oracle):
     rng = np.random.default_rng(3)
     x, r = rnd(rng, 2, 192, 150), rnd(rng, 2, 192, 150)

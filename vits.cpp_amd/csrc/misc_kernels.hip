@@ -318,35 +318,38 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
     }
     __syncthreads();
     // ---- scores: S[16 q][16 keys] per key tile, K = hd ----
-    // (k-steps in groups of 8 with the operands of a group fetched before its first MFMA: a rolled load -> MFMA loop exposes one
-    // memory latency per step, and a block of a 2049-token utterance is alone on its CU)
-    for (int n = wid; n < ntiles; n += 4) {
-        const int key = n * 16 + ln;
-        const int keyc = key < len ? key : len - 1;
-        att_float4v acc = {0.f, 0.f, 0.f, 0.f};
-        const float* kp = kb + (int64_t)lk * k_cs + keyc;
+    // (the K operands of key tile n + 4 are fetched while tile n is multiplied: a block of a 2049-token utterance is alone on its CU —
+    // one wave per SIMD — and a load -> MFMA sequence per tile exposed the memory latency 32 times per wave)
+    {
+        float bcur[MAXS], bnxt[MAXS];
+        auto load_tile = [&](int n, float* dst) __attribute__((always_inline)) {
+            const int key = n * 16 + ln;
+            const float* kp = kb + (int64_t)lk * k_cs + (key < len ? key : len - 1);
 #pragma unroll
-        for (int s0 = 0; s0 < MAXS; s0 += 8) {
-            if (s0 < nsteps) {
-                float bv[8];
+            for (int s2 = 0; s2 < MAXS; ++s2) dst[s2] = s2 < nsteps ? kp[(int64_t)(4 * s2) * k_cs] : 0.f;
+        };
+        if (wid < ntiles) load_tile(wid, bcur);
+        for (int n = wid; n < ntiles; n += 4) {
+            const bool more = n + 4 < ntiles;
+            if (more) load_tile(n + 4, bnxt);
+            att_float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
-                    bv[u] = kp[(int64_t)(4 * s) * k_cs];
+            for (int s2 = 0; s2 < MAXS; ++s2)
+                if (s2 < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s2], bcur[s2], acc, 0, 0, 0);
+            const int key = n * 16 + ln;
+            if (key < len) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = 4 * lk + r;
+                    const int rr = key - (i0 + qi) + window;
+                    float sv = acc[r];
+                    if (rr >= 0 && rr < nrel) sv += qe[qi * nrel + rr];
+                    sc[qi * lp + key] = sv;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s0 + u], bv[u], acc, 0, 0, 0);
             }
-        }
-        if (key < len) {
+            if (more) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = 4 * lk + r;
-                const int rr = key - (i0 + qi) + window;
-                float sv = acc[r];
-                if (rr >= 0 && rr < nrel) sv += qe[qi * nrel + rr];
-                sc[qi * lp + key] = sv;
+                for (int s2 = 0; s2 < MAXS; ++s2) bcur[s2] = bnxt[s2];
             }
         }
     }
@@ -372,6 +375,35 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
     // ---- O[16 q][hd] = P V: d tiles of 16, K = keys, V staged through LDS in chunks of vc keys ----
     const int ndt = hd >> 4;
     att_float4v oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d tiles wid and wid + 4 (head_dim <= 128)
+    if (vshift < 5) {
+        // long sequences (the scores of 2049 tokens leave LDS for 8-16 keys of V per chunk: two barriers per 4 MFMA steps): V operands
+        // straight from memory instead — lane (k = key 4s + lk, n = d) reads v[d][key], 16 rows x 16 bytes per instruction, eight
+        // k-steps in flight. The same MFMA sequence as the staged loop (k-steps of 4 keys, ascending): same bits.
+        const int kst = (len + 3) >> 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int dt = wid + 4 * u;
+            if (dt < ndt) {
+                const float* pa = sc + ln * lp + lk;
+                const float* vrow = vb + (int64_t)(dt * 16 + ln) * v_cs;
+                att_float4v a4 = oacc[u];
+                for (int s0 = 0; s0 < kst; s0 += 8) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8) {
+                        const int sx = s0 + w8 < kst ? s0 + w8 : kst - 1;
+                        const int key = 4 * sx + lk;
+                        av[w8] = pa[4 * sx];
+                        bv[w8] = key < len ? vrow[key] : 0.f;
+                    }
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8)
+                        if (s0 + w8 < kst) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[w8], bv[w8], a4, 0, 0, 0);
+                }
+                oacc[u] = a4;
+            }
+        }
+    } else
     for (int j0 = 0; j0 < len; j0 += vc) {
         const int nj = len - j0 < vc ? len - j0 : vc;
         for (int base = tid; base < (hd << vshift); base += 8 * 256) {  // eight loads in flight per thread
