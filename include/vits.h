@@ -78,13 +78,27 @@ VITS_API int vits_model_get_mode(const vits_model* model);
  *   VITS_ARITH_F16: the literal Q7 arithmetic: conv inputs rounded to fp16 (round-to-nearest-even) where the tile is staged,
  *     fp16 weights, fp32 accumulation on v_mfma_f32_32x32x16_f16.
  *   VITS_ARITH_BF16: the same with bf16 operands (BASELINE.json configs[4]: bf16 weights) on v_mfma_f32_32x32x16_bf16.
- * 16-bit modes apply to every Conv1d / ConvTranspose1d / Linear of the path; everything else (layer norms, attention
- * softmax, splines, gates, residual adds, accumulators) stays fp32. Set between calls, not during one. */
+ * 16-bit modes apply to the Conv1d / ConvTranspose1d of the scope chosen with vits_model_set_arith_scope (never to the Linear
+ * layers q/k/v/out, which are ggml_mul_mat on f32 x f32 in the reference, vits.cpp:287-289,358); everything else (layer norms,
+ * attention softmax, splines, gates, residual adds, accumulators) stays fp32. Set between calls, not during one. */
 #define VITS_ARITH_F32 0
 #define VITS_ARITH_BF16 1
 #define VITS_ARITH_F16 2
 VITS_API int vits_model_set_arith(vits_model* model, int arith);
 VITS_API int vits_model_get_arith(const vits_model* model);
+/* Which convolutions a 16-bit arithmetic mode applies to.
+ *   VITS_ARITH_SCOPE_FLOW_VOCODER (default): the coupling flow and HiFiGAN (99 % of the FLOPs) run on 16-bit operands; stage one
+ *     (text encoder, duration predictor, prior projection: vits.cpp:244-440,927-972) stays EXACT fp32, so the durations — the
+ *     path's only integer output, ceil(exp(logw) * length_scale) at vits.cpp:996-1001 — the frame counts and the sample counts
+ *     are bit-identical to the fp32 path's (and to the oracle's) in every arithmetic mode.
+ *   VITS_ARITH_SCOPE_ALL_CONVS: the literal Q7 arithmetic — every Conv1d / ConvTranspose1d of the path, stage one included
+ *     (custom-ops.h:684-690 rounds the im2col of EVERY conv). Durations then carry the mode's rounding noise: a log-duration
+ *     within an fp16 ulp of a ceil() boundary may land on either side.
+ * Set between calls, not during one. */
+#define VITS_ARITH_SCOPE_FLOW_VOCODER 0
+#define VITS_ARITH_SCOPE_ALL_CONVS 1
+VITS_API int vits_model_set_arith_scope(vits_model* model, int scope);
+VITS_API int vits_model_get_arith_scope(const vits_model* model);
 
 /* Noise source for the two N(0,1) draws (vits.cpp:948 [T,2] and :1059 [L,192]). */
 #define VITS_NOISE_REFERENCE 0 /* libstdc++ minstd_rand0 + normal_distribution<float>, global, host-serial */

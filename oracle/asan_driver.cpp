@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
                 o.noise_seed = 5 + n;
                 o.threads = 3;
                 o.arith = arith;
+                o.arith_scope = (n == 3) ? VO_SCOPE_ALL_CONVS : VO_SCOPE_FLOW_VOCODER;
                 vo_run* r = vo_process_ids(m, ids, n, &o);
                 if (!r) {
                     std::fprintf(stderr, "process failed: %s\n", vo_last_error());

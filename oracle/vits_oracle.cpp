@@ -1060,7 +1060,9 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
     try {
         const vo_model& m = *mp;
         if (T <= 0) throw std::runtime_error("empty input");
-        g_arith = opts ? opts->arith : 0;
+        const int arith_all = opts ? opts->arith : 0;
+        // scope FLOW_VOCODER: the text encoder and the duration predictor run in exact fp32, the 16-bit operand rounding starts at the flow
+        g_arith = (opts && opts->arith_scope == VO_SCOPE_ALL_CONVS) ? arith_all : 0;
         struct ArithReset {
             ~ArithReset() { g_arith = 0; }
         } arith_reset;
@@ -1125,6 +1127,7 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
                 n = n * m.noise_scale;                                // ref :1061
                 z_p.d[(size_t)ch * L + j] = mu + n;                   // ref :1063
             }
+        g_arith = arith_all;
         Act z;
         {
             StageTimer t("flow");

@@ -38,6 +38,10 @@ typedef struct vo_run vo_run;
 #define VO_ARITH_F32 0
 #define VO_ARITH_BF16 1
 #define VO_ARITH_F16 2
+/* scope of a 16-bit arithmetic: FLOW_VOCODER = the coupling flow and HiFiGAN only (text encoder and duration predictor stay
+ * exact fp32, so the integer durations do not depend on the arithmetic); ALL_CONVS = the literal Q7 (every conv of the graph) */
+#define VO_SCOPE_FLOW_VOCODER 0
+#define VO_SCOPE_ALL_CONVS 1
 #define VO_NOISE_REFERENCE 0
 #define VO_NOISE_COUNTER 1
 #define VO_NOISE_EXPLICIT 2
@@ -52,6 +56,7 @@ typedef struct vo_opts {
     int32_t fixed_duration;     /* >0: pin every id to this many frames */
     int32_t threads;            /* <=0: max(hardware_concurrency, 6) like src/include/common.h:19-21 */
     int32_t arith;              /* VO_ARITH_*: operand rounding of every Conv1d / ConvTranspose1d (not of the Linear layers) */
+    int32_t arith_scope;        /* VO_SCOPE_*: which convs `arith` applies to */
 } vo_opts;
 
 VO_API const char* vo_last_error(void);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "libvits_oracle.so")
 
 MODE_REFERENCE, MODE_HF = 0, 1
 ARITH_F32, ARITH_BF16, ARITH_F16 = 0, 1, 2
+SCOPE_FLOW_VOCODER, SCOPE_ALL_CONVS = 0, 1
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
 
 TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "noise_dur", "noise_prior", "z_p", "z_flow",
@@ -24,7 +25,7 @@ TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "n
 class Opts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("noise_kind", C.c_int32), ("noise_seed", C.c_uint64), ("noise_dur", C.c_void_p),
                 ("noise_prior", C.c_void_p), ("noise_prior_stride", C.c_int64), ("fixed_duration", C.c_int32),
-                ("threads", C.c_int32), ("arith", C.c_int32)]
+                ("threads", C.c_int32), ("arith", C.c_int32), ("arith_scope", C.c_int32)]
 
 
 class Conv1dDesc(C.Structure):
@@ -137,13 +138,13 @@ class Model:
         return buf[:n].copy()
 
     def process_ids(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, noise_dur=None,
-                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS, arith=0):
+                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS, arith=0, arith_scope=SCOPE_FLOW_VOCODER):
         """Runs the full restated graph for ONE utterance. Returns {tap: np.ndarray} (flat [C*len] arrays reshaped
         to [C, len] where C is known)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         nd, npr = _f32(noise_dur), _f32(noise_prior)
         o = Opts(mode, noise_kind, noise_seed, _ptr(nd), _ptr(npr), 0 if npr is None else npr.shape[-1], fixed_duration,
-                 threads, arith)
+                 threads, arith, arith_scope)
         r = lib().vo_process_ids(self._h, _ptr(ids), ids.size, C.byref(o))
         if not r:
             raise OracleError(lib().vo_last_error().decode())

@@ -95,6 +95,22 @@ def test_rel_attention_matches_oracle(pkg, oracle, T):
         assert rel_err(og[i, :, :lens[i]], orf[i, :, :lens[i]]) < TOL
 
 
+@pytest.mark.parametrize("w", [0, 1, 7, 8, 10, 33])
+def test_rel_attention_other_window_sizes_match_oracle(pkg, oracle, w):
+    """window_size is a hyper-parameter of the model file (vits.cpp:246-254): 2w+1 relative positions, more than one 16-column tile of
+    the q.Ek product from w = 8 on (the matrix-core kernel used to fill only the first 16 columns of its table)."""
+    rng = np.random.default_rng(100 + w)
+    heads, hd = 2, 48
+    for T in (5, 70, 300):
+        q, k, v = rnd(rng, 2, heads * hd, T, scale=0.3), rnd(rng, 2, heads * hd, T, scale=0.3), rnd(rng, 2, heads * hd, T)
+        rk, rv = rnd(rng, 2 * w + 1, hd, scale=0.3), rnd(rng, 2 * w + 1, hd, scale=0.3)
+        lens = np.array([T, max(1, T - 3)], np.int32)
+        og = pkg.op_rel_attention(q, k, v, rk, rv, heads, w, lens=lens)
+        orf = oracle.rel_attention(q, k, v, rk, rv, heads, w, lens=lens)
+        for i in range(2):
+            assert rel_err(og[i, :, :lens[i]], orf[i, :, :lens[i]]) < TOL, (w, T, i)
+
+
 def test_rel_attention_does_not_depend_on_the_longest_member_of_the_batch(pkg):
     """The attention kernel sizes its LDS by the longest utterance of the batch and, for very long ones, takes the V operands of the
     P.V product straight from memory instead of staging them through LDS: a 300-token utterance must come out bit-identical whether it

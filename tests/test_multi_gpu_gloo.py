@@ -158,3 +158,105 @@ def test_ragged_pcm_all_gather_world2(dtype):
         for u in range(total):
             assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap, dtype)[: want_len[u]])
             assert float(out[u, want_len[u]:].float().abs().sum()) == 0.0
+
+
+# ---- world 8 (the node size of BASELINE.json configs[3]) and the pipelined exchange ----------------------------------------------
+def _spawn(target, world, args, timeout=150):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda r: r[0])
+
+
+def _len_of(u, step=0):
+    return 100 + 37 * ((u * 5 + step * 3) % 11)
+
+
+def _worker_world8(rank, world, port, q, total, cap, balanced):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mg = _load_multi_gpu()
+    weights = [_len_of(u) for u in range(total)]
+    shards = mg.balanced_shards(weights, world) if balanced else [list(range(*mg.shard_range(total, world, r))) for r in range(world)]
+    mine = shards[rank]
+    lengths = torch.tensor([_len_of(u) for u in mine], dtype=torch.int64)
+    pcm = torch.stack([_fake_pcm(u, int(lengths[i]), cap) for i, u in enumerate(mine)]) if mine else torch.zeros((0, cap))
+    out, all_len = mg.gather_pcm(pcm, lengths)
+    out, all_len = mg.restore_order(out, all_len, shards)
+    fr = mg.gather_frames(lengths // 10)
+    q.put((rank, out.numpy().copy(), all_len.numpy().copy(), fr.numpy().copy(), mg.gather_index_map(shards)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("total,balanced", [(19, False), (19, True), (5, False)], ids=["uneven", "balanced", "empty_shards"])
+def test_world8_gather_uneven_balanced_and_empty_shards(total, balanced):
+    """Eight ranks: 19 utterances (blocks of 3 and 2), the same with frame-balanced (non-contiguous) shards put back into global
+    order with the returned index map, and 5 utterances (three ranks with an EMPTY shard: ADVICE r2 — they must send an
+    all-padding block instead of crashing in lengths.max() while the others hang in the collective)."""
+    world, cap = 8, 600
+    results = _spawn(_worker_world8, world, (total, cap, balanced))
+    want_len = torch.tensor([_len_of(u) for u in range(total)], dtype=torch.int64)
+    for rank, out, all_len, fr, imap in results:
+        out, all_len = torch.from_numpy(out), torch.from_numpy(all_len)
+        assert sorted(imap) == list(range(total))
+        assert torch.equal(all_len, want_len) and out.shape == (total, int(want_len.max()))
+        assert sorted(fr.tolist()) == sorted((want_len // 10).tolist())
+        for u in range(total):
+            assert torch.equal(out[u, : want_len[u]], _fake_pcm(u, int(want_len[u]), cap)[: want_len[u]])
+
+
+def _worker_exchange(rank, world, port, q, total, cap, steps, dtype):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mg = _load_multi_gpu()
+    lo, hi = mg.shard_range(total, world, rank)
+    blocks = []
+    tdt = torch.int16 if dtype == "int16" else torch.float32
+    ex = mg.PcmExchange(hi - lo, cap, dtype=tdt, device="cpu", on_block=lambda step, out, lens: blocks.append((step, out.numpy().copy(), lens.numpy().copy())))
+    allocs = (ex.out.data_ptr(), ex.send.data_ptr())
+    bufs = [torch.zeros((hi - lo, cap), dtype=tdt) for _ in range(3)]
+    for i in range(steps):
+        buf = bufs[i % 3]
+        lengths = torch.tensor([_len_of(u, i) for u in range(lo, hi)], dtype=torch.int64)
+        for r, u in enumerate(range(lo, hi)):
+            buf[r] = _fake_pcm(u + 1000 * i, int(lengths[r]), cap, dtype)
+        ex.submit(buf, lengths)
+        assert len(blocks) == i  # step i's block is produced one submit later: it never delays the step that made it
+    ex.flush()
+    assert (ex.out.data_ptr(), ex.send.data_ptr()) == allocs  # nothing was reallocated
+    q.put((rank, blocks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("world,total,dtype", [(8, 19, "float32"), (8, 64, "int16"), (2, 3, "float32"), (8, 5, "float32")])
+def test_pipelined_exchange_delivers_every_step_in_order(world, total, dtype):
+    """PcmExchange: no meta exchange, no .tolist() round trip and no allocation per step — the lengths of step i travel with step
+    i, the PCM of step i is gathered (exact common width) while step i + 1 is produced, flush() drains. Every step's block must
+    arrive once, in order, with every row equal to what its owner wrote — uneven shards, empty shards, fp32 and int16 rows."""
+    cap, steps = 600, 5
+    results = _spawn(_worker_exchange, world, (total, cap, steps, dtype))
+    for rank, blocks in results:
+        assert [b[0] for b in blocks] == list(range(steps))
+        for step, out, lens in blocks:
+            want_len = [_len_of(u, step) for u in range(total)]
+            assert lens.tolist() == want_len and out.shape == (total, max(want_len))
+            for u in range(total):
+                row = _fake_pcm(u + 1000 * step, want_len[u], cap, dtype).numpy()
+                assert (out[u, : want_len[u]] == row[: want_len[u]]).all() and not out[u, want_len[u]:].any()

@@ -240,6 +240,25 @@ def test_bf16_storage_extension_round_trips(pkg, oracle):
     np.testing.assert_array_equal(ea, eb)  # fp32 tensors untouched
 
 
+def test_arith_scope_keeps_stage_one_exact(pkg, oracle, tiny_bytes):
+    """vo_opts.arith_scope: under FLOW_VOCODER a 16-bit arithmetic leaves the text encoder and the duration predictor in exact fp32
+    (every stage-one tap and the integer durations equal the fp32 run bit for bit; the flow output and the waveform move), under
+    ALL_CONVS the log-durations move too (custom-ops.h:684-690 rounds the im2col of every conv, the duration predictor's included)."""
+    om = oracle.Model(tiny_bytes)
+    ids = np.zeros(21, np.int32)
+    ids[1::2] = np.arange(1, 11)
+    base = om.process_ids(ids, noise_seed=3)
+    for arith in (oracle.ARITH_F16, oracle.ARITH_BF16):
+        fv = om.process_ids(ids, noise_seed=3, arith=arith, arith_scope=oracle.SCOPE_FLOW_VOCODER)
+        for tap in ("enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "z_p"):
+            assert np.array_equal(fv[tap], base[tap]), tap
+        assert fv["waveform"].size == base["waveform"].size and not np.array_equal(fv["z_flow"], base["z_flow"])
+        assert not np.array_equal(fv["waveform"], base["waveform"])
+        ac = om.process_ids(ids, noise_seed=3, arith=arith, arith_scope=oracle.SCOPE_ALL_CONVS, fixed_duration=2)
+        b2 = om.process_ids(ids, noise_seed=3, fixed_duration=2)
+        assert not np.array_equal(ac["log_duration"], b2["log_duration"]) and not np.array_equal(ac["enc_out"], b2["enc_out"])
+
+
 def test_oracle_is_clean_under_asan_and_ubsan():
     """The reference's Debug configuration is an AddressSanitizer build (/root/reference/CMakeLists.txt:9-13). The GPU pool has no
     device-side sanitizer, so the CPU restatement gets it: `make -C oracle asan` builds the oracle + a driver with

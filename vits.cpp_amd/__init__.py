@@ -22,6 +22,7 @@ MODE_DEFAULT, MODE_REFERENCE, MODE_HF = -1, 0, 1
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
 SYNTH_FULL, SYNTH_TINY, SYNTH_BF16 = 0, 1, 0x100
 ARITH_F32, ARITH_BF16, ARITH_F16 = 0, 1, 2
+SCOPE_FLOW_VOCODER, SCOPE_ALL_CONVS = 0, 1
 
 #: every symbol include/vits.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
@@ -34,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
     "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
     "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
+    "vits_model_set_arith_scope", "vits_model_get_arith_scope",
 ]
 
 
@@ -122,6 +124,10 @@ def lib():
     L.vits_model_set_arith.argtypes = [vp, i32]
     L.vits_model_get_arith.restype = i32
     L.vits_model_get_arith.argtypes = [vp]
+    L.vits_model_set_arith_scope.restype = i32
+    L.vits_model_set_arith_scope.argtypes = [vp, i32]
+    L.vits_model_get_arith_scope.restype = i32
+    L.vits_model_get_arith_scope.argtypes = [vp]
     L.vits_reference_noise_seed.restype = None
     L.vits_reference_noise_seed.argtypes = [C.c_uint32]
     L.vits_model_process_ids.restype = VitsResult
@@ -310,6 +316,16 @@ class Model:
     @property
     def arith(self):
         return lib().vits_model_get_arith(self._h)
+
+    def set_arith_scope(self, scope):
+        """SCOPE_FLOW_VOCODER (default: stage one stays exact fp32, durations bit-identical to the fp32 path) | SCOPE_ALL_CONVS
+        (the literal Q7 arithmetic: every conv of the path) — include/vits.h VITS_ARITH_SCOPE_*"""
+        if lib().vits_model_set_arith_scope(self._h, scope) != 0:
+            raise VitsError(last_error())
+
+    @property
+    def arith_scope(self):
+        return lib().vits_model_get_arith_scope(self._h)
 
     @property
     def mode(self):

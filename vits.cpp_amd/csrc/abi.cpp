@@ -152,6 +152,15 @@ VITS_API int vits_model_set_arith(vits_model* model, int arith) {
     VITS_CATCH(-1)
 }
 VITS_API int vits_model_get_arith(const vits_model* model) { return model ? model->eng.arith : -1; }
+VITS_API int vits_model_set_arith_scope(vits_model* model, int scope) {
+    if (!model || (scope != VITS_ARITH_SCOPE_FLOW_VOCODER && scope != VITS_ARITH_SCOPE_ALL_CONVS)) {
+        set_err("bad arithmetic scope");
+        return -1;
+    }
+    model->eng.arith_scope = scope;
+    return 0;
+}
+VITS_API int vits_model_get_arith_scope(const vits_model* model) { return model ? model->eng.arith_scope : -1; }
 
 VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
                                       const vits_process_opts* opts, vits_batch_result* out) {

@@ -106,6 +106,23 @@ struct UpStageW {
     int channels, stride, k;
 };
 
+// Every VITS_* environment knob of the orchestrator, read ONCE when the model is loaded (never on the call path: getenv is
+// not thread-safe against setenv, and a per-layer lookup is host time inside the caller's timed region). INTEGRATION.md §9.
+struct Knobs {
+    int rb_streams = 3;          // VITS_RB_STREAMS (1 serialises the three resblocks of a stage on the main stream)
+    int lrelu_copy_minc = 128;   // VITS_LRELU_COPY_MINC: stages at least this wide also store leaky_relu(y)
+    bool no_dds_fuse = false;    // VITS_NO_DDS_FUSE: DDS layer as three launches
+    bool no_wn_fuse = false;     // VITS_NO_WN_FUSE: WaveNet layer as two launches
+    bool no_group16 = false;     // VITS_NO_GROUP16: 16-bit vocoder through the fp32-layout (converter) path
+    bool no_fuse16 = false;      // VITS_NO_FUSE16: 16-bit resblock conv pairs as two launches
+    bool no_fuse32 = false;      // VITS_NO_FUSE32: fp32 resblock conv pairs as two launches
+    bool no_rb_group = false;    // VITS_NO_RB_GROUP: the resblocks of a stage as separate launches (no grouped launch)
+    void read();
+};
+
+struct Call;    // engine_internal.h: the state of one process_batch call
+struct WinCtx;  // engine_internal.h: one vocoder window
+
 class Engine {
   public:
     ~Engine();
@@ -117,6 +134,9 @@ class Engine {
     int sync(std::string& err);
     int set_arith(int arith, std::string& err);  // VITS_ARITH_*: packs the 16-bit weight fragments on first use
     int arith = VITS_ARITH_F32;
+    // which convolutions a 16-bit arithmetic mode applies to (include/vits.h VITS_ARITH_SCOPE_*)
+    int arith_scope = VITS_ARITH_SCOPE_FLOW_VOCODER;
+    Knobs knobs;
     int64_t get_tap(const char* name, int utt, float* dst, size_t cap);
 
     HParams hp;
@@ -140,12 +160,20 @@ class Engine {
     std::vector<UpStageW> ups_;
     float* dec_post_w_ = nullptr;
     int dec_post_cin_ = 0, dec_post_k_ = 0;
-    // host copies of every Conv1d / ConvTranspose1d weight (torch layout, after the flip / negation folds), kept so that
-    // set_arith can pack the 16-bit A fragments on demand. Linear layers (q/k/v/out) are not listed: they stay fp32 (Q7).
+    // host copies of every Conv1d / ConvTranspose1d weight (torch layout, after the flip / negation folds, in the file's storage
+    // type), kept so that set_arith can pack the 16-bit A fragments on demand. Linear layers (q/k/v/out) are not listed: they stay fp32 (Q7).
     struct PackSrc {
-        PackedConv* pc;
-        std::vector<float> w;
+        PackedConv* pc;  // (points into enc_/flow_/ups_...: those vectors are sized before their entries are packed and never resized)
+        std::vector<float> w32;     // fp32-stored tensors
+        std::vector<uint16_t> w16;  // fp16 / bf16-stored tensors, as stored
+        uint32_t dtype;
         int cout, cin, k, epi, ct_stride;
+        std::vector<float> widen() const {
+            if (dtype != DT_F16 && dtype != DT_BF16) return w32;
+            std::vector<float> w(w16.size());
+            for (size_t e = 0; e < w.size(); ++e) w[e] = dtype == DT_F16 ? f16_to_f32(w16[e]) : bf16_to_f32(w16[e]);
+            return w;
+        }
     };
     std::vector<PackSrc> packs_;
     Ref16 x16_[3];           // per-stream scratch for the 16-bit copy of a conv input (transparent 16-bit path)
@@ -161,11 +189,12 @@ class Engine {
     // three streams so that the tail of one kernel's grid overlaps the head of another's. side_[j-1] carries resblock j.
     hipStream_t side_[2] = {nullptr, nullptr};
     hipEvent_t ev_fork_ = nullptr, ev_done_[3] = {nullptr, nullptr, nullptr};
-    int rb_streams_ = 3;
-    int lrelu_copy_minc_ = 128;  // stages at least this wide also store leaky_relu(y) (see the resblock loop)
     int halo_frames_ = 0;      // receptive field of the vocoder in frames, one side (computed at load)
     void* pinned_ = nullptr;   // grow-only pinned staging for streamed PCM
-    size_t pinned_cap_ = 0;  // VITS_RB_STREAMS=1 serialises everything on the main stream
+    size_t pinned_cap_ = 0;
+    // arithmetic of the convolutions being queued right now: `arith`, or fp32 while stage one runs under
+    // VITS_ARITH_SCOPE_FLOW_VOCODER (every conv wrapper and fused kernel reads this one, never `arith` itself)
+    int arith_now_ = VITS_ARITH_F32;
     struct HStage {  // pinned staging of the per-call host header (ids, lengths, stage tables)
         int* p = nullptr;
         size_t cap = 0;
@@ -188,6 +217,15 @@ class Engine {
     hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax, int64_t sum_t);
     void snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens);
     void clear_taps();
+    // the phases of one call (engine_stage1.cpp, engine_flow.cpp, engine_vocoder.cpp); each returns 0 or -1 with c.err set
+    int layout_stage_one(Call& c);
+    int run_text_encoder(Call& c);
+    int run_duration_predictor(Call& c);
+    int layout_stage_two(Call& c);
+    int run_prior_sampling(Call& c);
+    int run_flow(Call& c);
+    int run_vocoder_window32(Call& c, WinCtx& w);
+    int run_vocoder_window16(Call& c, WinCtx& w);
 };
 
 }  // namespace vits

@@ -1,0 +1,179 @@
+// engine_support.cpp — the engine's plumbing: roctx ranges, the reference noise stream, tokenizer, HIP-event profiler, arenas, knobs.
+#include <dlfcn.h>
+
+#include <mutex>
+#include <random>
+#include <sstream>
+
+#include "engine_internal.h"
+
+namespace vits {
+
+RoctxApi::RoctxApi() {
+    if (!std::getenv("VITS_ROCTX")) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+}
+const RoctxApi& roctx_api() {
+    static const RoctxApi api;
+    return api;
+}
+
+void Knobs::read() {
+    auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
+    if (const char* e = std::getenv("VITS_RB_STREAMS")) rb_streams = std::atoi(e) >= 2 ? 3 : 1;
+    if (const char* e = std::getenv("VITS_LRELU_COPY_MINC")) lrelu_copy_minc = std::atoi(e);
+    no_dds_fuse = flag("VITS_NO_DDS_FUSE");
+    no_wn_fuse = flag("VITS_NO_WN_FUSE");
+    no_group16 = flag("VITS_NO_GROUP16");
+    no_fuse16 = flag("VITS_NO_FUSE16");
+    no_fuse32 = flag("VITS_NO_FUSE32");
+    no_rb_group = flag("VITS_NO_RB_GROUP");
+}
+
+// ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----
+static std::default_random_engine g_ref_rng;
+static std::mutex g_ref_mu;
+void reference_noise_seed(uint32_t seed) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    g_ref_rng.seed(seed);
+}
+void reference_noise_fill(float* dst, size_t n) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    std::normal_distribution<float> dist(0.0f, 1.0f);
+    for (size_t i = 0; i < n; ++i) dst[i] = dist(g_ref_rng);
+}
+
+// ---- tokenizer (src/vits_tokenizer.cpp:57-78,182-208; deterministic longest match instead of unordered_map order, Q11) ----
+void Tokenizer::init(const ModelFile& f) {
+    vocab.clear();
+    for (auto& kv : f.vocab) vocab.emplace_back(kv.first, (int32_t)kv.second);
+    std::stable_sort(vocab.begin(), vocab.end(), [](auto& a, auto& b) { return a.first.size() > b.first.size(); });
+    add_blank = f.add_blank != 0;
+    blank_id = 0;
+    for (auto& kv : f.vocab)
+        if (kv.first == f.pad_token) blank_id = (int32_t)kv.second;  // vocab[pad_token], vits_tokenizer.cpp:201
+}
+
+std::vector<int32_t> Tokenizer::tokenize(const std::string& text) const {
+    std::string s = text;
+    for (auto& c : s) c = (char)std::tolower((unsigned char)c);  // :195-197
+    std::vector<int32_t> toks;
+    size_t i = 0;
+    while (i < s.size()) {
+        bool found = false;
+        for (auto& kv : vocab) {
+            if (!kv.first.empty() && s.compare(i, kv.first.size(), kv.first) == 0) {
+                toks.push_back(kv.second);
+                i += kv.first.size();
+                found = true;
+                break;
+            }
+        }
+        if (!found) i++;  // unknown bytes are skipped (:72-75)
+    }
+    std::vector<int32_t> fin;
+    if (add_blank) {  // :200-206 ; without add_blank the reference returns an empty vector
+        fin.assign(toks.size() * 2 + 1, blank_id);
+        for (size_t k = 0; k < toks.size(); ++k) fin[k * 2 + 1] = toks[k];
+    }
+    return fin;
+}
+
+// ---- profiler -----------------------------------------------------------------------------------------
+hipEvent_t Profiler::get() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s, bool chain) {
+    if (!on) return;
+    auto it = ids.find(name);
+    int id;
+    if (it == ids.end()) {
+        id = (int)names.size();
+        names.push_back(name);
+        ids[name] = id;
+        agg.emplace_back();
+    } else
+        id = it->second;
+    const bool share = chain && last_ok && last_s == s;
+    Rec r{id, share ? last_b : get(), get(), flop, bytes, share};
+    if (!share) hipEventRecord(r.a, s);
+    recs.push_back(r);
+    last_ok = false;
+}
+void Profiler::end(hipStream_t s) {
+    if (!on || recs.empty()) return;
+    hipEventRecord(recs.back().b, s);
+    last_b = recs.back().b;
+    last_s = s;
+    last_ok = true;
+}
+void Profiler::collect() {
+    for (auto& r : recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.name_id];
+            a.calls++;
+            a.ms += ms;
+            a.flop += r.flop;
+            a.bytes += r.bytes;
+        }
+        if (!r.a_shared) pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    recs.clear();
+    last_ok = false;
+}
+void Profiler::reset() {
+    collect();
+    for (auto& a : agg) a = Agg();
+}
+std::string Profiler::report() {
+    collect();
+    std::ostringstream o;
+    o.precision(9);
+    o << "{\"kernels\":[";
+    bool first = true;
+    for (size_t i = 0; i < names.size(); ++i) {
+        if (!agg[i].calls) continue;
+        o << (first ? "" : ",") << "{\"name\":\"" << names[i] << "\",\"calls\":" << agg[i].calls << ",\"ms\":" << agg[i].ms << ",\"flop\":" << agg[i].flop
+          << ",\"bytes\":" << agg[i].bytes << "}";
+        first = false;
+    }
+    o << "]}";
+    return o.str();
+}
+Profiler::~Profiler() {
+    collect();
+    for (auto e : pool) hipEventDestroy(e);
+}
+
+// ---- arena ----------------------------------------------------------------------------------------------
+hipError_t Arena::reserve(size_t bytes) {
+    off = 0;
+    if (bytes <= cap) return hipSuccess;
+    if (base) hipFree(base);
+    base = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    hipError_t e = hipMalloc((void**)&base, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+}
+Arena::~Arena() {
+    if (base) hipFree(base);
+}
+
+
+}  // namespace vits

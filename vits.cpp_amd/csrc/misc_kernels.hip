@@ -298,22 +298,24 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
     float qa[MAXS];
 #pragma unroll
     for (int s2 = 0; s2 < MAXS; ++s2) qa[s2] = s2 < nsteps ? qt[(4 * s2 + lk) * ATT_Q + ln] : 0.f;
-    // q_i . Ek[r] for the 2w+1 relative positions: one more 16 x 16 product (columns r < nrel of the table), wave 0
-    if (wid == 0) {
+    // q_i . Ek[r] for the 2w+1 relative positions: one more 16 x 16 product per tile of 16 relative positions (one tile — wave 0 — for
+    // windows up to 7, the MMS-TTS architecture has 4; wider windows take further tiles on the other waves)
+    for (int ct = wid; ct * 16 < nrel; ct += 4) {
+        const int rcol = ct * 16 + ln;
         att_float4v acc = {0.f, 0.f, 0.f, 0.f};
-        const float* rp = rel_k + (int64_t)(ln < nrel ? ln : 0) * hd + lk;
+        const float* rp = rel_k + (int64_t)(rcol < nrel ? rcol : 0) * hd + lk;
 #pragma unroll
         for (int s0 = 0; s0 < MAXS; s0 += 8) {
             float bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bv[u] = (s0 + u < nsteps && ln < nrel) ? rp[4 * (s0 + u)] : 0.f;
+            for (int u = 0; u < 8; ++u) bv[u] = (s0 + u < nsteps && rcol < nrel) ? rp[4 * (s0 + u)] : 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s0 + u], bv[u], acc, 0, 0, 0);
         }
-        if (ln < nrel) {
+        if (rcol < nrel) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) qe[(4 * lk + r) * nrel + ln] = acc[r];
+            for (int r = 0; r < 4; ++r) qe[(4 * lk + r) * nrel + rcol] = acc[r];
         }
     }
     __syncthreads();

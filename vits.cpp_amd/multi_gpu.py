@@ -84,13 +84,15 @@ def gather_pcm(pcm, lengths):
     Returns (gathered [sum of B over ranks, smax], all_lengths) on every rank, rank blocks in rank order; world == 1 is a
     no-op view. B may differ between ranks (shard_range hands out blocks that differ by one): the row counts travel first
     and short blocks are padded to the largest for the fixed-size collective, then the padding rows are dropped."""
+    B = pcm.shape[0]
     if not dist.is_available() or not dist.is_initialized():
-        smax = int(lengths.max().item())
+        smax = int(lengths.max().item()) if B else 0
         return pcm[:, :smax], lengths
     world = dist.get_world_size()
-    B = pcm.shape[0]
-    # one small control message: [B, longest length] of this rank -> every rank
-    meta = torch.stack([torch.tensor(B, dtype=torch.int64, device=lengths.device), lengths.max().to(torch.int64)])
+    # one small control message: [B, longest length] of this rank -> every rank (a rank whose shard is empty — fewer utterances
+    # than ranks — sends [0, 0] and an all-padding block)
+    own_max = lengths.max().to(torch.int64) if B else torch.zeros((), dtype=torch.int64, device=lengths.device)
+    meta = torch.stack([torch.tensor(B, dtype=torch.int64, device=lengths.device), own_max])
     metas = torch.empty(2 * world, dtype=torch.int64, device=lengths.device)
     dist.all_gather_into_tensor(metas, meta)
     metas = metas.view(world, 2).tolist()
@@ -116,3 +118,145 @@ def gather_pcm(pcm, lengths):
         return out, all_len
     keep = torch.cat([torch.arange(r * bmax, r * bmax + counts[r], device=out.device) for r in range(world)])
     return out.index_select(0, keep), all_len.index_select(0, keep.to(all_len.device))
+
+
+def gather_index_map(shards):
+    """Row r of a gathered block holds global utterance gather_index_map(shards)[r]: rank blocks arrive in rank order, so with
+    `balanced_shards` (or any non-contiguous assignment) the gathered rows are NOT in global utterance order."""
+    return [i for s in shards for i in s]
+
+
+def restore_order(gathered, lengths, shards):
+    """Reorders the rows of a gather over `shards` (list of per-rank index lists) into global utterance order."""
+    idx = torch.as_tensor(gather_index_map(shards), dtype=torch.int64, device=gathered.device)
+    inv = torch.empty_like(idx)
+    inv[idx] = torch.arange(idx.numel(), device=idx.device)
+    return gathered.index_select(0, inv), lengths.index_select(0, inv.to(lengths.device))
+
+
+class PcmExchange:
+    """The path's one exchange as a PIPELINE with no host round trip and no allocation in the steady state.
+
+    `gather_pcm` above is the simple synchronous form: a meta all-gather + `.tolist()` (two host syncs) and three allocations per
+    call, all inside the step. Here everything that does not change is agreed ONCE (row counts per rank, row capacity), every
+    buffer is allocated once, and step i's traffic overlaps step i + 1's compute:
+
+      submit(pcm_i, lengths_i)   (1) queues the fixed-size all-gather of the int64 lengths of step i and their copy to pinned
+                                     host memory on the exchange stream — nothing waits for it;
+                                 (2) reads the lengths of step i-1 (that copy finished a whole step ago), which gives the exact
+                                     common width smax_{i-1}, and queues the all-gather of PCM_{i-1}[:, :smax] on the exchange stream;
+      flush()                    drains the pipeline (end of a run, or when the caller needs the last block).
+
+    The PCM of step i is therefore read by the collective while step i + 1 runs: the caller must not overwrite it before step
+    i + 2 begins (rotate THREE output buffers: `slot(i) = i % 3`; submit(i + 2) first waits for gather i-... see `submit`).
+    Results arrive through `on_block(step, gathered [rows, smax], lengths [rows])` (views into the exchange's own buffers, valid
+    until the next block is produced) or `last`. Works on CPU tensors with gloo (synchronous there) and on the GPU with
+    nccl == RCCL; int16 PCM travels as bytes."""
+
+    def __init__(self, rows, cap, dtype=torch.float32, device="cpu", on_block=None):
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.dist_on else 1
+        self.rank = dist.get_rank() if self.dist_on else 0
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.cap, self.dtype, self.on_block = int(cap), dtype, on_block
+        # agreed once: rows per rank (shards may differ by one, or be empty)
+        if self.dist_on:
+            mine = torch.tensor([rows], dtype=torch.int64, device=self.device)
+            allc = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allc, mine)
+            self.counts = [int(x) for x in allc.tolist()]
+        else:
+            self.counts = [int(rows)]
+        self.rows = int(rows)
+        self.bmax = max(max(self.counts), 1)
+        n = self.world * self.bmax
+        self.keep = None
+        if any(c != self.bmax for c in self.counts):
+            self.keep = torch.cat([torch.arange(r * self.bmax, r * self.bmax + self.counts[r], device=self.device) for r in range(self.world)])
+        pin = dict(pin_memory=True) if self.cuda else {}
+        self.len_send = [torch.zeros(self.bmax, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.len_all = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.len_host = [torch.zeros(n, dtype=torch.int64, **pin) for _ in range(2)]
+        self.send = torch.zeros(self.bmax * self.cap, dtype=dtype, device=self.device)  # (rows beyond `rows` are the padding block: never read back, see `keep`)
+        self.out = torch.zeros(n * self.cap, dtype=dtype, device=self.device)
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.len_ev = [torch.cuda.Event() if self.cuda else None for _ in range(2)]
+        self.out_ev = torch.cuda.Event() if self.cuda else None
+        self.pending = None  # (step, pcm, slot): lengths queued, PCM not yet
+        self.step = 0
+        self.last = None
+        self.bytes_moved = 0
+
+    def _on_side(self):
+        return torch.cuda.stream(self.side) if self.cuda else _NullCtx()
+
+    def submit(self, pcm, lengths):
+        """pcm [rows, >= cap used] on self.device (fp32 or int16), rows valid up to lengths[b]; lengths int64 [rows] on the same
+        device. The data must be complete (the producing stream synchronised, which vits_model_process_batch does before it
+        returns). Returns immediately; pcm must stay untouched until the SECOND next submit / the next flush."""
+        assert pcm.shape[0] == self.rows and pcm.dtype == self.dtype and pcm.shape[1] <= self.cap
+        slot = self.step & 1
+        with self._on_side():
+            if self.cuda:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+            self.len_send[slot][: self.rows].copy_(lengths)
+            if self.dist_on:
+                dist.all_gather_into_tensor(self.len_all[slot], self.len_send[slot])
+            else:
+                self.len_all[slot].copy_(self.len_send[slot])
+            self.len_host[slot].copy_(self.len_all[slot], non_blocking=True)
+            if self.cuda:
+                self.len_ev[slot].record(self.side)
+        prev, self.pending = self.pending, (self.step, pcm, slot)
+        self.step += 1
+        if prev is not None:
+            self._gather(*prev)
+
+    def _gather(self, step, pcm, slot):
+        if self.cuda:
+            self.len_ev[slot].synchronize()  # (recorded a whole step ago: no wait in the steady state)
+        lens_host = self.len_host[slot]
+        smax = int(lens_host.max())
+        if smax > pcm.shape[1]:
+            raise ValueError("PCM buffer narrower than the longest utterance of another rank: all ranks must use the same capacity")
+        n = self.world * self.bmax
+        with self._on_side():
+            send = self.send[: self.bmax * smax].view(self.bmax, smax)
+            send[: self.rows].copy_(pcm[:, :smax])
+            out = self.out[: n * smax].view(n, smax)
+            if self.dist_on:
+                if self.dtype == torch.float32:
+                    dist.all_gather_into_tensor(out, send)
+                else:  # an all-gather only copies: int16 (not an element type of RCCL / gloo) travels as bytes
+                    dist.all_gather_into_tensor(out.view(torch.uint8), send.view(torch.uint8))
+            else:
+                out.copy_(send)
+            if self.cuda:
+                self.out_ev.record(self.side)
+        self.bytes_moved += n * smax * out.element_size()
+        lens = lens_host.clone()
+        if self.keep is not None:
+            out, lens = out.index_select(0, self.keep), lens.index_select(0, self.keep.cpu())
+        self.last = (step, out, lens)
+        if self.on_block is not None:
+            if self.cuda:
+                self.out_ev.synchronize()
+            self.on_block(step, out, lens)
+
+    def flush(self):
+        """Queue the PCM gather of the last submitted step and wait for everything in flight."""
+        prev, self.pending = self.pending, None
+        if prev is not None:
+            self._gather(*prev)
+        if self.cuda:
+            self.side.synchronize()
+        return self.last
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
