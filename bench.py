@@ -32,6 +32,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA / vector peak
 PEAK_HBM_GBS = 8000.0
+PEAK_MFMA16_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure has 2:1 sparsity)
+ALG_BYTES_PER_SAMPLE_F32 = 19.6e3 + 0.1e3  # layer-granular fp32 activation model (HiFiGAN + flow), per output sample
+# the same layer-granular model with 16-bit conv inputs: a resblock conv pair moves 16 B per element (fp32: 24 B),
+# the transposed convs and conv_pre / conv_post read 16-bit inputs -> 0.66 of the fp32 figure
+ALG_BYTES_PER_SAMPLE_16 = ALG_BYTES_PER_SAMPLE_F32 * 16.0 / 24.0
 
 
 def load_package():
@@ -95,7 +100,7 @@ def cpu_baseline(jobs, mode_name, with_one_thread=True, budget_s=9.0):
     best = max(sweep, key=sweep.get)
     fastest = sustained(best, budget_s, len(order))
     at_rule = fastest if hw == best else sustained(hw, 4.0, 4)
-    one = sustained(1, 0.0, 1) if with_one_thread else None  # one utterance (several seconds)
+    one = sustained(1, 1e9, 3) if with_one_thread else None  # three utterances (several seconds each)
     T = jobs[0][1].shape[1]
     res = {"value": fastest["value"], "unit": "samples/s", "cores": best, "kind": "port",
            "sample": f"{fastest['utterances']} utterance(s) of the same workload ({T} ids each, {mode_name} mode), {fastest['wall_s']:.1f} s wall, sequential "
@@ -106,6 +111,119 @@ def cpu_baseline(jobs, mode_name, with_one_thread=True, budget_s=9.0):
     if one:
         res["one_thread"] = one
     return res
+
+
+def duration_boundary_margin(pkg, model, model_bytes, ids, noise_base, mode, mode_name):
+    """Error bar on "durations bit-exact vs the real ggml path" (VERDICT r2 #6). A duration is ceil(exp(logw) * length_scale)
+    (vits.cpp:996-1001): it can only differ between two implementations whose log-durations differ by eps if w = exp(logw) *
+    length_scale sits within eps (relative) of an integer. The ggml GELU / softmax tables of the absent fork (Q8) are INFERRED here
+    (erf-GELU, fp32 softmax), so this counts, over every id of the benchmark batch, how many w lie within 1e-3 / 1e-2 relative of a
+    ceil() boundary — from the ORACLE's stage one (vo_log_durations) — and checks the GPU's durations against the oracle's on all of them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    om = O.Model(model_bytes)
+    omode = O.MODE_REFERENCE if mode_name == "reference" else O.MODE_HF
+    t0 = time.perf_counter()
+    model.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=noise_base, collect_taps=True, keep_pcm=False)
+    rel, equal, total, maxdev = [], 0, 0, 0.0
+    for u in range(len(ids)):
+        logw, dur = om.log_durations(ids[u], mode=omode, noise_kind=O.NOISE_COUNTER, noise_seed=noise_base + u, threads=min(os.cpu_count() or 1, 16))
+        w = np.exp(logw.astype(np.float64))
+        rel.append(np.abs(w - np.round(w)) / np.maximum(w, 1e-30))
+        g = model.tap("durations", u)
+        equal += int((g == dur).sum())
+        total += dur.size
+        maxdev = max(maxdev, float(np.abs(model.tap("log_duration", u) - logw).max()))
+    rel = np.concatenate(rel)
+    return {"ids": int(total), "within_1e-3_of_a_ceil_boundary": int((rel < 1e-3).sum()), "within_1e-2_of_a_ceil_boundary": int((rel < 1e-2).sum()),
+            "within_1e-4_of_a_ceil_boundary": int((rel < 1e-4).sum()), "smallest_relative_margin": float(rel.min()),
+            "gpu_durations_equal_to_oracle": int(equal), "max_abs_log_duration_gpu_minus_oracle": maxdev,
+            "note": "relative distance of w = exp(log_duration) to the nearest integer, oracle stage one on every id of the benchmark batch; an implementation whose "
+                    "log-durations differ from the oracle's by eps (e.g. ggml's GELU / softmax tables, Q8: inferred, fork absent) can change at most the ids counted "
+                    "within eps", "wall_s": time.perf_counter() - t0}
+
+
+def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
+    """The other configurations of BASELINE.json on the driver's clock: compact, library-default configuration (no
+    per-kernel events), few steps each. c2 = batch 1 x 128 ids fp32 (ms per utterance); c3 in f16 / bf16 arithmetic; c5 = two
+    resident bf16-stored models x 8 x 1024 ids in fp32 and in bf16 arithmetic. Each with the whole-path fraction of its roofs."""
+    out = {}
+    noise_base = 4321
+
+    def run(models_ids, steps, warmup=2):
+        def one():
+            tot, frs = 0, []
+            for m, ids, seed, buf, cap in models_ids:
+                _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=seed, out_device=buf.data_ptr(), out_device_stride=cap,
+                                                     skip_host_copy=True, keep_pcm=False)
+                tot += int(lengths.sum())
+                frs.append(frames)
+            return tot, np.concatenate(frs)
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        samples = 0
+        for _ in range(steps):
+            n, frames = one()
+            samples += n
+        torch.cuda.synchronize()
+        return time.perf_counter() - t, samples, frames
+
+    def entry(e, samples, frames, steps, T, arith, utterances):
+        fl = sum(algorithmic_flops(T, int(f)) for f in frames) * steps
+        sps = samples / e
+        d = {"value": sps, "unit": "samples/s", "ms_per_step": 1000.0 * e / steps, "utterances_per_step": utterances, "ids_per_utterance": T, "steps": steps,
+             "algorithmic_tflops": fl / e / 1e12}
+        if arith == "f32":
+            d.update({"binding_roof": "mfma_f32", "frac_of_binding_roof": fl / e / 1e12 / PEAK_F32_TFLOPS})
+        else:
+            hbm = ALG_BYTES_PER_SAMPLE_16 * sps / 1e9 / PEAK_HBM_GBS
+            mf = fl / e / 1e12 / PEAK_MFMA16_TFLOPS
+            d.update({"binding_roof": "hbm" if hbm >= mf else "mfma_16bit", "frac_of_binding_roof": max(hbm, mf), "frac_hbm_algorithmic": hbm, "frac_mfma16": mf})
+        return d
+
+    def buf_for(B, T):
+        cap = 256 * 8 * T + 294
+        return torch.empty((B, cap), dtype=torch.float32, device="cuda"), cap
+
+    # c2: batch 1, fp32
+    ids1 = pkg.synth_ids(1, 128)
+    b, cap = buf_for(1, 128)
+    n = max(5, int(40 * steps_scale))
+    e, s_, fr = run([(base_model, ids1, noise_base, b, cap)], n, warmup=5)
+    out["c2_f32"] = entry(e, s_, fr, n, 128, "f32", 1)
+    out["c2_f32"]["ms_per_utterance"] = 1000.0 * e / n
+    # c3 in the 16-bit arithmetic modes (default scope: stage one exact, durations identical to the fp32 run's)
+    ids64 = pkg.synth_ids(64, 128)
+    b, cap = buf_for(64, 128)
+    for name, arith in (("f16", pkg.ARITH_F16), ("bf16", pkg.ARITH_BF16)):
+        base_model.set_arith(arith)
+        n = max(3, int(10 * steps_scale))
+        e, s_, fr = run([(base_model, ids64, noise_base, b, cap)], n)
+        out["c3_" + name] = entry(e, s_, fr, n, 128, name, 64)
+    base_model.set_arith(pkg.ARITH_F32)
+    del b
+    # c5: two resident bf16-stored models, 8 x 1024 ids each, calls interleaved
+    specs = [(0x5EED, 1234), (0xBEEF, 91234)]
+    ms = []
+    for seed, ids_seed in specs:
+        m = pkg.Model(pkg.synth_model_bytes(seed, pkg.SYNTH_FULL | pkg.SYNTH_BF16))
+        m.set_mode(mode)
+        bb, cap = buf_for(8, 1024)
+        ms.append((m, pkg.synth_ids(8, 1024, ids_seed=ids_seed), noise_base, bb, cap))
+    try:
+        for name, arith in (("f32", pkg.ARITH_F32), ("bf16", pkg.ARITH_BF16)):
+            for m, *_ in ms:
+                m.set_arith(arith)
+            n = max(2, int((3 if name == "f32" else 5) * steps_scale))
+            e, s_, fr = run(ms, n, warmup=1)
+            out["c5_" + name] = entry(e, s_, fr, n, 1024, name, 16)
+    finally:
+        for m, *_ in ms:
+            m.close()
+    return out
+
 
 
 def find_profile_artifact(pkg, suffix, key, tag):
@@ -185,6 +303,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the pinned-duration and host-PCM passes reported beside the headline")
+    ap.add_argument("--no-sub-results", action="store_true", help="skip the compact sub-results (c2_f32, c3_f16, c3_bf16, c5_f32, c5_bf16) and the "
+                    "duration-boundary report that the default single-GPU run prints beside the headline")
     ap.add_argument("--pcm16", action="store_true", help="multi-GPU: convert to int16 on the device and gather that (half the bytes)")
     ap.add_argument("--balance", choices=["none", "frames"], default="none",
                     help="multi-GPU: 'frames' = every step first predicts frames (frames_only pre-pass on the own block), all-gathers "
@@ -245,8 +365,15 @@ def main():
         if arith != pkg.ARITH_F32:
             m.set_arith(arith)
         ids_all = pkg.synth_ids(B * world, T, ids_seed=ids_seed)  # global batch; rank r owns [r*B, (r+1)*B) unless --balance
+        # the PCM of step i is read by the exchange while step i + 1 is synthesised: three output buffers rotate (multi_gpu.PcmExchange)
+        nbuf = 3 if dist_on else 1
         jobs.append({"model": m, "bytes": mb, "ids_all": ids_all, "ids": ids_all[rank * B:(rank + 1) * B], "offsets": None,
-                     "out": torch.empty((B, cap), dtype=torch.float32, device="cuda")})
+                     "outs": [torch.empty((B, cap), dtype=torch.float32, device="cuda") for _ in range(nbuf)],
+                     "outs16": [torch.zeros((B, cap), dtype=torch.int16, device="cuda") for _ in range(nbuf)] if (dist_on and args.pcm16) else None,
+                     "ex": None, "n": 0})
+    if dist_on:
+        for j in jobs:
+            j["ex"] = mg.PcmExchange(B, cap, dtype=torch.int16 if args.pcm16 else torch.float32, device="cuda")
     noise_base = 4321  # global utterance u draws from the counter stream with seed 4321 + u, wherever it runs
 
     def step(host_pcm=False, pinned=0, collect=None):
@@ -264,20 +391,31 @@ def main():
                 kw = {"noise_seed": noise_base + rank * B}
             else:
                 kw = {"noise_seed": noise_base, "noise_seed_offsets": offs}
-            _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, fixed_duration=pinned, out_device=j["out"].data_ptr(),
+            out = j["outs"][j["n"] % len(j["outs"])]
+            _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, fixed_duration=pinned, out_device=out.data_ptr(),
                                                  out_device_stride=cap, skip_host_copy=not host_pcm, keep_pcm=False,
                                                  vocoder_chunk_frames=args.chunk_frames, **kw)
             if dist_on:
-                # the path's only exchange: ragged all-gather of the PCM (lengths first) over RCCL/xGMI
+                # the path's only exchange: ragged all-gather of the PCM over RCCL/xGMI, pipelined — the lengths of this step are
+                # queued now (fixed-size, no host round trip), the PCM of the PREVIOUS step is gathered while the next one is
+                # synthesised; the last one is drained inside the timed region (see timed()). No meta exchange, no allocation.
                 lens_d = torch.from_numpy(lengths).cuda()
-                g, gl = mg.gather_pcm(mg.to_pcm16(pkg, j["out"], lens_d) if args.pcm16 else j["out"], lens_d)
-                if collect is not None:
-                    collect.append((g, gl))
+                if args.pcm16:
+                    o16 = j["outs16"][j["n"] % len(j["outs16"])]
+                    pkg.pcm16_device(out.data_ptr(), out.stride(0), o16.data_ptr(), o16.stride(0), B, cap, lengths_ptr=lens_d.data_ptr(),
+                                     stream=torch.cuda.current_stream().cuda_stream)
+                    out = o16
+                j["ex"].on_block = (lambda step, g, gl: collect.append((g.clone(), gl.clone()))) if collect is not None else None
+                j["ex"].submit(out, lens_d)
+            j["n"] += 1
             tot_len.append(lengths)
             tot_frames.append(frames)
         return np.concatenate(tot_len), np.concatenate(tot_frames)
 
     def fence():
+        for j in jobs:
+            if j["ex"] is not None:
+                j["ex"].flush()  # drain the exchange pipeline: the last step's PCM gather belongs to the region it was submitted in
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -392,14 +530,33 @@ def main():
                 g["bytes"] += k["bytes"]
                 g["labels"].add(parts[0])
             # dominant kernel: among the matrix-core kernels (the ones with algorithmic FLOP / byte accounting; with 1024-id inputs the
-            # VALU attention kernel can be the longest single entry of a 16-bit step, and it has no MFMA / HBM roof to be priced against)
+            # VALU attention kernel can be the longest single entry of a 16-bit step, and it has no MFMA / HBM roof to be priced against).
+            # fp32: one template instantiation == one rocprofv3 kernel name. 16-bit modes: every fused pair / layer is its own
+            # instantiation (none above 10 % of the step), so the instantiations are first aggregated by kernel FAMILY (the tile letter:
+            # F = rbpair16, T = conv16, W = wavenet16, ...) and the roofline describes the dominant family — per launch averages over
+            # its instantiations, traffic from the PMC file summed the same way.
             mfma_keys = [kk for kk in groups if kk.startswith("k") and groups[kk]["flop"] > 0]
-            dom_key = max(mfma_keys or groups, key=lambda kk: groups[kk]["ms"])
-            dom = groups[dom_key]
+            family_of = lambda kk: (kk.split("|")[2][0] if len(kk.split("|")) >= 3 else "?")
+            FAMILY_NAMES = {"F": "rbpair16_kernel (fused ResBlock conv pair)", "T": "conv16_kernel", "W": "wavenet16_kernel", "f": "rbpair32_kernel",
+                            "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "rbgroup kernels"}
+            dom_members = None
+            if args.arith != "f32" and mfma_keys:
+                fam = {}
+                for kk in mfma_keys:
+                    fam.setdefault(family_of(kk), []).append(kk)
+                dom_fam = max(fam, key=lambda f: sum(groups[kk]["ms"] for kk in fam[f]))
+                dom_members = fam[dom_fam]
+                dom = {"calls": sum(groups[kk]["calls"] for kk in dom_members), "ms": sum(groups[kk]["ms"] for kk in dom_members),
+                       "flop": sum(groups[kk]["flop"] for kk in dom_members), "bytes": sum(groups[kk]["bytes"] for kk in dom_members)}
+                dom_key = "family " + dom_fam + ": " + FAMILY_NAMES.get(dom_fam, dom_fam) + " (" + ", ".join(sorted(dom_members)) + ")"
+            else:
+                dom_key = max(mfma_keys or groups, key=lambda kk: groups[kk]["ms"])
+                dom = groups[dom_key]
+                dom_members = [dom_key]
             avg_ms = dom["ms"] / dom["calls"]
             achieved = dom["flop"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
             all_ms = sum(g["ms"] for g in groups.values())
-            peak = PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
+            peak = PEAK_F32_TFLOPS if args.arith == "f32" else PEAK_MFMA16_TFLOPS  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
             alg_gbs = dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
             mfma_frac, hbm_frac = achieved / peak, alg_gbs / PEAK_HBM_GBS
             if args.arith == "f32" or mfma_frac >= hbm_frac:
@@ -412,24 +569,37 @@ def main():
                                     "algorithmic_tflops": achieved, "mfma_frac_if_algorithmic": mfma_frac,
                                     "algorithmic_gbytes_per_launch": dom["bytes"] / dom["calls"] / 1e9,
                                     "hbm_frac_if_algorithmic": hbm_frac})
-            # HBM bytes per launch of that kernel and MFMA-busy fraction from the PMC passes (separate rocprofv3 --pmc runs over
-            # this same command, reduced by tools/pmc_traffic.py / tools/pmc_summary.py): only a file collected for THIS
-            # build (same source hash) is used, otherwise the fields stay null
+            # HBM bytes per launch of that kernel (family: launch-weighted mean over its instantiations) and MFMA-busy fraction from the
+            # PMC passes (separate rocprofv3 --pmc runs over this same command, reduced by tools/pmc_traffic.py / tools/pmc_mfma.py):
+            # only a file collected for THIS build (same source hash) and THIS workload is used, otherwise the fields stay null
             pmc_tag = "%s|b%d|%s" % (args.workload, B, args.arith)
-            art = find_profile_artifact(pkg, "_pmc_traffic.json", dom_key, pmc_tag)
-            if art:
-                ent = art[1].get("by_bench_key", {}).get(dom_key)
-                if ent:
-                    res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_unit"] = "bytes per launch (" + art[1].get("calibration", "PMC") + "; " + os.path.relpath(art[0], ROOT) + ")"
-                    res["roofline"]["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / (dom["bytes"] / dom["calls"])
-            art = find_profile_artifact(pkg, "_pmc_mfma.json", dom_key, pmc_tag)
-            if art:
-                ent = art[1].get("by_bench_key", {}).get(dom_key)
-                if ent:
-                    res["roofline"]["mfma_busy_frac"] = ent.get("mfma_busy_frac")
-                    res["roofline"]["lds_bank_conflict_frac"] = ent.get("lds_bank_conflict_frac")
-                    res["roofline"]["pmc_source"] = os.path.relpath(art[0], ROOT)
+            art = find_profile_artifact(pkg, "_pmc_traffic.json", dom_members[0], pmc_tag)
+            if art and all(kk in art[1].get("by_bench_key", {}) for kk in dom_members):
+                ents = art[1]["by_bench_key"]
+                tot = sum(ents[kk]["hbm_bytes_per_launch"] * groups[kk]["calls"] for kk in dom_members)
+                res["roofline"]["traffic"] = tot / dom["calls"]
+                res["roofline"]["traffic_unit"] = "bytes per launch (" + art[1].get("calibration", "PMC") + "; " + os.path.relpath(art[0], ROOT) + ")"
+                res["roofline"]["traffic_over_algorithmic"] = tot / dom["bytes"]
+                # whole step: every kernel of the trace (PMC bytes summed over all launches / steps in the trace) against the
+                # layer-granular algorithmic model of SURVEY 8(d) — the figure that matters where the path is HBM-bound
+                ws = art[1].get("whole_step")
+                if ws:
+                    sps = total_samples / args.steps / world
+                    alg = (ALG_BYTES_PER_SAMPLE_F32 if args.arith == "f32" else ALG_BYTES_PER_SAMPLE_16) * sps
+                    res["roofline"]["whole_step_traffic"] = {
+                        "hbm_bytes_per_step": ws["hbm_bytes_per_step"], "fetch_bytes_per_step": ws["fetch_bytes_per_step"], "write_bytes_per_step": ws["write_bytes_per_step"],
+                        "algorithmic_bytes_per_step": alg, "algorithmic_model": "%.1f KB per output sample (SURVEY 8d layer-granular activation model%s) x %d samples" % (
+                            (ALG_BYTES_PER_SAMPLE_F32 if args.arith == "f32" else ALG_BYTES_PER_SAMPLE_16) / 1e3, "" if args.arith == "f32" else ", 16-bit conv inputs: x 16/24", sps),
+                        "ratio": ws["hbm_bytes_per_step"] / alg, "samples_per_step_in_trace": ws.get("samples_per_step"),
+                        "hbm_gbs_at_this_step_time": ws["hbm_bytes_per_step"] / (elapsed / args.steps) / 1e9,
+                        "frac_of_hbm_peak": ws["hbm_bytes_per_step"] / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS, "source": os.path.relpath(art[0], ROOT)}
+            art = find_profile_artifact(pkg, "_pmc_mfma.json", dom_members[0], pmc_tag)
+            if art and all(kk in art[1].get("by_bench_key", {}) for kk in dom_members):
+                ents = art[1]["by_bench_key"]
+                wsum = lambda f: (sum(ents[kk].get(f) * groups[kk]["ms"] for kk in dom_members) / dom["ms"]) if all(ents[kk].get(f) is not None for kk in dom_members) else None
+                res["roofline"]["mfma_busy_frac"] = wsum("mfma_busy_frac")
+                res["roofline"]["lds_bank_conflict_frac"] = wsum("lds_bank_conflict_frac")
+                res["roofline"]["pmc_source"] = os.path.relpath(art[0], ROOT)
             conv_ms = sum(g["ms"] for kk, g in groups.items() if kk.startswith("k"))
             conv_flop = sum(g["flop"] for kk, g in groups.items() if kk.startswith("k"))
             res["kernel_time_ms_per_step"] = all_ms / args.steps
@@ -439,6 +609,16 @@ def main():
             res["top_kernels"] = [{"kernel": kk, "ms_per_step": g["ms"] / args.steps, "calls_per_step": g["calls"] / args.steps,
                                    "tflops": (g["flop"] / (g["ms"] * 1e-3) / 1e12) if g["flop"] else None,
                                    "algorithmic_gbs": (g["bytes"] / (g["ms"] * 1e-3) / 1e9) if g["bytes"] else None} for kk, g in top]
+        default_run = world == 1 and not c5 and args.arith == "f32" and not args.batch and not args.ids_per_utt and not args.pinned and not args.single_pass and \
+            not args.chunk_frames and not dist_on
+        if default_run and not args.no_sub_results:
+            t0 = time.perf_counter()
+            res["sub_results"] = sub_results(pkg, torch, models[0], jobs[0]["bytes"], mode)
+            res["sub_results"]["wall_s"] = time.perf_counter() - t0
+            res["sub_results"]["note"] = ("library default configuration (no per-kernel events), ids -> fp32 PCM in HBM, reference mode, predicted durations; 16-bit modes: "
+                                          "VITS_ARITH_SCOPE_FLOW_VOCODER (stage one exact fp32, durations identical to the fp32 run)")
+            if not args.no_cpu_baseline:
+                res["duration_boundary_margin"] = duration_boundary_margin(pkg, models[0], jobs[0]["bytes"], jobs[0]["ids"], noise_base, mode, args.mode)
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = 24 if not c5 else 1
             cb = cpu_baseline([(j["bytes"], j["ids"][:n_cpu], noise_base) for j in jobs], args.mode, with_one_thread=not c5)

@@ -1156,6 +1156,40 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
     }
 }
 
+/* stage one only (text encoder + duration predictor, ~1 % of the work): the log-durations of one utterance and the durations
+ * ceil(exp(logw) * length_scale) (vits.cpp:995-1001). Used by bench.py's duration-boundary report, which needs all 8,192 ids of the
+ * benchmark batch and cannot afford 64 full vocoder runs. Same code path as vo_process_ids up to that point. */
+VO_API int vo_log_durations(vo_model* mp, const int32_t* ids, int32_t T, const vo_opts* opts, float* logw_out, float* dur_out) {
+    try {
+        const vo_model& m = *mp;
+        if (T <= 0) throw std::runtime_error("empty input");
+        g_arith = (opts && opts->arith_scope == VO_SCOPE_ALL_CONVS) ? opts->arith : 0;
+        struct ArithReset {
+            ~ArithReset() { g_arith = 0; }
+        } arith_reset;
+        Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
+        Act enc, m_p, logs_p;
+        text_encoder(c, ids, T, enc, m_p, logs_p);
+        Act nd(2, T);
+        const int nk = opts ? opts->noise_kind : VO_NOISE_REFERENCE;
+        if (nk == VO_NOISE_EXPLICIT) std::memcpy(nd.d.data(), opts->noise_dur, sizeof(float) * 2 * T);
+        else if (nk == VO_NOISE_COUNTER)
+            for (int i = 0; i < 2 * T; ++i) nd.d[i] = vits_counter_normal(opts->noise_seed, VITS_STREAM_NOISE_DUR, (uint64_t)i);
+        else
+            ref_noise_fill(nd.d.data(), (size_t)2 * T);
+        Act logw = duration_predictor(c, enc, nd.d.data());
+        const float length_scale = (float)(1.0 / m.speaking_rate);
+        for (int t = 0; t < T; ++t) {
+            if (logw_out) logw_out[t] = logw.d[t];
+            if (dur_out) dur_out[t] = std::ceil(std::exp(logw.d[t]) * length_scale);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 VO_API int64_t vo_run_tap(const vo_run* r, const char* name, float* dst, size_t cap) {
     auto it = r->taps.find(name);
     if (it == r->taps.end()) return 0;

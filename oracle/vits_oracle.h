@@ -70,6 +70,8 @@ VO_API int64_t vo_config(const vo_model* m, const char* key, char* dst, size_t c
 
 /* full forward for one utterance of T ids; returns all stage taps */
 VO_API vo_run* vo_process_ids(vo_model* m, const int32_t* ids, int32_t T, const vo_opts* opts);
+/* stage one only: log-durations [T] and durations [T] (= ceil(exp(logw) * length_scale), vits.cpp:995-1001) of one utterance */
+VO_API int vo_log_durations(vo_model* m, const int32_t* ids, int32_t T, const vo_opts* opts, float* logw_out, float* dur_out);
 /* tap names as in include/vits.h vits_model_get_tap */
 VO_API int64_t vo_run_tap(const vo_run* r, const char* name, float* dst, size_t cap);
 VO_API void vo_run_free(vo_run* r);

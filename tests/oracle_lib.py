@@ -67,6 +67,8 @@ def lib():
     L.vo_config.argtypes = [vp, C.c_char_p, C.c_char_p, sz]
     L.vo_process_ids.restype = vp
     L.vo_process_ids.argtypes = [vp, vp, i32, C.POINTER(Opts)]
+    L.vo_log_durations.restype = i32
+    L.vo_log_durations.argtypes = [vp, vp, i32, C.POINTER(Opts), vp, vp]
     L.vo_run_tap.restype = i64
     L.vo_run_tap.argtypes = [vp, C.c_char_p, vp, sz]
     L.vo_run_free.argtypes = [vp]
@@ -158,6 +160,19 @@ class Model:
             return out
         finally:
             lib().vo_run_free(r)
+
+
+def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, threads=0, arith=0, arith_scope=SCOPE_FLOW_VOCODER):
+    """Stage one only (text encoder + duration predictor): (log_duration [T], durations [T]) of one utterance."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    o = Opts(mode, noise_kind, noise_seed, None, None, 0, 0, threads, arith, arith_scope)
+    logw, dur = np.zeros(ids.size, np.float32), np.zeros(ids.size, np.float32)
+    if lib().vo_log_durations(self._h, _ptr(ids), ids.size, C.byref(o), _ptr(logw), _ptr(dur)) != 0:
+        raise OracleError(lib().vo_last_error().decode())
+    return logw, dur
+
+
+Model.log_durations = _log_durations
 
 
 def reference_noise(n, seed=None):

@@ -59,6 +59,7 @@ def test_kernel_names_map_to_the_keys_the_engine_prints():
         "void vits::rbpair32_kernel<3, 5, 32>(vits::RbPair32Params)": "k3|d5|f32|e0",
         "void vits::wavenet32_kernel<192, 5>(vits::WaveNet32Params)": "k5|d1|w192|e1",
         "void vits::wavenet16_kernel<192, 5, false>(vits::WaveNet16Params)": "k5|d1|W192|e1",
+        "void vits::conv_group_kernel<3>(vits::ConvGroupParams)": "kG|d3|G0|e0",
     }
     for name, key in cases.items():
         assert pmc_common.bench_key(name) == key, name

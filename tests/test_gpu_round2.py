@@ -143,6 +143,39 @@ def test_benchmark_batch_is_bit_reproducible_run_to_run(pkg, full_bytes, arith):
                 assert np.array_equal(x, y), (rep, u)
 
 
+def test_grouped_resblock_launches_are_bit_identical_to_separate_launches(pkg, full_bytes, monkeypatch):
+    """conv_group_kernel (conv_mfma.hip): the same-position convolutions of the three resblocks of a C = 256 / C = 128 stage as ONE
+    launch (11-tap blocks first, 3-tap blocks last; /root/reference/src/vits.cpp:622-635 runs the resblocks on the same input). Same
+    kernel body per member, same order of the additions into the shared sum: the PCM of the benchmark batch and of a ragged,
+    windowed batch must not move by a bit against VITS_NO_RB_GROUP=1 — with the profiler on (single stream) and off (fused
+    resblocks on a side stream), both semantics modes."""
+    ids = pkg.synth_ids(64, 128)
+    Ts = [128, 3, 77, 128, 1, 40]
+    outs = {}
+    monkeypatch.setenv("VITS_RB_GROUP", "1")  # (grouped launches also without the profiler, where the library prefers its three streams)
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setenv("VITS_NO_RB_GROUP", "1")
+        with pkg.Model(full_bytes) as m:
+            outs[(grouped, "bench")] = m.process_batch(ids, noise_seed=4321)
+            m.prof_enable(True)
+            outs[(grouped, "bench_prof")] = m.process_batch(ids, noise_seed=4321)
+            if grouped:
+                names = [k["name"] for k in m.prof_report()["kernels"]]
+                assert any("hifigan_resblock_group3" in n for n in names) and any("hifigan_resblock_group2" in n for n in names), names
+            m.prof_enable(False)
+            for mode in (0, 1):
+                outs[(grouped, mode)] = m.process_batch(ids[:6], id_lengths=Ts, mode=mode, noise_seed=9)
+                outs[(grouped, mode, "win")] = m.process_batch(ids[:6], id_lengths=Ts, mode=mode, noise_seed=9, vocoder_chunk_frames=100)
+    for key in [k for k in outs if k[0]]:
+        a, b_ = outs[key], outs[(False,) + key[1:]]
+        assert np.array_equal(a[1], b_[1]), key
+        for x, y in zip(a[0], b_[0]):
+            assert np.array_equal(x, y), key
+    for x, y in zip(outs[(True, "bench")][0], outs[(True, "bench_prof")][0]):
+        assert np.array_equal(x, y)
+
+
 # ---- BASELINE.json config 5 as written -----------------------------------------------------------------------------------
 def test_config5_two_bf16_models_1024_ids_interleaved_and_concurrent(pkg, oracle):
     """Two resident models (seeds 0x5EED / 0xBEEF), conv weights stored as bf16 (type tag 2), 1024-id utterances:

@@ -71,6 +71,38 @@ def main():
     for row, u in enumerate(order):
         n = int(ref_len[u])
         assert int(gl[row]) == n and torch.equal(g[row, :n], ref_all[u, :n]), f"rank {rank}: balanced row {row} (utterance {u}) differs"
+    # 3) the pipelined exchange bench.py uses (multi_gpu.PcmExchange): three steps with different noise seeds through three rotating
+    # buffers, fp32 and int16; every block must arrive once, in order, every row bit-equal to a local recomputation ---------------
+    for pcm16 in (False, True):
+        blocks = []
+        ex = mg.PcmExchange(len(mine), cap, dtype=torch.int16 if pcm16 else torch.float32, device="cuda",
+                            on_block=lambda step, g_, gl_: blocks.append((step, g_.clone(), gl_.clone())))
+        bufs = [torch.zeros((len(mine), cap), dtype=torch.float32, device="cuda") for _ in range(3)]
+        bufs16 = [torch.zeros((len(mine), cap), dtype=torch.int16, device="cuda") for _ in range(3)]
+        for i in range(3):
+            _, lengths, _ = m.process_batch(ids_all[mine], noise_seed=base + 100 * i, noise_seed_offsets=np.asarray(mine, np.int32), out_device=bufs[i].data_ptr(),
+                                            out_device_stride=cap, skip_host_copy=True)
+            lens_d = torch.from_numpy(lengths).cuda()
+            src = bufs[i]
+            if pcm16:
+                pkg.pcm16_device(src.data_ptr(), src.stride(0), bufs16[i].data_ptr(), bufs16[i].stride(0), len(mine), cap, lengths_ptr=lens_d.data_ptr(),
+                                 stream=torch.cuda.current_stream().cuda_stream)
+                src = bufs16[i]
+            ex.submit(src, lens_d)
+            assert len(blocks) == i
+        ex.flush()
+        assert [b[0] for b in blocks] == [0, 1, 2]
+        for i, (_, g, gl) in enumerate(blocks):
+            ref = torch.zeros((total, cap), dtype=torch.float32, device="cuda")
+            _, rl, _ = m.process_batch(ids_all, noise_seed=base + 100 * i, noise_seed_offsets=np.arange(total, dtype=np.int32), out_device=ref.data_ptr(), out_device_stride=cap,
+                                       skip_host_copy=True)
+            rl = torch.from_numpy(rl)
+            if pcm16:
+                ref = mg.to_pcm16(pkg, ref, rl.cuda())
+            assert torch.equal(gl.cpu(), rl), (i, pcm16)
+            for u in range(total):
+                n = int(rl[u])
+                assert torch.equal(g[u, :n], ref[u, :n]), f"rank {rank}: exchange step {i} utterance {u} differs (pcm16={pcm16})"
     dist.barrier()
     dist.destroy_process_group()
     m.close()

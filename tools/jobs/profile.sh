@@ -17,7 +17,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLE
 done
 cd $GRAFT_REPO_ROOT
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
-python3 tools/pmc_traffic.py $O/pmc_traffic.json --workload "$WTAG" --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
+SPS=$(python3 -c "import json; print(json.load(open('$O/bench_under_rocprof.json'))['config']['samples_per_step'])" 2>/dev/null || echo 0)
+python3 tools/pmc_traffic.py $O/pmc_traffic.json --workload "$WTAG" --steps-in-trace 3 --samples-per-step $SPS --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
 python3 tools/pmc_mfma.py $O/pmc_mfma.json --workload "$WTAG" $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT
 # keep the merged payload small: drop the raw traces
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_LDS_BANK_CONFLICT

@@ -17,6 +17,18 @@ if "--workload" in sys.argv:
     WORKLOAD_TAG = sys.argv[i + 1]
     del sys.argv[i:i + 2]
 
+# --steps-in-trace N: bench steps the traced command ran (warm-up + timed: with --single-pass every one of them is instrumented), for
+# the whole-step total; --samples-per-step S is recorded beside it (bench.py checks it against its own run)
+STEPS_IN_TRACE, SAMPLES_PER_STEP = 0, None
+for flag in ("--steps-in-trace", "--samples-per-step"):
+    if flag in sys.argv:
+        i = sys.argv.index(flag)
+        if flag == "--steps-in-trace":
+            STEPS_IN_TRACE = int(sys.argv[i + 1])
+        else:
+            SAMPLES_PER_STEP = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+
 argv = sys.argv[1:]
 out = argv.pop(0)
 FETCH_CAL, WRITE_CAL = 2.0, 1.0
@@ -47,7 +59,14 @@ for name in set(fetch) | set(write):
     key = bench_key(name)
     if key and (key not in by_key or res[name]["launches_sampled"] > by_key[key]["launches_sampled"]):
         by_key[key] = dict(res[name], kernel_name=name)
+whole = None
+if STEPS_IN_TRACE > 0:
+    # every kernel of the trace (library kernels AND the few torch / RCCL ones): counter totals / steps
+    fb = FETCH_CAL * 1024.0 * sum(fetch.values()) / STEPS_IN_TRACE
+    wb = WRITE_CAL * 1024.0 * sum(write.values()) / STEPS_IN_TRACE
+    whole = {"fetch_bytes_per_step": fb, "write_bytes_per_step": wb, "hbm_bytes_per_step": fb + wb, "steps_in_trace": STEPS_IN_TRACE,
+             "samples_per_step": SAMPLES_PER_STEP, "launches_per_step": sum(calls_f.values()) / STEPS_IN_TRACE}
 cal = f"rocprofv3 --pmc FETCH_SIZE x {FETCH_CAL:g} + WRITE_SIZE x {WRITE_CAL:g} (KiB -> bytes; factors calibrated with tools/fetch_calib.hip)"
 json.dump({"note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-pass`",
-           "calibration": cal, "source_sha16": source_sha16(), "workload_tag": WORKLOAD_TAG, "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+           "calibration": cal, "source_sha16": source_sha16(), "workload_tag": WORKLOAD_TAG, "whole_step": whole, "by_bench_key": by_key, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 print(len(res), "kernels ->", out)

@@ -33,7 +33,7 @@
 #include "kernels.h"
 
 // The kernel template is instantiated for ~40 (taps, dilation, tile, epilogue) combinations; one translation unit takes
-// minutes, so the Makefile compiles this file four times: VITS_CONV_PART 0 = host code + taps 1/2/5, 1 = taps 3, 2 = taps 7,
+// minutes, so the Makefile compiles this file five times: VITS_CONV_PART 0 = host code + taps 1/2/5, 1 = taps 3, 2 = taps 7, 4 = grouped launch,
 // 3 = taps 11 (each part defines launch_conv_k<taps>() for the dispatcher in part 0).
 #ifndef VITS_CONV_PART
 #define VITS_CONV_PART 0
@@ -95,7 +95,7 @@ __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]
 #define VITS_STAMP(k)                                                                                               \
     do {                                                                                                            \
         if (tid == 0) {                                                                                             \
-            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
+            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
             if (lin < 65536) {                                                                                      \
                 vits_phase_buf[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                                   \
                 if ((k) == 1 || (k) == 2) vits_phase_buf[8 * lin + 3 + (k)] = __builtin_amdgcn_s_memtime();         \
@@ -116,8 +116,11 @@ __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]
 #ifndef VITS_WAVES_ATTR
 #define VITS_WAVES_ATTR
 #endif
+// The kernel body as a device function of the block's (column tile, row-tile group, utterance) coordinates and the block's dynamic
+// LDS: conv_mfma_kernel runs it for one convolution; conv_group_kernel (below) runs the bodies of up to three convolutions with
+// different tap counts in ONE launch.
 template <int KT, int DIL, bool DB, int WM, int WN, int MR, int NR, int EPI>
-__global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, const int bx, const int by, const int bz) {
     constexpr int BN = WN * NR * 32;
     constexpr int SPAN_C = (KT - 1) * (DIL < 0 ? -DIL : DIL);
     constexpr int STEPS = KT * (CK / 8);  // float4 A-fragments (4 MFMA k-steps each) per chunk and row tile
@@ -128,12 +131,12 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
 #define VITS_LRELU_AT_READ_MAXK 3
 #endif
     constexpr bool LRELU_AT_READ = KT <= VITS_LRELU_AT_READ_MAXK;
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][xw]
+    // xs: [CK][xw] input tile(s)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * BN;
+    const int b = bz;
+    const int t0 = bx * BN;
     const int len_in = p.len_in ? p.len_in[b] : p.t_in;
     // number of valid GEMM columns for this utterance
     int ncols;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     if (t0 >= ncols || len_in <= 0) return;  // (an utterance that has no frames in this vocoder window has length 0)
     VITS_STAMP(0);
 
-    const int mt0 = (blockIdx.y * WM + wm) * MR;  // first 32-row tile of this wave
+    const int mt0 = (by * WM + wm) * MR;  // first 32-row tile of this wave
     // LDS row pitch granularity: 16 floats. (64 — whole dword-DMA pieces — fetched 192 columns for a 128 + 2..10 column
     // tile; 144 needs 18 instead of 24 DMA instructions per chunk and moves 25 % less through L2: 85.8 -> 84.1 ms per step.)
 #ifndef VITS_XWP_GRAN
@@ -547,14 +550,14 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
                 buf = buf + 1 == p.nbuf ? 0 : buf + 1;
 #ifdef VITS_PHASE_TIMING
                 if (tid == 0 && c < 4) {
-                    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
                     if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
                 }
 #endif
                 if (c + 1 < p.nchunks && !oneshot) __syncthreads();  // (see the producer: the last chunk needs no barrier)
 #ifdef VITS_PHASE_TIMING
                 if (tid == 0 && c < 4) {
-                    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
                     if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c + 1] = __builtin_amdgcn_s_memtime();
                 }
 #endif
@@ -839,7 +842,33 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     VITS_STAMP(3);
 }
 
+template <int KT, int DIL, bool DB, int WM, int WN, int MR, int NR, int EPI>
+__global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
+    conv_mfma_body<KT, DIL, DB, WM, WN, MR, NR, EPI>(p, xs_dyn, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- grouped launch: the convolutions of the SAME position in the (up to) three ResBlocks of a vocoder stage (kernel sizes 11 / 7 /
+// 3, one dilation, one channel count; vits.cpp:622-635 runs the resblocks on the same input) as ONE launch -----------------------
+// The resblocks are independent chains, so conv number i of each can run side by side; launched one by one, each of them ends in a
+// partially filled round of blocks (C = 256: 7.2 rounds of 80 us blocks -> 8; three such tails per position). Here blockIdx.z =
+// member * batch + utterance with the members ordered by DESCENDING tap count: the k = 11 blocks are dispatched first and the last
+// round is made of k = 3 blocks, a quarter as long. Same body per member as conv_mfma_kernel -> bit-identical results.
+struct ConvGroupParams {
+    ConvParams m[3];  // slot 0: 11 taps, 1: 7 taps, 2: 3 taps
+    int zend[3];      // blockIdx.z < zend[i] -> member i (an absent member has zend[i] == zend[i - 1])
+};
+template <int DIL>
+__global__ __launch_bounds__(320) VITS_WAVES_ATTR void conv_group_kernel(const ConvGroupParams g) {
+    extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
+    const int z = blockIdx.z;
+    if (z < g.zend[0]) conv_mfma_body<11, DIL, true, 2, 2, 2, 2, EPI_STD>(g.m[0], xs_dyn, blockIdx.x, blockIdx.y, z);
+    else if (z < g.zend[1]) conv_mfma_body<7, DIL, true, 2, 2, 2, 2, EPI_STD>(g.m[1], xs_dyn, blockIdx.x, blockIdx.y, z - g.zend[0]);
+    else conv_mfma_body<3, DIL, true, 2, 2, 2, 2, EPI_STD>(g.m[2], xs_dyn, blockIdx.x, blockIdx.y, z - g.zend[1]);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------
+hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, ConvParams& p);
 struct TileShape {
     int wm, wn, mr, nr;
 };
@@ -1003,6 +1032,57 @@ VITS_LAUNCHER(11) {
 }
 #endif
 
+#if VITS_CONV_PART == 4
+bool conv_group_supported(const PackedConv& w, int dil) {
+    return w.epi == EPI_STD && (w.kt == 11 || w.kt == 7 || w.kt == 3) && (dil == 1 || dil == 3 || dil == 5) && w.rows % 128 == 0 && w.cin % CK == 0;
+}
+hipError_t launch_conv_group(const PackedConv* const* w, const ConvCall* c, int n, hipStream_t s) {
+    if (n < 1 || n > 3) return hipErrorInvalidValue;
+    ConvGroupParams g;
+    std::memset(&g, 0, sizeof(g));
+    const int slot_kt[3] = {11, 7, 3};
+    int have[3] = {-1, -1, -1};
+    for (int i = 0; i < n; ++i) {
+        if (!conv_group_supported(*w[i], c[i].dil) || c[i].dil != c[0].dil || c[i].batch != c[0].batch || w[i]->rows != w[0]->rows || c[i].tile >= 0) return hipErrorInvalidValue;
+        const int slot = w[i]->kt == 11 ? 0 : w[i]->kt == 7 ? 1 : 2;
+        if (have[slot] >= 0) return hipErrorInvalidValue;
+        have[slot] = i;
+    }
+    int z = 0, ncols_max = 0;
+    size_t lds = 0;
+    for (int slot = 0; slot < 3; ++slot) {
+        if (have[slot] >= 0) {
+            const int i = have[slot];
+            if (hipError_t e = make_conv_params(*w[i], c[i], TILE_128x128, g.m[slot])) return e;
+            if (g.m[slot].oneshot) return hipErrorInvalidValue;  // (never: 128 x 128 tiles have MR * NR = 4)
+            g.m[slot].nbuf = 2;
+            z += c[i].batch;
+            ncols_max = std::max(ncols_max, c[i].t_out);
+            const int xwp = (g.m[slot].xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN;
+            lds = std::max(lds, (size_t)2 * CK * xwp * sizeof(float));
+        }
+        g.zend[slot] = z;
+        (void)slot_kt;
+    }
+    dim3 grid((ncols_max + 127) / 128, w[0]->mtiles_used / 4, z);
+#define VITS_GROUP_LAUNCH(D)                                                                                                              \
+    do {                                                                                                                                  \
+        static std::atomic<bool> big_lds_set{false};                                                                                      \
+        if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {                                                            \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_group_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (ea != hipSuccess) return ea;                                                                                              \
+            big_lds_set.store(true, std::memory_order_release);                                                                           \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((conv_group_kernel<D>), grid, dim3(320), lds, s, g);                                                           \
+    } while (0)
+    if (c[0].dil == 1) VITS_GROUP_LAUNCH(1);
+    else if (c[0].dil == 3) VITS_GROUP_LAUNCH(3);
+    else VITS_GROUP_LAUNCH(5);
+#undef VITS_GROUP_LAUNCH
+    return hipGetLastError();
+}
+#endif
+
 #if VITS_CONV_PART == 0
 // The tile a launch will run on: shape rule (choose_conv_tile), then the small-grid steps. Also what the engine's profiler prints.
 int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
@@ -1041,8 +1121,8 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
     return tile;
 }
 
-hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
-    ConvParams p;
+// ConvCall -> kernel parameters for the tile `tile` (also used by the grouped launch, part 4)
+hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, ConvParams& p) {
     p.x = c.x.p;
     p.x_bs = c.x.bs;
     p.x_cs = c.x.cs;
@@ -1076,7 +1156,6 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     p.ct_stride = w.ct_stride;
     p.ct_crop = c.ct_crop;
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
-    const int tile = resolve_conv_tile(w, c);
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
     if (w.epi == EPI_CONVT) {
@@ -1108,6 +1187,15 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
             p.nbuf = w.nchunks;
         }
     }
+    return hipSuccess;
+}
+
+hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
+    ConvParams p;
+    const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
+    const int tile = resolve_conv_tile(w, c);
+    if (hipError_t e = make_conv_params(w, c, tile, p)) return e;
+    const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;
     // compile-time dilation for the combinations the MMS architecture uses; run-time dilation (DIL = 0) otherwise

@@ -33,6 +33,7 @@ void Knobs::read() {
     no_fuse16 = flag("VITS_NO_FUSE16");
     no_fuse32 = flag("VITS_NO_FUSE32");
     no_rb_group = flag("VITS_NO_RB_GROUP");
+    rb_group_always = flag("VITS_RB_GROUP");
 }
 
 // ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----

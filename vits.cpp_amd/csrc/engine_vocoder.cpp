@@ -254,10 +254,220 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             }
             HIP_OK(conv("hifigan_upsample_convT", U.up, c));
         }
-        // resblock j runs on its own stream (engine.h); only the LAST convolution of each resblock touches the shared
-        // sum, and those are chained j-1 -> j by events so the additions keep the reference's order (vits.cpp:622-635)
-        // (per-kernel event timing needs kernels that do not overlap: the profiler serialises the stage)
+        // ---- the resblocks of this stage (vits.cpp:622-635): independent chains of `nd` conv pairs on the same input that meet only in
+        // the sum. Only the LAST launch of each chain touches the shared sum, and those run in the reference's order (RB0, += RB1,
+        // += RB2 and the 1/num_kernels scale) on the main stream. Everything before them is scheduled one of two ways:
+        //   grouped  — the same-position convs of the resblocks as ONE launch (conv_group_kernel: 11-tap blocks first, 3-tap blocks
+        //              last, one grid tail instead of three); resblocks that run as fused pairs (rbpair32) keep their own chain;
+        //   separate — every resblock its own chain of launches, on three streams (or serialised under the profiler, whose
+        //              per-kernel events need kernels that do not overlap).
+        // Same kernels bodies, same operands, same order of the additions either way: the PCM is bit-identical (GPU test).
+        const bool lcopy = C >= knobs.lrelu_copy_minc;
+        TensorRef bul = TR(s2.bul, C, sts[st_out]);
+        auto al16 = [](const TensorRef& t) { return (reinterpret_cast<uintptr_t>(t.p) & 15) == 0 && (t.cs & 3) == 0 && (t.bs & 3) == 0; };
+        // which resblocks run as fused pairs (narrow stages; all pairs of a resblock or none)
+        bool fusedrb[3] = {false, false, false};
+        for (size_t j = 0; j < nk && j < 3; ++j) {
+            const ResBlockW& R = U.rbs[j];
+            bool f = !knobs.no_fuse32 && al16(bu) && (reinterpret_cast<uintptr_t>(s2.by[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(s2.bt[0]) & 15) == 0 && (sts[st_out] & 3) == 0;
+            for (size_t d = 0; d < R.dil.size() && f; ++d) f = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
+            fusedrb[j] = f;
+        }
+        // grouped schedule: at least two un-fused resblocks with distinct tap counts of {11, 7, 3}, the same dilation list, on the 128 x 128 tile
+        // (measured, batch 64 x 128 ids: serialised launches 79.7 ms per step, grouped 79.1, three streams 76.8 — kernels of DIFFERENT
+        // launches share a CU, which blocks of one launch do not, so the streams win where they can be used: the
+        // grouped schedule is for the single-stream case, i.e. under the per-kernel profiler; VITS_RB_GROUP=1 forces it)
+        bool grouped = !knobs.no_rb_group && nk >= 2 && nk <= 3 && knobs.rb_streams > 1 && (prof.on || knobs.rb_group_always);
+        {
+            int members = 0, seen = 0;
+            for (size_t j = 0; j < nk && grouped; ++j) {
+                const ResBlockW& R = U.rbs[j];
+                if (R.dil != U.rbs[0].dil) grouped = false;
+                if (fusedrb[j]) continue;
+                const int bit = R.k == 11 ? 1 : R.k == 7 ? 2 : R.k == 3 ? 4 : 0;
+                if (!bit || (seen & bit)) grouped = false;
+                seen |= bit;
+                ConvCall shape;  // (what the tile rule looks at: small grids step down from the 128 x 128 tile and are not grouped)
+                shape.batch = B;
+                shape.t_in = shape.t_out = smax[st_out];
+                for (size_t d = 0; d < R.dil.size() && grouped; ++d)
+                    grouped = conv_group_supported(R.c1[d], R.dil[d]) && conv_group_supported(R.c2[d], 1) && resolve_conv_tile(R.c1[d], shape) == TILE_128x128;
+                ++members;
+            }
+            grouped = grouped && members >= 2;
+        }
         const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on;
+        auto bufq = [&](size_t j) { return (par || grouped) ? (int)j : 0; };  // resblocks that overlap in time need their own (y, t, y') buffers
+        // conv 1 / conv 2 of pair d of resblock j (two-launch form)
+        auto mk_c1 = [&](size_t j, size_t d) {
+            const ResBlockW& R = U.rbs[j];
+            const int q = bufq(j);
+            TensorRef by = TR(s2.by[q], C, sts[st_out]), bt = TR(s2.bt[q], C, sts[st_out]), byl = TR(s2.byl[q], C, sts[st_out]);
+            TensorRef resid = d == 0 ? bu : by;
+            // LeakyReLU is applied where a tensor is WRITTEN, not where it is read: the first conv of a pair stores leaky_relu(t)
+            // (t has no other reader), and for wide stages the second conv stores leaky_relu(y) beside y (y itself stays the
+            // residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the issue port, measured 5 % (k = 11)
+            // to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
+            ConvCall c1;
+            c1.x = lcopy ? (d > 0 ? byl : bul) : resid;
+            c1.y = bt;
+            c1.len_in = c1.len_out = d_len[st_out];
+            c1.batch = B;
+            c1.t_in = c1.t_out = smax[st_out];
+            c1.sum_in = c1.sum_out = ssum[st_out];
+            c1.dil = R.dil[d];
+            c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
+            c1.pre_act = lcopy ? 0 : 1;
+            c1.slope = hp.lrelu;
+            c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
+            c1.post_slope = hp.lrelu;
+            return c1;
+        };
+        auto mk_c2 = [&](size_t j, size_t d) {
+            const ResBlockW& R = U.rbs[j];
+            const size_t nd = R.dil.size();
+            const int q = bufq(j);
+            TensorRef by = TR(s2.by[q], C, sts[st_out]), bt = TR(s2.bt[q], C, sts[st_out]), byl = TR(s2.byl[q], C, sts[st_out]);
+            ConvCall c2 = mk_c1(j, d);
+            c2.x = bt;
+            c2.pre_act = 0;
+            c2.post_act = 0;
+            c2.y2 = (d + 1 < nd && lcopy) ? byl.p : nullptr;
+            c2.dil = 1;
+            c2.pad_l = (R.k - 1) / 2;
+            c2.res = d == 0 ? bu : by;  // residual add (vits.cpp:578)
+            if (d + 1 < nd) c2.y = by;
+            else {
+                // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)
+                c2.y = bsum;
+                if (j > 0) c2.acc = bsum;
+                if (j + 1 == nk) {
+                    if (refmode) {
+                        c2.scale = (float)(1.0 / (double)nk);  // ggml_scale by float(1/num_kernels) (vits.cpp:607)
+                        c2.scale_div = 0;
+                    } else {
+                        c2.scale = (float)nk;  // HF divides (modeling_vits.py:546)
+                        c2.scale_div = 1;
+                    }
+                } else {
+                    c2.scale = 1.f;
+                }
+                // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the scale 1/1 is the
+                // identity, so no special case is needed)
+                if (j + 1 == nk && i + 1 < n_up) {
+                    // the stage output feeds only the next upsampler, which wants leaky_relu of it (vits.cpp:613); the last
+                    // stage stays raw: conv_post applies its own slope (Q2)
+                    c2.post_act = 2;
+                    c2.post_slope = hp.lrelu;
+                }
+            }
+            return c2;
+        };
+        // pair d of resblock j as ONE kernel, t stays in LDS (rbpair32.hip; bit-identical to the two launches). A fused block reads a
+        // halo of its neighbours' input columns while other blocks store their output, so the resblock's stream ping-pongs between
+        // `by` and the buffer the two-launch path uses for t.
+        auto run_fused = [&](size_t j, size_t d, hipStream_t sj) -> int {
+            const ResBlockW& R = U.rbs[j];
+            const size_t nd = R.dil.size();
+            const int q = bufq(j);
+            TensorRef by = TR(s2.by[q], C, sts[st_out]), bt = TR(s2.bt[q], C, sts[st_out]);
+            const bool last = d + 1 == nd;
+            RbPair32Call f;
+            f.x = d == 0 ? bu : ((d & 1) ? by : bt);
+            f.lens = d_len[st_out];
+            f.batch = B;
+            f.tmax = smax[st_out];
+            f.dil = R.dil[d];
+            f.slope = hp.lrelu;
+            if (!last) {
+                f.y = (d & 1) ? bt : by;
+            } else {
+                f.y = bsum;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635), as in mk_c2
+                if (j > 0) f.acc = bsum;
+                if (j + 1 == nk) {
+                    if (refmode) {
+                        f.scale = (float)(1.0 / (double)nk);
+                        f.scale_div = 0;
+                    } else {
+                        f.scale = (float)nk;
+                        f.scale_div = 1;
+                    }
+                    if (i + 1 < n_up) {
+                        f.post_act = 2;
+                        f.post_slope = hp.lrelu;
+                    }
+                } else {
+                    f.scale = 1.f;
+                }
+            }
+            if (prof.on) {
+                char full[160];
+                std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|f%d|e0|c%dx%d", R.k, R.dil[d], C, C, C);
+                const double n_out = (double)C * (double)ssum[st_out];
+                prof.begin(full, 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], 4.0 * n_out * (3 + (f.acc.p ? 1 : 0)) + (double)R.c1[d].bytes + (double)R.c2[d].bytes, sj, true);
+            }
+            HIP_OK(launch_rbpair32(R.c1[d], R.c2[d], f, sj));
+            prof.end(sj);
+            return 0;
+        };
+        if (grouped) {
+            // ---- grouped schedule ---------------------------------------------------------------------------------------------------
+            const size_t nd = U.rbs[0].dil.size();
+            // fused resblocks: their chain up to (not including) the last pair, beside the group — on a side stream unless the profiler
+            // needs kernels that do not overlap
+            bool any_fused = false;
+            for (size_t j = 0; j < nk; ++j) any_fused = any_fused || fusedrb[j];
+            hipStream_t sf = (any_fused && !prof.on) ? side_[0] : stream;
+            if (sf != stream) {
+                HIP_OK(hipEventRecord(ev_fork_, stream));
+                HIP_OK(hipStreamWaitEvent(sf, ev_fork_, 0));
+            }
+            for (size_t j = 0; j < nk; ++j)
+                if (fusedrb[j])
+                    for (size_t d = 0; d + 1 < nd; ++d)
+                        if (run_fused(j, d, sf)) return -1;
+            if (sf != stream) HIP_OK(hipEventRecord(ev_done_[0], sf));
+            auto run_group = [&](size_t d, bool second) -> int {
+                const PackedConv* gw[3];
+                ConvCall gc[3];
+                int n = 0;
+                double flop = 0, bytes = 0;
+                for (size_t j = 0; j < nk; ++j) {
+                    if (fusedrb[j]) continue;
+                    const ResBlockW& R = U.rbs[j];
+                    gw[n] = second ? &R.c2[d] : &R.c1[d];
+                    gc[n] = second ? mk_c2(j, d) : mk_c1(j, d);
+                    const ConvCall& cc = gc[n];
+                    flop += conv_flops(*gw[n], cc, ssum[st_out]);
+                    bytes += 4.0 * ((double)C * ssum[st_out] * (2 + (cc.res.p ? 1 : 0) + (cc.acc.p ? 1 : 0) + (cc.y2 ? 1 : 0))) + (double)gw[n]->bytes;
+                    ++n;
+                }
+                if (prof.on) {
+                    char full[160];
+                    std::snprintf(full, sizeof(full), "hifigan_resblock_group%d|kG|d%d|G0|e0|c%dx%d", n, second ? 1 : U.rbs[0].dil[d], C, C);
+                    prof.begin(full, flop, bytes, stream, /*chain=*/true);
+                }
+                HIP_OK(launch_conv_group(gw, gc, n, stream));
+                prof.end(stream);
+                return 0;
+            };
+            for (size_t d = 0; d < nd; ++d) {
+                if (run_group(d, false)) return -1;
+                if (d + 1 < nd && run_group(d, true)) return -1;
+            }
+            // the last launch of every resblock, in the reference's order of the additions
+            if (sf != stream) HIP_OK(hipStreamWaitEvent(stream, ev_done_[0], 0));
+            for (size_t j = 0; j < nk; ++j) {
+                if (fusedrb[j]) {
+                    if (run_fused(j, nd - 1, stream)) return -1;
+                } else {
+                    HIP_OK(conv("hifigan_resblock_conv", U.rbs[j].c2[nd - 1], mk_c2(j, nd - 1), stream));
+                }
+            }
+            cur = bsum;
+            continue;
+        }
+        // ---- separate schedule: resblock j on its own stream (engine.h), the last launches chained j-1 -> j by events ---------------
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
@@ -266,120 +476,16 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             const ResBlockW& R = U.rbs[j];
             const size_t nd = R.dil.size();
             hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
-            TensorRef by = TR(s2.by[par ? j : 0], C, sts[st_out]), bt = TR(s2.bt[par ? j : 0], C, sts[st_out]);
-            // LeakyReLU is applied where a tensor is WRITTEN, not where it is read: the first conv of a pair stores
-            // leaky_relu(t) (t has no other reader), and for wide stages the second conv stores leaky_relu(y) beside y
-            // (y itself stays the residual). A reader-side LeakyReLU is VALU work next to the MFMAs — they share the
-            // issue port, measured 5 % (k = 11) to 20 % (k = 3) of the K loop — a writer-side one sits in the epilogue.
-            const bool lcopy = C >= knobs.lrelu_copy_minc;
-            TensorRef byl = TR(s2.byl[par ? j : 0], C, sts[st_out]), bul = TR(s2.bul, C, sts[st_out]);
-            // narrow stages: each pair as ONE kernel, t stays in LDS (rbpair32.hip; bit-identical to the two launches below).
-            // A fused block reads a halo of its neighbours' input columns while other blocks store their output, so the
-            // resblock's stream ping-pongs between `by` and the buffer the two-launch path uses for t. All pairs or none.
-            bool fuse_rb = !knobs.no_fuse32;  // (the fused kernel reads the RAW stream: the activated copies of wide stages are for the other resblocks)
-            // (16-byte LDS-DMA rows: every buffer a pair may read has to be 16-byte aligned with strides that are multiples of 4)
-            auto al16 = [](const TensorRef& t) { return (reinterpret_cast<uintptr_t>(t.p) & 15) == 0 && (t.cs & 3) == 0 && (t.bs & 3) == 0; };
-            fuse_rb = fuse_rb && al16(bu) && al16(by) && al16(bt);
-            for (size_t d = 0; d < nd && fuse_rb; ++d) fuse_rb = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
-            if (fuse_rb) {
-                TensorRef src = bu;
-                for (size_t d = 0; d < nd; ++d) {
-                    const bool last = d + 1 == nd;
-                    RbPair32Call f;
-                    f.x = src;
-                    f.lens = d_len[st_out];
-                    f.batch = B;
-                    f.tmax = smax[st_out];
-                    f.dil = R.dil[d];
-                    f.slope = hp.lrelu;
-                    if (!last) {
-                        f.y = src.p == by.p ? bt : by;
-                    } else {
-                        f.y = bsum;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635), as below
-                        if (j > 0) f.acc = bsum;
-                        if (j + 1 == nk) {
-                            if (refmode) {
-                                f.scale = (float)(1.0 / (double)nk);
-                                f.scale_div = 0;
-                            } else {
-                                f.scale = (float)nk;
-                                f.scale_div = 1;
-                            }
-                            if (i + 1 < n_up) {
-                                f.post_act = 2;
-                                f.post_slope = hp.lrelu;
-                            }
-                        } else {
-                            f.scale = 1.f;
-                        }
-                    }
-                    if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
-                    if (prof.on) {
-                        char full[160];
-                        std::snprintf(full, sizeof(full), "hifigan_resblock_pair|k%d|d%d|f%d|e0|c%dx%d", R.k, R.dil[d], C, C, C);
-                        const double n_out = (double)C * (double)ssum[st_out];
-                        prof.begin(full, 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out],
-                                   4.0 * n_out * (3 + (f.acc.p ? 1 : 0)) + (double)R.c1[d].bytes + (double)R.c2[d].bytes, sj, true);
-                    }
-                    HIP_OK(launch_rbpair32(R.c1[d], R.c2[d], f, sj));
-                    prof.end(sj);
-                    if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
-                    src = f.y;
-                }
-                continue;
-            }
+            const bool fuse_rb = j < 3 ? fusedrb[j] : false;
             for (size_t d = 0; d < nd; ++d) {
-                TensorRef resid = d == 0 ? bu : by;
-                ConvCall c1;
-                c1.x = lcopy ? (d > 0 ? byl : bul) : resid;
-                c1.y = bt;
-                c1.len_in = c1.len_out = d_len[st_out];
-                c1.batch = B;
-                c1.t_in = c1.t_out = smax[st_out];
-                c1.sum_in = c1.sum_out = ssum[st_out];
-                c1.dil = R.dil[d];
-                c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;  // vits.cpp:541-543
-                c1.pre_act = lcopy ? 0 : 1;
-                c1.slope = hp.lrelu;
-                c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
-                c1.post_slope = hp.lrelu;
-                HIP_OK(conv("hifigan_resblock_conv", R.c1[d], c1, sj));
-                ConvCall c2 = c1;
-                c2.x = bt;
-                c2.pre_act = 0;
-                c2.post_act = 0;
-                c2.y2 = (d + 1 < nd && lcopy) ? byl.p : nullptr;
-                c2.dil = 1;
-                c2.pad_l = (R.k - 1) / 2;
-                c2.res = resid;  // residual add (vits.cpp:578)
-                if (d + 1 < nd) c2.y = by;
-                else {
-                    // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)
-                    c2.y = bsum;
-                    if (j > 0) c2.acc = bsum;
-                    if (j + 1 == nk) {
-                        if (refmode) {
-                            c2.scale = (float)(1.0 / (double)nk);  // ggml_scale by float(1/num_kernels) (vits.cpp:607)
-                            c2.scale_div = 0;
-                        } else {
-                            c2.scale = (float)nk;  // HF divides (modeling_vits.py:546)
-                            c2.scale_div = 1;
-                        }
-                    } else {
-                        c2.scale = 1.f;
-                    }
-                    // (a vocoder with a single resblock kernel has nothing to accumulate: acc stays null and the
-                    // scale 1/1 is the identity, so no special case is needed)
-                    if (j + 1 == nk && i + 1 < n_up) {
-                        // the stage output feeds only the next upsampler, which wants leaky_relu of it (vits.cpp:613);
-                        // the last stage stays raw: conv_post applies its own slope (Q2)
-                        c2.post_act = 2;
-                        c2.post_slope = hp.lrelu;
-                    }
-                }
                 const bool last = d + 1 == nd;
+                if (!fuse_rb) HIP_OK(conv("hifigan_resblock_conv", R.c1[d], mk_c1(j, d), sj));
                 if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
-                HIP_OK(conv("hifigan_resblock_conv", R.c2[d], c2, sj));
+                if (fuse_rb) {
+                    if (run_fused(j, d, sj)) return -1;
+                } else {
+                    HIP_OK(conv("hifigan_resblock_conv", R.c2[d], mk_c2(j, d), sj));
+                }
                 if (par && last) HIP_OK(hipEventRecord(ev_done_[j], sj));
             }
         }

@@ -81,6 +81,10 @@ int choose_conv_tile(int rows, int epi, int t_hint);
 int resolve_conv_tile(const PackedConv& w, const ConvCall& c);  // the tile launch_conv will use (small-grid rules included)
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s);
 double conv_flops(const PackedConv& w, const ConvCall& c, int64_t total_cols);
+// The same-position convolutions of up to three ResBlocks (11 / 7 / 3 taps, one dilation of {1, 3, 5}, one channel count that is a
+// multiple of 128) as ONE launch on the 128 x 128 tile; results are bit-identical to n launch_conv calls.
+bool conv_group_supported(const PackedConv& w, int dil);
+hipError_t launch_conv_group(const PackedConv* const* w, const ConvCall* c, int n, hipStream_t s);
 
 // ---- 16-bit-operand convolution (conv16.hip): v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate --------------------
 struct Conv16Call {
