@@ -40,6 +40,29 @@ __device__ __forceinline__ unsigned rb_pack16(float a, float b) {
     else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, half2v));
 }
 
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/rb16_micro.hip): per-block phase timestamps
+__device__ unsigned long long vits_rb_phase[16 * 65536];  // [block][0..6] 100 MHz stamps, [7] HW_ID, [8] XCC_ID, [9..10] shader clock around conv1
+#define RB_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if (threadIdx.x == 0) {                                                                         \
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;                                   \
+            if (lin < 65536) {                                                                          \
+                vits_rb_phase[16 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                       \
+                if ((k) == 1 || (k) == 2) vits_rb_phase[16 * lin + 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+                if ((k) == 0) {                                                                         \
+                    unsigned hw, xcc;                                                                   \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                   \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                 \
+                    vits_rb_phase[16 * lin + 7] = hw;                                                   \
+                    vits_rb_phase[16 * lin + 8] = xcc;                                                  \
+                }                                                                                       \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
+#else
+#define RB_STAMP(k)
+#endif
+
 struct RbPairParams {
     const uint16_t* x;  // leaky_relu(y), rounded: group layout [b][C/8][x_ts][8]
     int64_t x_bs;
@@ -93,6 +116,7 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
     const int len = p.lens ? p.lens[b] : p.tmax;
     const int t0 = blockIdx.x * BO;
     if (t0 >= len) return;
+    RB_STAMP(0);
     const int h = lane >> 5;
     const int rt0 = ROWS ? wid : 0;               // first 32-row tile of this wave
     const int cb = ROWS ? 0 : wid * (NR * 32);    // first mid column of this wave
@@ -166,43 +190,51 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int i = 0; i < RD; ++i) ring[i][mr] = load_a(mr, i < TOTAL ? i : TOTAL - 1);
+        // B operands come from LDS PD steps ahead of their MFMAs (a ring of PD + 1 register sets). Measured (tools/rb16_micro.hip, C = 128,
+        // k = 11 / 3): PD = 2 / 3 and a deeper residual ring in the epilogue are +-0 — the pair is not latency-bound: the matrix pipes are
+        // 83-98 % busy at the shader clock the power budget leaves (1.1 GHz in the conv phases with the epilogue's HBM traffic beside them,
+        // 1.24 GHz without it; a register-only fp16 MFMA loop sustains 1.93 GHz, tools/mfma16_peak.hip). DESIGN.md section 4.3.
+#ifndef VITS_RB16_PD
+#define VITS_RB16_PD 1
+#endif
+        constexpr int PD = VITS_RB16_PD;
+        auto boff = [&](int G) __attribute__((always_inline)) -> int {  // slot offset of global step G (compile time after unrolling)
+            const int c = G / STEPS, sl = G % STEPS;
+            return c * 4 * pitch + ((sl & 1) ? 2 * pitch : 0) + (sl >> 1) * dstep;
+        };
+        int4v bq[PD + 1][NR];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            LdsV xb = base + c * 4 * pitch;
-            int4v b_nxt[NR];
+        for (int i = 0; i < PD; ++i)
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[nr * 32];
+            for (int nr = 0; nr < NR; ++nr) bq[i][nr] = base[boff(i < TOTAL ? i : TOTAL - 1) + nr * 32];
 #pragma unroll
-            for (int j = 0; j < KT; ++j)
+        for (int s = 0; s < TOTAL; ++s) {
+            {
+                const int nstep = s + RD < TOTAL ? s + RD : TOTAL - 1;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int s = c * STEPS + j * 2 + kk;  // compile time after unrolling
-                    {
-                        const int nstep = s + RD < TOTAL ? s + RD : TOTAL - 1;
+                for (int mr = 0; mr < MR; ++mr) ring[(s + RD) % RS][mr] = load_a(mr, nstep);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int ns = s + PD < TOTAL ? s + PD : TOTAL - 1;  // (past the end: a valid slot, value unused)
+#ifndef VAR_NOB  // (ablations of tools/rb16_micro.hip: VAR_NOB / VAR_NOEPI drop the LDS operand reads / the epilogue)
 #pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) ring[(s + RD) % RS][mr] = load_a(mr, nstep);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    int4v b_cur[NR];
+                for (int nr = 0; nr < NR; ++nr) bq[(s + PD) % (PD + 1)][nr] = base[boff(ns) + nr * 32];
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
-                    {
-                        const int noff = kk == 0 ? 2 * pitch + j * dstep : (j + 1) * dstep;
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[noff + nr * 32];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s % RS][mr], b_cur[nr], acc[mr][nr]);
-                }
+                for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s % RS][mr], bq[s % (PD + 1)][nr], acc[mr][nr]);
         }
     };
 
     __syncthreads();
+    RB_STAMP(1);
     // ---- phase 1: conv1 over the x tile: mid column i reads x slots i + j*DIL ------------------------------------------------
     conv(p.w1, (LdsV)(xs + h * XWP + cb + (lane & 31)), XWP, DIL);
+    RB_STAMP(2);
     if constexpr (ALIAS) __syncthreads();  // every wave is done with the x tile: t takes its place
 
     // ---- phase 2: t = round(leaky_relu(conv1 + b1)), zero outside the sequence, into LDS (group layout) -------------------
@@ -234,18 +266,37 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    RB_STAMP(3);
 
     // ---- phase 3: conv2 over the t tile: output column o reads t slots o + j -------------------------------------------------
     conv(p.w2, (LdsV)(ts + h * TW + cb + (lane & 31)), TW, 1);
+    RB_STAMP(4);
 
     // ---- phase 4: epilogue (as conv16's group epilogue): + b2, + residual, resblock sum / scale, fp32 stream + 16-bit copy ----
+#ifdef VAR_NOEPI
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) p.yg[tid] = sacc;
+        RB_STAMP(5);
+        return;
+    }
+#endif
     {
         float* yg = p.yg ? p.yg + (int64_t)b * p.g_bs : nullptr;
         const float* rg = p.resg ? p.resg + (int64_t)b * p.g_bs : nullptr;
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
         constexpr int NGR = MR * 4;
-        constexpr int RD = ROWS ? 2 : 3;  // residual look-ahead ring (row split: NR = 4 float4 per entry, and 208 VGPRs with three of them)
+#ifndef VITS_RB16_ERD
+#define VITS_RB16_ERD (ROWS ? 2 : 3)
+#endif
+        constexpr int RD = VITS_RB16_ERD;  // residual look-ahead ring (row split: NR = 4 float4 per entry, and 208 VGPRs with three of them)
         float4v rv[RD][NR];
         auto col_ok = [&](int nr, int& t) __attribute__((always_inline)) -> bool {
             const int o = cb + nr * 32 + (lane & 31);
@@ -302,6 +353,7 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
             }
         }
     }
+    RB_STAMP(5);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
