@@ -538,7 +538,7 @@ def main():
             mfma_keys = [kk for kk in groups if kk.startswith("k") and groups[kk]["flop"] > 0]
             family_of = lambda kk: (kk.split("|")[2][0] if len(kk.split("|")) >= 3 else "?")
             FAMILY_NAMES = {"F": "rbpair16_kernel (fused ResBlock conv pair)", "T": "conv16_kernel", "W": "wavenet16_kernel", "f": "rbpair32_kernel",
-                            "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "rbgroup kernels"}
+                            "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "conv_group_kernel", "B": "rbblock16_kernel (whole ResBlock)"}
             dom_members = None
             if args.arith != "f32" and mfma_keys:
                 fam = {}
@@ -605,7 +605,7 @@ def main():
             res["kernel_time_ms_per_step"] = all_ms / args.steps
             res["all_conv_kernels"] = {"tflops": conv_flop / (conv_ms * 1e-3) / 1e12, "frac_of_peak": conv_flop / (conv_ms * 1e-3) / 1e12 / peak,
                                        "share_of_gpu_time": conv_ms / all_ms}
-            top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:10]
+            top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:48]
             res["top_kernels"] = [{"kernel": kk, "ms_per_step": g["ms"] / args.steps, "calls_per_step": g["calls"] / args.steps,
                                    "tflops": (g["flop"] / (g["ms"] * 1e-3) / 1e12) if g["flop"] else None,
                                    "algorithmic_gbs": (g["bytes"] / (g["ms"] * 1e-3) / 1e9) if g["bytes"] else None} for kk, g in top]

@@ -274,6 +274,46 @@ def test_fused_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, full_b
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name,arith,_tol", ARITHS)
+def test_whole_resblock_kernel_is_bit_identical_to_the_pair_path(pkg, full_bytes, monkeypatch, name, arith, _tol):
+    """rbblock16.hip (C = 32 / 64: the three conv pairs of a resblock as ONE kernel, the fp32 stream in registers, x / t in one LDS tile)
+    against three rbpair16 launches (VITS_NO_RBBLOCK16=1): same operands, rounding points and k-order, so the PCM must not move by a bit —
+    ragged batch with very short members (tiles that are mostly sequence-end padding), windowed vocoder, both semantics modes, and
+    utterances long enough that a launch runs many rounds of blocks (/root/reference/src/vits.cpp:545-581,622-635)."""
+    Ts = [30, 11, 40, 1, 2]
+    ids = np.zeros((5, 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = _ids(T, 90 + b)
+    long_ids = pkg.synth_ids(2, 700, ids_seed=4242)
+    outs = {}
+    for block in (True, False):
+        if not block:
+            monkeypatch.setenv("VITS_NO_RBBLOCK16", "1")
+        with pkg.Model(full_bytes) as m:
+            m.set_arith(arith)
+            for mode in (0, 1):
+                outs[(block, mode, 0)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33)
+                outs[(block, mode, 1)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=33, vocoder_chunk_frames=24)
+            outs[(block, "long", 0)] = m.process_batch(long_ids, noise_seed=34, fixed_duration=2)
+            m.prof_enable(True)
+            outs[(block, "prof", 0)] = m.process_batch(ids, id_lengths=Ts, noise_seed=33)
+            names = [k["name"] for k in m.prof_report()["kernels"]]
+            assert any("hifigan_resblock_block" in n for n in names) == block, names
+            m.prof_enable(False)
+    for x, y in zip(outs[(True, "long", 0)][0], outs[(False, "long", 0)][0]):
+        assert np.array_equal(x, y), "long utterance"
+    for x, y in zip(outs[(True, "prof", 0)][0], outs[(True, 0, 0)][0]):
+        assert np.array_equal(x, y), "profiler (serial) run"
+    for mode in (0, 1):
+        for w in (0, 1):
+            a, b_ = outs[(True, mode, w)], outs[(False, mode, w)]
+            assert np.array_equal(a[1], b_[1])
+            for x, y in zip(a[0], b_[0]):
+                assert np.array_equal(x, y), (mode, w)
+        for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
+            assert np.array_equal(x, y)
+
+
 def test_long_form_1024_ids_in_f16_mode(pkg, oracle, full_bytes):
     """BASELINE config 5 input length in the reference's arithmetic: a 1024-id utterance (pinned durations: 2048 frames, 33 s of
     audio) against the oracle in fp16 mode, the windowed vocoder bit-identical to the whole-utterance run, and the bf16 mode

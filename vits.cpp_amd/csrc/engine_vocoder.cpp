@@ -62,6 +62,17 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         const int g_ts = sts[st_out];
         const double n_out = (double)C * (double)ssum[st_out];
         const Ref16 bul16 = R16(s2.bul, C, sts[st_out]), bsum16 = R16(s2.bs16, C, sts[st_out]);
+        // narrow stages: each RESBLOCK as one kernel (rbblock16.hip: the fp32 stream stays in registers across its three pairs; bit-identical
+        // to the pair path). When every resblock of the stage runs that way nobody reads the 16-bit copy of the stage input.
+        bool blockrb[3] = {false, false, false};
+        bool all_block = nk <= 3;
+        for (size_t j = 0; j < nk && j < 3; ++j) {
+            const ResBlockW& R = U.rbs[j];
+            bool f = c.fuse16 && !knobs.no_rbblock16 && rbblock16_supported(C, R.k, R.dil.data(), (int)R.dil.size());
+            for (size_t d = 0; d < R.dil.size() && f; ++d) f = R.c1[d].bias && R.c2[d].bias && R.c1[d].wp16 && R.c2[d].wp16;
+            blockrb[j] = f;
+            all_block = all_block && f;
+        }
         {
             Conv16Call c;
             c.x = cur16;
@@ -76,9 +87,11 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
             c.yg = s2.bu;
             c.g_bs = g_bs;
             c.g_ts = g_ts;
-            c.y16 = bul16;
-            c.y16_slope = hp.lrelu;
-            HIP_OK(conv16("hifigan_upsample_convT", U.up, c, stream, 2.0 * U.up.cin * (double)ssum[st_in] + 6.0 * n_out + (double)U.up.bytes16));
+            if (!all_block) {
+                c.y16 = bul16;
+                c.y16_slope = hp.lrelu;
+            }
+            HIP_OK(conv16("hifigan_upsample_convT", U.up, c, stream, 2.0 * U.up.cin * (double)ssum[st_in] + (all_block ? 4.0 : 6.0) * n_out + (double)U.up.bytes16));
         }
         const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on;
         if (par) {
@@ -96,6 +109,47 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
             // pair must never write the 16-bit stream it reads: the pairs of a resblock ping-pong between the two 16-bit buffers
             // the two-kernel path uses for the stream and for t. (All pairs of the resblock fuse, or none: a two-kernel pair needs
             // the second buffer for its t.)
+            if (j < 3 && blockrb[j]) {
+                const PackedConv* w1[3] = {&R.c1[0], &R.c1[1], &R.c1[2]};
+                const PackedConv* w2[3] = {&R.c2[0], &R.c2[1], &R.c2[2]};
+                RbBlock16Call f;
+                f.y0 = s2.bu;
+                f.lens = d_len[st_out];
+                f.batch = B;
+                f.tmax = smax[st_out];
+                f.slope = hp.lrelu;
+                f.yg = s2.bs;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635), as the last pair of the pair path
+                f.g_bs = g_bs;
+                f.g_ts = g_ts;
+                double bytes = (4.0 + 4.0) * n_out;
+                if (j > 0) {
+                    f.accg = s2.bs;
+                    bytes += 4.0 * n_out;
+                }
+                if (j + 1 == nk) {
+                    if (refmode) {
+                        f.scale = (float)(1.0 / (double)nk);
+                        f.scale_div = 0;
+                    } else {
+                        f.scale = (float)nk;
+                        f.scale_div = 1;
+                    }
+                    f.y16 = bsum16;
+                    f.y16_slope = i + 1 < n_up ? hp.lrelu : final_slope;
+                    bytes += 2.0 * n_out;
+                }
+                if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));  // (the accumulation is inside the kernel: the resblocks chain)
+                if (prof.on) {
+                    char full[160];
+                    std::snprintf(full, sizeof(full), "hifigan_resblock_block|k%d|d135|B%d|e0g|c%dx%d", R.k, C, C, C);
+                    for (size_t d = 0; d < nd; ++d) bytes += (double)R.c1[d].bytes16 + (double)R.c2[d].bytes16;
+                    prof.begin(full, 3.0 * 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], bytes, sj, true);
+                }
+                HIP_OK(launch_rbblock16(w1, w2, f, arith_now_, sj));
+                prof.end(sj);
+                if (par) HIP_OK(hipEventRecord(ev_done_[j], sj));
+                continue;
+            }
             bool fuse_rb = c.fuse16;
             for (size_t d = 0; d < nd; ++d) fuse_rb = fuse_rb && rbpair16_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
             for (size_t d = 0; d < nd; ++d) {

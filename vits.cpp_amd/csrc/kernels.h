@@ -129,6 +129,24 @@ struct RbPair16Call {
     int scale_div = 0;
 };
 bool rbpair16_supported(int channels, int kt, int dil);
+// One whole ResBlock (three pairs, dilations 1 / 3 / 5) as a single kernel (rbblock16.hip): the fp32 stream stays in registers across the
+// pairs, HBM sees the stage input once and the resblock output once. C = 32 / 64, k = 3 / 7 / 11.
+struct RbBlock16Call {
+    const float* y0 = nullptr;  // stage input, fp32 group layout [b][C/8][g_ts][8]
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0;
+    float slope = 0.1f;
+    float* yg = nullptr;  // output (same strides as y0)
+    const float* accg = nullptr;
+    int64_t g_bs = 0;
+    int g_ts = 0;
+    Ref16 y16;
+    float y16_slope = 1.f;
+    float scale = 1.f;
+    int scale_div = 0;
+};
+bool rbblock16_supported(int channels, int kt, const int* dils, int ndil);
+hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s);
 // fp32 ResBlock conv pair as one kernel (rbpair32.hip): y = x + conv2(leaky_relu(conv1(leaky_relu(x)) + b1)) + b2; y must not alias x
 struct RbPair32Call {
     TensorRef x, y, acc;

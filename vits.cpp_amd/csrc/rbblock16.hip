@@ -1,0 +1,361 @@
+// rbblock16.hip — one WHOLE HiFiGAN ResBlock (three conv pairs, dilations D0 / D1 / D2) as a single kernel, 16-bit-operand modes, the
+// narrow vocoder stages (C = 32 / 64):
+//     y_{p+1} = y_p + Conv_{k,1}( leaky_relu( Conv_{k,D_p}( leaky_relu(y_p) ) + b1_p ) ) + b2_p ,  p = 0, 1, 2     (/root/reference/src/vits.cpp:545-581)
+//     out     = [sum of the previous resblocks +] y_3 [ * 1/num_kernels ]                                             (vits.cpp:622-635)
+// Why: in the 16-bit modes these stages are bound by HBM bytes (and, through the power budget, by the clock those bytes leave the matrix
+// cores: tools/rb16_micro.hip — a C = 64, k = 3 pair takes 0.29 ms, 0.085 ms without its epilogue's traffic). As three fused pairs
+// (rbpair16.hip) a resblock moves 3 x 12 B per element: every pair reads the 16-bit input and the fp32 residual and writes the fp32 stream
+// and its 16-bit copy. Here the fp32 stream lives in REGISTERS across the three pairs (the MFMA C layout: a wave owns all 32 rows of a row
+// tile for its 96 columns), the 16-bit conv inputs x_p = round(leaky_relu(y_p)) and t_p live in ONE LDS tile that the phases take turns
+// in, and HBM sees the stage input once (4 B, + halo) and the resblock output once (4 B, + 4 B accumulator, + 2 B 16-bit copy on the last
+// resblock): 10-14 B per element and resblock instead of 36. The price is the halo: a tile of W = 384 columns yields W - 24 (k - 1) / 2
+// outputs (k = 3: 360, 7: 312, 11: 264), i.e. 1.07 / 1.23 / 1.45 x the MFMA work, which these stages have to spare.
+// Same operands, rounding points and k-order of accumulation (chunk, tap, k-half) as rbpair16_kernel / conv16_kernel: bit-identical to
+// the pair path (GPU test), which stays for C >= 128 (MFMA-bound: the halo would cost more than the bytes) and behind VITS_NO_RBBLOCK16=1.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+
+#include "../../include/vits.h"
+#include "kernels.h"
+
+namespace vits {
+
+namespace rbb {
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+
+template <bool BF>
+__device__ __forceinline__ unsigned pack16(float a, float b) {
+    float2v f = {a, b};
+    if constexpr (BF) return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2v));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, half2v));
+}
+}  // namespace rbb
+
+struct RbBlockParams {
+    const float* y0;  // stage input (the fp32 stream), group layout [b][C/8][g_ts][8]
+    const uint16_t* w1[3];
+    const uint16_t* w2[3];  // A fragments of the six convs (pack_conv_weights16)
+    const float* b1[3];
+    const float* b2[3];
+    const int* lens;
+    int tmax;
+    float slope;  // leaky_relu in front of every conv
+    float* yg;    // output, fp32 group layout (same strides as y0)
+    const float* accg;
+    int64_t g_bs;
+    int g_ts;
+    uint16_t* y16;
+    int64_t y16_bs;
+    int y16_ts;
+    float y16_slope;
+    float scale;
+    int scale_div;
+};
+
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/rb16_micro.hip)
+__device__ unsigned long long vits_rbb_phase[16 * 65536];
+#define RBB_STAMP(k)                                                                                            \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;                                           \
+            if (lin < 65536) vits_rbb_phase[16 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                 \
+        }                                                                                                       \
+    } while (0)
+#else
+#define RBB_STAMP(k)
+#endif
+
+// Block = NSTRIP column strips x C/32 row tiles of waves; wave (strip, rt) owns rows [32 rt, 32 rt + 32) of the NRW 32-column tiles of its strip.
+template <int KT, int C, int NSTRIP, int NRW, int D0, int D1, int D2, bool BF>
+__global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (NRW <= 3 ? 3 : 2) : 1) void rbblock16_kernel(const RbBlockParams p) {
+    using namespace rbb;
+    constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
+    constexpr int P2 = (KT - 1) / 2;
+    constexpr int DMAX = D0 > D1 ? (D0 > D2 ? D0 : D2) : (D1 > D2 ? D1 : D2);
+    constexpr int H = P2 * (3 + D0 + D1 + D2);  // halo per side: every pair costs P2 (second conv) + P2 * D_p (first conv)
+    constexpr int BO = W - 2 * H;               // output columns per block
+    constexpr int PADX = P2 * DMAX;             // the first conv of a pair reads up to P2 * D_p columns beyond a tile column
+    constexpr int PITCH = (W + 2 * PADX + 7) / 8 * 8;
+    constexpr int STEPS = 2 * KT, TOTAL = NCH * STEPS;
+    static_assert(BO > 0, "tile too narrow for this kernel size");
+    extern __shared__ __attribute__((aligned(16))) int4v tile[];  // [G][PITCH] slots of 8 x 16 bit: x_p, then t_p, then x_{p+1}, ...
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int strip = wid % NSTRIP, rt = wid / NSTRIP;
+    const int b = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    const int t0 = blockIdx.x * BO;
+    if (t0 >= len) return;
+    RBB_STAMP(0);
+    const int h = lane >> 5, col = lane & 31;
+    const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
+    const int tg0 = t0 - H;                   // global time of tile column 0
+    typedef const __attribute__((address_space(3))) int4v* LdsV;
+    typedef __attribute__((address_space(3))) int2v* LdsW;
+
+    // ---- the fp32 stream of this wave's rows x columns, in the MFMA C layout: register 4 g + e of yv[nr] = channel 32 rt + 8 g + 4 h + e ----
+    floatx16 yv[NRW];
+    {
+        const float* yb = p.y0 + (int64_t)b * p.g_bs;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = rt * 32 + 8 * g + 4 * h;
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) {
+                const int t = tg0 + u0 + 32 * nr;
+                float4v v = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < len) v = *reinterpret_cast<const float4v*>(yb + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[nr][4 * g + e] = v[e];
+            }
+        }
+    }
+    // x = round(leaky_relu(y)) of this wave's rows x columns into the LDS tile, zero outside the sequence (what a conv sees as padding)
+    auto write_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) {
+                const int u = u0 + 32 * nr, t = tg0 + u;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = yv[nr][4 * g + e];
+                    v[e] = fmaxf(v[e], v[e] * p.slope);
+                    if (t < 0 || t >= len) v[e] = 0.f;
+                }
+                int2v w2;
+                w2.x = (int)pack16<BF>(v[0], v[1]);
+                w2.y = (int)pack16<BF>(v[2], v[3]);
+                *((LdsW)(tile + (rt * 4 + g) * PITCH + PADX + u) + h) = w2;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    auto mfma = [&](int4v a, int4v bq, floatx16 c) __attribute__((always_inline)) -> floatx16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, bq), c, 0, 0, 0);
+    };
+    floatx16 acc[NRW];
+    // one conv over the LDS tile: output column u reads slots u + off0 + j * dstep; acc = sum over (chunk, tap, k-half) — the order of
+    // rbpair16_kernel / conv16_kernel
+    auto conv = [&](const uint16_t* wp, const int off0, const int dstep) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NRW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        LdsV base = (LdsV)(tile + h * PITCH + PADX + u0 + off0);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+        const int wvoff = (int)(((size_t)rt * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int step) __attribute__((always_inline)) -> int4v {
+            return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, step * 1024, 0));
+        };
+        constexpr int RS = 8, RD = RS - 2;  // weight-fragment ring: a step is three 32-cycle MFMAs, an L2 round trip several steps
+        int4v ring[RS];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) ring[i] = load_a(i < TOTAL ? i : TOTAL - 1);
+        auto boff = [&](int S) __attribute__((always_inline)) -> int {  // slot offset of step S (compile time after unrolling)
+            const int c = S / STEPS, sl = S % STEPS;
+            return c * 4 * PITCH + ((sl & 1) ? 2 * PITCH : 0) + (sl >> 1) * dstep;
+        };
+        int4v b_nxt[NRW];
+#pragma unroll
+        for (int nr = 0; nr < NRW; ++nr) b_nxt[nr] = base[boff(0) + nr * 32];
+#pragma unroll
+        for (int s = 0; s < TOTAL; ++s) {
+            ring[(s + RD) % RS] = load_a(s + RD < TOTAL ? s + RD : TOTAL - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            int4v b_cur[NRW];
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) b_cur[nr] = b_nxt[nr];
+            {
+                const int ns = s + 1 < TOTAL ? s + 1 : TOTAL - 1;
+#pragma unroll
+                for (int nr = 0; nr < NRW; ++nr) b_nxt[nr] = base[boff(ns) + nr * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) acc[nr] = mfma(ring[s % RS], b_cur[nr], acc[nr]);
+        }
+    };
+
+    auto pair = [&](const int pi, const int dil, const bool last) __attribute__((always_inline)) {
+        // conv 1 over x_p: t column u reads x columns u - P2 dil + j dil
+        conv(p.w1[pi], -P2 * dil, dil);
+        __syncthreads();  // every wave is done with x_p: t_p takes its place
+        // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = rt * 32 + 8 * g + 4 * h;
+            const float4v bias = *reinterpret_cast<const float4v*>(p.b1[pi] + ch0);
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) {
+                const int u = u0 + 32 * nr, t = tg0 + u;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[nr][4 * g + e] + bias[e];
+                    v[e] = fmaxf(v[e], v[e] * p.slope);
+                    if (t < 0 || t >= len) v[e] = 0.f;
+                }
+                int2v w2;
+                w2.x = (int)pack16<BF>(v[0], v[1]);
+                w2.y = (int)pack16<BF>(v[2], v[3]);
+                *((LdsW)(tile + (rt * 4 + g) * PITCH + PADX + u) + h) = w2;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // conv 2 over t_p: y column u reads t columns u - P2 + j
+        conv(p.w2[pi], -P2, 1);
+        // the stream: y_{p+1} = y_p + (conv2 + b2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = rt * 32 + 8 * g + 4 * h;
+            const float4v bias = *reinterpret_cast<const float4v*>(p.b2[pi] + ch0);
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[nr][4 * g + e] + bias[e];
+                    yv[nr][4 * g + e] = yv[nr][4 * g + e] + v;
+                }
+        }
+        if (!last) {
+            __syncthreads();  // every wave is done with t_p: x_{p+1} takes its place
+            write_x();
+            __syncthreads();
+        }
+    };
+
+    write_x();
+    __syncthreads();
+    RBB_STAMP(1);
+    pair(0, D0, false);
+    RBB_STAMP(2);
+    pair(1, D1, false);
+    RBB_STAMP(3);
+    pair(2, D2, true);
+    RBB_STAMP(4);
+
+    // ---- epilogue (as the last pair's in rbpair16_kernel): resblock sum / scale, fp32 output + 16-bit copy, the BO owned columns only ----
+    {
+        float* yg = p.yg + (int64_t)b * p.g_bs;
+        const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
+        uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = rt * 32 + 8 * g + 4 * h;
+#pragma unroll
+            for (int nr = 0; nr < NRW; ++nr) {
+                const int u = u0 + 32 * nr, t = tg0 + u;
+                if (u < H || u >= H + BO || t >= len) continue;
+                const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = yv[nr][4 * g + e];
+                if (ag) {
+                    const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = a4[e] + v[e];
+                        v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
+                    }
+                }
+                *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+                if (y16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
+                    int2v w2;
+                    w2.x = (int)pack16<BF>(v[0], v[1]);
+                    w2.y = (int)pack16<BF>(v[2], v[3]);
+                    *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
+                }
+            }
+        }
+    }
+    RBB_STAMP(5);
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+template <int KT, int C, int NSTRIP, int NRW, bool BF>
+static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
+    constexpr int D0 = 1, D1 = 3, D2 = 5;
+    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
+    const size_t lds = (size_t)(C / 8) * PITCH * 16;
+    static std::atomic<bool> big_lds_set{false};
+    if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        big_lds_set.store(true, std::memory_order_release);
+    }
+    dim3 grid((p.tmax + BO - 1) / BO, batch);
+    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, D0, D1, D2, BF>), grid, dim3(C / 32 * NSTRIP * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+bool rbblock16_supported(int channels, int kt, const int* dils, int ndil) {
+    if (!(channels == 32 || channels == 64) || !(kt == 3 || kt == 7 || kt == 11)) return false;
+    // C = 64, k = 11: with 1.45 x the MFMA work the whole-resblock kernel is bound by the matrix cores (at the clock the power budget
+    // leaves them) and loses to three fused pairs, 1.59 against 1.45 ms per step (batch 64 x 128 ids); VITS_RBB_C64K11=1 runs it anyway
+    static const bool c64k11 = getenv("VITS_RBB_C64K11") != nullptr;
+    if (channels == 64 && kt == 11 && !c64k11) return false;
+    return ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
+}
+
+hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s) {
+    const int C = c1[0]->cin, kt = c1[0]->kt;
+    RbBlockParams p;
+    for (int i = 0; i < 3; ++i) {
+        if (!c1[i]->wp16 || !c2[i]->wp16 || !c1[i]->bias || !c2[i]->bias || c1[i]->cin != C || c1[i]->cout != C || c2[i]->cin != C || c2[i]->cout != C || c1[i]->kt != kt ||
+            c2[i]->kt != kt)
+            return hipErrorInvalidValue;
+        p.w1[i] = c1[i]->wp16;
+        p.w2[i] = c2[i]->wp16;
+        p.b1[i] = c1[i]->bias;
+        p.b2[i] = c2[i]->bias;
+    }
+    const int dils[3] = {1, 3, 5};
+    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || !c.yg) return hipErrorInvalidValue;
+    p.y0 = c.y0;
+    p.lens = c.lens;
+    p.tmax = c.tmax;
+    p.slope = c.slope;
+    p.yg = c.yg;
+    p.accg = c.accg;
+    p.g_bs = c.g_bs;
+    p.g_ts = c.g_ts;
+    p.y16 = c.y16.p;
+    p.y16_bs = c.y16.bs;
+    p.y16_ts = c.y16.ts;
+    p.y16_slope = c.y16_slope;
+    p.scale = c.scale;
+    p.scale_div = c.scale_div;
+    const bool bf = arith == VITS_ARITH_BF16;
+    // tile shape (column strips x 32-column tiles per wave): 4 x 3 = 384 columns. Measured alternatives (batch 64 x 128 ids, f16): C = 32 with
+    // 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 6 x 2 (twelve waves) +-0, as 8 x 2 = 512 columns
+    // (sixteen waves at 128 VGPRs, spills) -5 % on k = 11 only.
+#define VITS_RBB_GO(K, CC, NS, NRW_)                                                              \
+    if (kt == K && C == CC) return bf ? launch_rbb<K, CC, NS, NRW_, true>(p, c.batch, s) : launch_rbb<K, CC, NS, NRW_, false>(p, c.batch, s)
+    VITS_RBB_GO(3, 32, 4, 3);
+    VITS_RBB_GO(7, 32, 4, 3);
+    VITS_RBB_GO(11, 32, 4, 3);
+    VITS_RBB_GO(3, 64, 4, 3);
+    VITS_RBB_GO(7, 64, 4, 3);
+    VITS_RBB_GO(11, 64, 4, 3);
+#undef VITS_RBB_GO
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vits
