@@ -40,6 +40,15 @@ __device__ __forceinline__ unsigned pack16(float a, float b) {
     if constexpr (BF) return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2v));
     else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, half2v));
 }
+// Two 8-byte halves of two 16-byte slots per lane -> one whole slot per lane. In the MFMA C layout lane l < 32 holds channels 0-3 and lane
+// l + 32 channels 4-7 of a channel group at one column; writing them as two ds_write_b64 at a 16-byte stride is a 4-way bank conflict
+// (PMC: 0.08-0.20 of the LDS cycles of the pair kernels). v_permlane32_swap exchanges the upper half of one register with the lower half of
+// another: given groups g0 (a) and g1 (b), lanes < 32 end up with the whole slot of g0 and lanes >= 32 with the whole slot of g1.
+__device__ __forceinline__ int4v slot_pair(int2v a, int2v b) {
+    const auto x = __builtin_amdgcn_permlane32_swap((unsigned)a.x, (unsigned)b.x, false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap((unsigned)a.y, (unsigned)b.y, false, false);
+    return int4v{(int)x[0], (int)y[0], (int)x[1], (int)y[1]};
+}
 }  // namespace rbb
 
 struct RbBlockParams {
@@ -102,7 +111,6 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
     const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
     const int tg0 = t0 - H;                   // global time of tile column 0
     typedef const __attribute__((address_space(3))) int4v* LdsV;
-    typedef __attribute__((address_space(3))) int2v* LdsW;
 
     // ---- the fp32 stream of this wave's rows x columns, in the MFMA C layout: register 4 g + e of yv[nr] = channel 32 rt + 8 g + 4 h + e ----
     floatx16 yv[NRW];
@@ -122,12 +130,14 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         }
     }
     // x = round(leaky_relu(y)) of this wave's rows x columns into the LDS tile, zero outside the sequence (what a conv sees as padding)
+    typedef __attribute__((address_space(3))) int4v* LdsS;
     auto write_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int nr = 0; nr < NRW; ++nr) {
+            const int u = u0 + 32 * nr, t = tg0 + u;
+            int2v w[4];
 #pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) {
-                const int u = u0 + 32 * nr, t = tg0 + u;
+            for (int g = 0; g < 4; ++g) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -135,11 +145,12 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
                     v[e] = fmaxf(v[e], v[e] * p.slope);
                     if (t < 0 || t >= len) v[e] = 0.f;
                 }
-                int2v w2;
-                w2.x = (int)pack16<BF>(v[0], v[1]);
-                w2.y = (int)pack16<BF>(v[2], v[3]);
-                *((LdsW)(tile + (rt * 4 + g) * PITCH + PADX + u) + h) = w2;
+                w[g].x = (int)pack16<BF>(v[0], v[1]);
+                w[g].y = (int)pack16<BF>(v[2], v[3]);
             }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *((LdsS)(tile + (rt * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[2 * k], w[2 * k + 1]);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
@@ -195,24 +206,28 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         conv(p.w1[pi], -P2 * dil, dil);
         __syncthreads();  // every wave is done with x_p: t_p takes its place
         // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
+        {
+            float4v bias[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = rt * 32 + 8 * g + 4 * h;
-            const float4v bias = *reinterpret_cast<const float4v*>(p.b1[pi] + ch0);
+            for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const float4v*>(p.b1[pi] + rt * 32 + 8 * g + 4 * h);
 #pragma unroll
             for (int nr = 0; nr < NRW; ++nr) {
                 const int u = u0 + 32 * nr, t = tg0 + u;
-                float v[4];
+                int2v w[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[nr][4 * g + e] + bias[e];
-                    v[e] = fmaxf(v[e], v[e] * p.slope);
-                    if (t < 0 || t >= len) v[e] = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[nr][4 * g + e] + bias[g][e];
+                        v[e] = fmaxf(v[e], v[e] * p.slope);
+                        if (t < 0 || t >= len) v[e] = 0.f;
+                    }
+                    w[g].x = (int)pack16<BF>(v[0], v[1]);
+                    w[g].y = (int)pack16<BF>(v[2], v[3]);
                 }
-                int2v w2;
-                w2.x = (int)pack16<BF>(v[0], v[1]);
-                w2.y = (int)pack16<BF>(v[2], v[3]);
-                *((LdsW)(tile + (rt * 4 + g) * PITCH + PADX + u) + h) = w2;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) *((LdsS)(tile + (rt * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[2 * k], w[2 * k + 1]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -238,31 +238,41 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
     if constexpr (ALIAS) __syncthreads();  // every wave is done with the x tile: t takes its place
 
     // ---- phase 2: t = round(leaky_relu(conv1 + b1)), zero outside the sequence, into LDS (group layout) -------------------
+    // (whole 16-byte slots per lane: in the C layout lane l holds channels 0-3 and lane l + 32 channels 4-7 of a group; v_permlane32_swap
+    // trades halves between two groups so that lanes < 32 write one group's slots and lanes >= 32 the other's — two ds_write_b64 at a 16-byte
+    // stride were a 4-way bank conflict, 0.08-0.20 of this kernel's LDS cycles in the round-2 PMC pass)
     {
-        typedef __attribute__((address_space(3))) int2v* LdsW;
+        typedef __attribute__((address_space(3))) int4v* LdsS;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
+        for (int mr = 0; mr < MR; ++mr) {
+            float4v bias[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = (rt0 + mr) * 32 + 8 * g + 4 * h;
-                const float4v bias = *reinterpret_cast<const float4v*>(p.b1 + ch0);
+            for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const float4v*>(p.b1 + (rt0 + mr) * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    const int i = cb + nr * 32 + (lane & 31);
-                    const int tm = t0 - P2 + i;
+            for (int nr = 0; nr < NR; ++nr) {
+                const int i = cb + nr * 32 + (lane & 31);
+                const int tm = t0 - P2 + i;
+                int2v w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mr][nr][4 * g + e] + bias[e];
+                        v[e] = acc[mr][nr][4 * g + e] + bias[g][e];
                         v[e] = fmaxf(v[e], v[e] * p.slope);
                         if (tm < 0 || tm >= len) v[e] = 0.f;  // the second conv's zero padding
                     }
-                    int2v w2;
-                    w2.x = (int)rb_pack16<BF>(v[0], v[1]);
-                    w2.y = (int)rb_pack16<BF>(v[2], v[3]);
-                    *((LdsW)(ts + ((rt0 + mr) * 4 + g) * TW + i) + h) = w2;
+                    w[g].x = (int)rb_pack16<BF>(v[0], v[1]);
+                    w[g].y = (int)rb_pack16<BF>(v[2], v[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const auto x = __builtin_amdgcn_permlane32_swap((unsigned)w[2 * k].x, (unsigned)w[2 * k + 1].x, false, false);
+                    const auto y = __builtin_amdgcn_permlane32_swap((unsigned)w[2 * k].y, (unsigned)w[2 * k + 1].y, false, false);
+                    *((LdsS)(ts + ((rt0 + mr) * 4 + 2 * k + h) * TW + i)) = int4v{(int)x[0], (int)y[0], (int)x[1], (int)y[1]};
                 }
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
