@@ -180,7 +180,8 @@ def test_config5_in_its_own_arithmetic(pkg, oracle):
             d = pcm[0].astype(np.float64) - ref["waveform"]
             rms = np.sqrt((ref["waveform"].astype(np.float64) ** 2).mean())
             print("config 5 model %d bf16: max |d| / RMS = %.3e, RMS(d) / RMS = %.3e" % (k, np.abs(d).max() / rms, np.sqrt((d ** 2).mean()) / rms))
-            assert np.abs(d).max() / rms < 0.16 and np.sqrt((d ** 2).mean()) / rms < 2e-2
+            # (measured: max 3.5e-2 / 4.6e-2, RMS 6.9e-3 / 7.7e-3 on the two models; 8 x the fp16 figures of the test below, as the mantissas)
+            assert np.abs(d).max() / rms < 0.1 and np.sqrt((d ** 2).mean()) / rms < 1.5e-2
             tiled, lt, _ = m.process_batch(ids[k], noise_seed=50 + k, vocoder_chunk_frames=256)
             assert np.array_equal(lt, lengths) and all(np.array_equal(a, b) for a, b in zip(tiled, pcm))
 
