@@ -315,6 +315,30 @@ def test_whole_resblock_kernel_is_bit_identical_to_the_pair_path(pkg, full_bytes
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name", ["f16", "bf16"])
+def test_16bit_kernel_choices_do_not_change_a_single_bit(name):
+    """The 16-bit path has several interchangeable kernels per layer — streaming transposed conv (convt16.hip) or GEMM tile, whole-resblock
+    kernel or fused pairs or two launches per pair, group layout or converter path: same operands, rounding points and k-order, so the PCM
+    of ragged batches (short and 300-id utterances, whole and windowed, both semantics modes) must hash identically whichever runs. One
+    process per setting (the kernel files read their knobs once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "knob_identity.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        env["VITS_KNOB_ARITH"] = name
+        out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-1]
+
+    base = run({})
+    for extra in ({"VITS_NO_CONVT16S": "1"}, {"VITS_NO_CONVT16L": "1"}, {"VITS_CONVT16S_ALL": "1"}, {"VITS_NO_RBBLOCK16": "1"}, {"VITS_RBB_C64K11": "1"}, {"VITS_RBB_C128": "0"},
+                  {"VITS_NO_FUSE16": "1", "VITS_NO_CONVT16S": "1"}, {"VITS_RB_STREAMS": "1"}):
+        assert run(extra) == base, extra
+
+
 def test_long_form_1024_ids_in_f16_mode(pkg, oracle, full_bytes):
     """BASELINE config 5 input length in the reference's arithmetic: a 1024-id utterance (pinned durations: 2048 frames, 33 s of
     audio) against the oracle in fp16 mode, the windowed vocoder bit-identical to the whole-utterance run, and the bf16 mode

@@ -12,6 +12,7 @@ _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+
 _WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
 _RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
+_CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\w+)>")
 _GROUP = re.compile(r"conv_group_kernel<(-?\d+)>")
 _RBPAIR32 = re.compile(r"rbpair32_kernel<(-?\d+), (-?\d+), (\d+)>")
 _RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)(?:, \w+)?>")
@@ -47,6 +48,9 @@ def bench_key(kernel_name):
     if m:  # `rbblock16_kernel<11, 64, 1, 3, 5, false>` -> `k11|d135|B64|e0g`
         kt, c, d0, d1, d2, _ = m.groups()
         return f"k{kt}|d{d0}{d1}{d2}|B{c}|e0g"
+    m = _CONVT16.search(kernel_name)
+    if m:  # `convt16_kernel<4, 1, false>` -> `k2|d-1|S|e2g` (the engine prints the stride behind the S; one rocprof name serves several stages)
+        return "k2|d-1|S|e2g"
     m = _GROUP.search(kernel_name)
     if m:  # `conv_group_kernel<3>` -> `kG|d3|G0|e0` (two or three member convolutions of 11 / 7 / 3 taps per launch, 128 x 128 tile)
         return f"kG|d{m.group(1)}|G0|e0"

@@ -91,7 +91,19 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                 c.y16 = bul16;
                 c.y16_slope = hp.lrelu;
             }
-            HIP_OK(conv16("hifigan_upsample_convT", U.up, c, stream, 2.0 * U.up.cin * (double)ssum[st_in] + (all_block ? 4.0 : 6.0) * n_out + (double)U.up.bytes16));
+            const double ct_bytes = 2.0 * U.up.cin * (double)ssum[st_in] + (all_block ? 4.0 : 6.0) * n_out + (double)U.up.bytes16;
+            if (convt16_stream_supported(U.up)) {
+                // the upsampler as a streaming kernel (convt16.hip: every phase of a tile of input positions in one block; bit-identical)
+                if (prof.on) {
+                    char full[160];
+                    std::snprintf(full, sizeof(full), "hifigan_upsample_convT|k2|d-1|S%d|e2g|c%dx%d", U.stride, U.up.cin, U.up.cout);
+                    prof.begin(full, 2.0 * (double)U.up.rows * (double)U.up.cin * 2.0 * (double)ssum[st_in], ct_bytes, stream, true);
+                }
+                HIP_OK(launch_convt16_stream(U.up, c, arith_now_, stream));
+                prof.end(stream);
+            } else {
+                HIP_OK(conv16("hifigan_upsample_convT", U.up, c, stream, ct_bytes));
+            }
         }
         const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on;
         if (par) {

@@ -174,6 +174,10 @@ hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbP
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);
 int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch);
 hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
+// ConvTranspose1d (kernel = 2 x stride) in the group layout as a streaming kernel (convt16.hip): all stride x c_out rows of a tile of input
+// positions per block; bit-identical to launch_conv16 on the same call
+bool convt16_stream_supported(const PackedConv& w);
+hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
 hipError_t launch_to_group16(TensorRef x, const int* lens, int batch, int channels, int tmax, float slope, Ref16 y, int arith, hipStream_t s);
 hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef pre, TensorRef wave, const int* lens, int batch, int tmax, int arith, hipStream_t s,
                               int emit_lo = 0, const int* emit_hi = nullptr);

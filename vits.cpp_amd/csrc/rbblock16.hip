@@ -85,9 +85,10 @@ __device__ unsigned long long vits_rbb_phase[16 * 65536];
 #define RBB_STAMP(k)
 #endif
 
-// Block = NSTRIP column strips x C/32 row tiles of waves; wave (strip, rt) owns rows [32 rt, 32 rt + 32) of the NRW 32-column tiles of its strip.
-template <int KT, int C, int NSTRIP, int NRW, int D0, int D1, int D2, bool BF>
-__global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (NRW <= 3 ? 3 : 2) : 1) void rbblock16_kernel(const RbBlockParams p) {
+// Block = NSTRIP column strips x C / (32 MRW) row groups of waves; wave (strip, rg) owns the MRW row tiles [MRW rg, MRW rg + MRW) (32 rows each)
+// of the NRW 32-column tiles of its strip.
+template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF>
+__global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : 1) void rbblock16_kernel(const RbBlockParams p) {
     using namespace rbb;
     constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
     constexpr int P2 = (KT - 1) / 2;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
     extern __shared__ __attribute__((aligned(16))) int4v tile[];  // [G][PITCH] slots of 8 x 16 bit: x_p, then t_p, then x_{p+1}, ...
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int strip = wid % NSTRIP, rt = wid / NSTRIP;
+    const int strip = wid % NSTRIP, rt0 = (wid / NSTRIP) * MRW;
     const int b = blockIdx.y;
     const int len = p.lens ? p.lens[b] : p.tmax;
     const int t0 = blockIdx.x * BO;
@@ -112,45 +113,58 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
     const int tg0 = t0 - H;                   // global time of tile column 0
     typedef const __attribute__((address_space(3))) int4v* LdsV;
 
-    // ---- the fp32 stream of this wave's rows x columns, in the MFMA C layout: register 4 g + e of yv[nr] = channel 32 rt + 8 g + 4 h + e ----
-    floatx16 yv[NRW];
+    // ---- the fp32 stream of this wave's rows x columns, in the MFMA C layout: register 4 g + e of yv[m][nr] = channel 32 (rt0 + m) + 8 g + 4 h + e ----
+    floatx16 yv[MRW][NRW];
     {
         const float* yb = p.y0 + (int64_t)b * p.g_bs;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = rt * 32 + 8 * g + 4 * h;
-#pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) {
-                const int t = tg0 + u0 + 32 * nr;
-                float4v v = {0.f, 0.f, 0.f, 0.f};
-                if (t >= 0 && t < len) v = *reinterpret_cast<const float4v*>(yb + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) yv[nr][4 * g + e] = v[e];
-            }
-        }
-    }
-    // x = round(leaky_relu(y)) of this wave's rows x columns into the LDS tile, zero outside the sequence (what a conv sees as padding)
-    typedef __attribute__((address_space(3))) int4v* LdsS;
-    auto write_x = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int nr = 0; nr < NRW; ++nr) {
-            const int u = u0 + 32 * nr, t = tg0 + u;
-            int2v w[4];
+        for (int m = 0; m < MRW; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[4];
+                const int ch0 = (rt0 + m) * 32 + 8 * g + 4 * h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = yv[nr][4 * g + e];
-                    v[e] = fmaxf(v[e], v[e] * p.slope);
-                    if (t < 0 || t >= len) v[e] = 0.f;
+                for (int nr = 0; nr < NRW; ++nr) {
+                    const int t = tg0 + u0 + 32 * nr;
+                    float4v v = {0.f, 0.f, 0.f, 0.f};
+                    if (t >= 0 && t < len) v = *reinterpret_cast<const float4v*>(yb + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[m][nr][4 * g + e] = v[e];
                 }
-                w[g].x = (int)pack16<BF>(v[0], v[1]);
-                w[g].y = (int)pack16<BF>(v[2], v[3]);
             }
+    }
+    // round(leaky_relu(src + bias)) of this wave's rows x columns into the LDS tile as whole 16-byte slots, zero outside the sequence (what a
+    // conv sees as padding): x_p from the stream (bias = nullptr), t_p from the first conv's accumulators
+    typedef __attribute__((address_space(3))) int4v* LdsS;
+    auto write_tile = [&](const floatx16 (&src)[MRW][NRW], const float* bias_p) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) *((LdsS)(tile + (rt * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[2 * k], w[2 * k + 1]);
-        }
+        for (int m = 0; m < MRW; ++m)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {  // channel groups 2k and 2k + 1 of the row tile: one slot each per lane after the half swap
+                float4v bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (bias_p) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bias[q] = *reinterpret_cast<const float4v*>(bias_p + (rt0 + m) * 32 + 8 * (2 * k + q) + 4 * h);
+                }
+#pragma unroll
+                for (int nr = 0; nr < NRW; ++nr) {
+                    const int u = u0 + 32 * nr, t = tg0 + u;
+                    int2v w[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = src[m][nr][4 * (2 * k + q) + e];
+                            if (bias_p) v[e] = v[e] + bias[q][e];
+                            v[e] = fmaxf(v[e], v[e] * p.slope);
+                            if (t < 0 || t >= len) v[e] = 0.f;
+                        }
+                        w[q].x = (int)pack16<BF>(v[0], v[1]);
+                        w[q].y = (int)pack16<BF>(v[2], v[3]);
+                    }
+                    *((LdsS)(tile + ((rt0 + m) * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[0], w[1]);
+                }
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
@@ -158,24 +172,31 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, bq), c, 0, 0, 0);
     };
-    floatx16 acc[NRW];
+    floatx16 acc[MRW][NRW];
     // one conv over the LDS tile: output column u reads slots u + off0 + j * dstep; acc = sum over (chunk, tap, k-half) — the order of
     // rbpair16_kernel / conv16_kernel
     auto conv = [&](const uint16_t* wp, const int off0, const int dstep) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NRW; ++j)
+        for (int m = 0; m < MRW; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int j = 0; j < NRW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         LdsV base = (LdsV)(tile + h * PITCH + PADX + u0 + off0);
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
-        const int wvoff = (int)(((size_t)rt * TOTAL * 64 + lane) * 16);
-        auto load_a = [&](int step) __attribute__((always_inline)) -> int4v {
-            return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, step * 1024, 0));
-        };
-        constexpr int RS = 8, RD = RS - 2;  // weight-fragment ring: a step is three 32-cycle MFMAs, an L2 round trip several steps
-        int4v ring[RS];
+        int wvoff[MRW];
 #pragma unroll
-        for (int i = 0; i < RD; ++i) ring[i] = load_a(i < TOTAL ? i : TOTAL - 1);
+        for (int m = 0; m < MRW; ++m) wvoff[m] = (int)(((size_t)(rt0 + m) * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int m, int step) __attribute__((always_inline)) -> int4v {
+            return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
+        };
+        // weight-fragment ring: a step is NRW 32-cycle MFMAs per row tile, an L2 round trip several steps (C = 32, k >= 7: six slots — eight spill at the 168-VGPR cap of three blocks per CU)
+        constexpr int RS = MRW == 1 ? ((C == 32 && KT > 3) ? 6 : 8) : 4, RD = RS - 2;
+        int4v ring[RS][MRW];
+#pragma unroll
+        for (int i = 0; i < RD; ++i)
+#pragma unroll
+            for (int m = 0; m < MRW; ++m) ring[i][m] = load_a(m, i < TOTAL ? i : TOTAL - 1);
         auto boff = [&](int S) __attribute__((always_inline)) -> int {  // slot offset of step S (compile time after unrolling)
             const int c = S / STEPS, sl = S % STEPS;
             return c * 4 * PITCH + ((sl & 1) ? 2 * PITCH : 0) + (sl >> 1) * dstep;
@@ -185,7 +206,8 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         for (int nr = 0; nr < NRW; ++nr) b_nxt[nr] = base[boff(0) + nr * 32];
 #pragma unroll
         for (int s = 0; s < TOTAL; ++s) {
-            ring[(s + RD) % RS] = load_a(s + RD < TOTAL ? s + RD : TOTAL - 1);
+#pragma unroll
+            for (int m = 0; m < MRW; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
             __builtin_amdgcn_sched_barrier(0);
             int4v b_cur[NRW];
 #pragma unroll
@@ -197,7 +219,9 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) acc[nr] = mfma(ring[s % RS], b_cur[nr], acc[nr]);
+            for (int m = 0; m < MRW; ++m)
+#pragma unroll
+                for (int nr = 0; nr < NRW; ++nr) acc[m][nr] = mfma(ring[s % RS][m], b_cur[nr], acc[m][nr]);
         }
     };
 
@@ -205,56 +229,33 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         // conv 1 over x_p: t column u reads x columns u - P2 dil + j dil
         conv(p.w1[pi], -P2 * dil, dil);
         __syncthreads();  // every wave is done with x_p: t_p takes its place
-        // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
-        {
-            float4v bias[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const float4v*>(p.b1[pi] + rt * 32 + 8 * g + 4 * h);
-#pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) {
-                const int u = u0 + 32 * nr, t = tg0 + u;
-                int2v w[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[nr][4 * g + e] + bias[g][e];
-                        v[e] = fmaxf(v[e], v[e] * p.slope);
-                        if (t < 0 || t >= len) v[e] = 0.f;
-                    }
-                    w[g].x = (int)pack16<BF>(v[0], v[1]);
-                    w[g].y = (int)pack16<BF>(v[2], v[3]);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) *((LdsS)(tile + (rt * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[2 * k], w[2 * k + 1]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        write_tile(acc, p.b1[pi]);  // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
         __syncthreads();
         // conv 2 over t_p: y column u reads t columns u - P2 + j
         conv(p.w2[pi], -P2, 1);
         // the stream: y_{p+1} = y_p + (conv2 + b2)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = rt * 32 + 8 * g + 4 * h;
-            const float4v bias = *reinterpret_cast<const float4v*>(p.b2[pi] + ch0);
+        for (int m = 0; m < MRW; ++m)
 #pragma unroll
-            for (int nr = 0; nr < NRW; ++nr)
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = (rt0 + m) * 32 + 8 * g + 4 * h;
+                const float4v bias = *reinterpret_cast<const float4v*>(p.b2[pi] + ch0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[nr][4 * g + e] + bias[e];
-                    yv[nr][4 * g + e] = yv[nr][4 * g + e] + v;
-                }
-        }
+                for (int nr = 0; nr < NRW; ++nr)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[m][nr][4 * g + e] + bias[e];
+                        yv[m][nr][4 * g + e] = yv[m][nr][4 * g + e] + v;
+                    }
+            }
         if (!last) {
             __syncthreads();  // every wave is done with t_p: x_{p+1} takes its place
-            write_x();
+            write_tile(yv, nullptr);
             __syncthreads();
         }
     };
 
-    write_x();
+    write_tile(yv, nullptr);
     __syncthreads();
     RBB_STAMP(1);
     pair(0, D0, false);
@@ -270,57 +271,61 @@ __global__ __launch_bounds__(C / 32 * NSTRIP * 64, (C == 32 && NSTRIP == 4) ? (N
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = rt * 32 + 8 * g + 4 * h;
+        for (int m = 0; m < MRW; ++m)
 #pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) {
-                const int u = u0 + 32 * nr, t = tg0 + u;
-                if (u < H || u >= H + BO || t >= len) continue;
-                const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
-                float v[4];
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = (rt0 + m) * 32 + 8 * g + 4 * h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = yv[nr][4 * g + e];
-                if (ag) {
-                    const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
+                for (int nr = 0; nr < NRW; ++nr) {
+                    const int u = u0 + 32 * nr, t = tg0 + u;
+                    if (u < H || u >= H + BO || t >= len) continue;
+                    const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = a4[e] + v[e];
-                        v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
+                    for (int e = 0; e < 4; ++e) v[e] = yv[m][nr][4 * g + e];
+                    if (ag) {
+                        const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = a4[e] + v[e];
+                            v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
+                        }
+                    }
+                    *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+                    if (y16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
+                        int2v w2;
+                        w2.x = (int)pack16<BF>(v[0], v[1]);
+                        w2.y = (int)pack16<BF>(v[2], v[3]);
+                        *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
                     }
                 }
-                *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
-                if (y16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
-                    int2v w2;
-                    w2.x = (int)pack16<BF>(v[0], v[1]);
-                    w2.y = (int)pack16<BF>(v[2], v[3]);
-                    *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
-                }
             }
-        }
     }
     RBB_STAMP(5);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-template <int KT, int C, int NSTRIP, int NRW, bool BF>
+template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
 static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
     constexpr int D0 = 1, D1 = 3, D2 = 5;
     constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
     const size_t lds = (size_t)(C / 8) * PITCH * 16;
     static std::atomic<bool> big_lds_set{false};
     if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, D0, D1, D2, BF>), grid, dim3(C / 32 * NSTRIP * 64), lds, s, p);
+    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
     return hipGetLastError();
 }
 
 bool rbblock16_supported(int channels, int kt, const int* dils, int ndil) {
+    static const bool c128 = getenv("VITS_RBB_C128") ? atoi(getenv("VITS_RBB_C128")) != 0 : true;
+    if (channels == 128) return c128 && kt == 3 && ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
     if (!(channels == 32 || channels == 64) || !(kt == 3 || kt == 7 || kt == 11)) return false;
     // C = 64, k = 11: with 1.45 x the MFMA work the whole-resblock kernel is bound by the matrix cores (at the clock the power budget
     // leaves them) and loses to three fused pairs, 1.59 against 1.45 ms per step (batch 64 x 128 ids); VITS_RBB_C64K11=1 runs it anyway
@@ -361,14 +366,16 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
     // tile shape (column strips x 32-column tiles per wave): 4 x 3 = 384 columns. Measured alternatives (batch 64 x 128 ids, f16): C = 32 with
     // 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 6 x 2 (twelve waves) +-0, as 8 x 2 = 512 columns
     // (sixteen waves at 128 VGPRs, spills) -5 % on k = 11 only.
-#define VITS_RBB_GO(K, CC, NS, NRW_)                                                              \
-    if (kt == K && C == CC) return bf ? launch_rbb<K, CC, NS, NRW_, true>(p, c.batch, s) : launch_rbb<K, CC, NS, NRW_, false>(p, c.batch, s)
-    VITS_RBB_GO(3, 32, 4, 3);
-    VITS_RBB_GO(7, 32, 4, 3);
-    VITS_RBB_GO(11, 32, 4, 3);
-    VITS_RBB_GO(3, 64, 4, 3);
-    VITS_RBB_GO(7, 64, 4, 3);
-    VITS_RBB_GO(11, 64, 4, 3);
+#define VITS_RBB_GO(K, CC, NS, NRW_, MRW_)                                                              \
+    if (kt == K && C == CC) return bf ? launch_rbb<K, CC, NS, NRW_, MRW_, true>(p, c.batch, s) : launch_rbb<K, CC, NS, NRW_, MRW_, false>(p, c.batch, s)
+    VITS_RBB_GO(3, 32, 4, 3, 1);
+    VITS_RBB_GO(7, 32, 4, 3, 1);
+    VITS_RBB_GO(11, 32, 4, 3, 1);
+    VITS_RBB_GO(3, 64, 4, 3, 1);
+    VITS_RBB_GO(7, 64, 4, 3, 1);
+    VITS_RBB_GO(11, 64, 4, 3, 1);
+    // C = 128, k = 3: the pairs are HBM-bound (4.4 TB/s); eight waves of two row tiles x two column tiles (256-column tiles, 232 outputs)
+    VITS_RBB_GO(3, 128, 4, 2, 2);
 #undef VITS_RBB_GO
     return hipErrorInvalidValue;
 }
