@@ -190,43 +190,44 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int i = 0; i < RD; ++i) ring[i][mr] = load_a(mr, i < TOTAL ? i : TOTAL - 1);
-        // B operands come from LDS PD steps ahead of their MFMAs (a ring of PD + 1 register sets). Measured (tools/rb16_micro.hip, C = 128,
-        // k = 11 / 3): PD = 2 / 3 and a deeper residual ring in the epilogue are +-0 — the pair is not latency-bound: the matrix pipes are
-        // 83-98 % busy at the shader clock the power budget leaves (1.1 GHz in the conv phases with the epilogue's HBM traffic beside them,
-        // 1.24 GHz without it; a register-only fp16 MFMA loop sustains 1.93 GHz, tools/mfma16_peak.hip). DESIGN.md section 4.3.
-#ifndef VITS_RB16_PD
-#define VITS_RB16_PD 1
-#endif
-        constexpr int PD = VITS_RB16_PD;
-        auto boff = [&](int G) __attribute__((always_inline)) -> int {  // slot offset of global step G (compile time after unrolling)
-            const int c = G / STEPS, sl = G % STEPS;
-            return c * 4 * pitch + ((sl & 1) ? 2 * pitch : 0) + (sl >> 1) * dstep;
-        };
-        int4v bq[PD + 1][NR];
+        // (Measured with tools/rb16_micro.hip, C = 128, k = 11 / 3: operands fetched 2-3 steps ahead instead of one, or a deeper residual ring in
+        // the epilogue, are +-0 — the pair is not latency-bound: the matrix pipes are 83-98 % busy at the shader clock the power budget leaves,
+        // 1.1 GHz in the conv phases with the epilogue's HBM traffic beside them, 1.24 GHz without it; a register-only fp16 MFMA loop sustains
+        // 1.93 GHz, tools/mfma16_peak.hip; DESIGN.md section 4.3. A flat fully unrolled step loop with absolute operand offsets instead of
+        // the chunk / tap / k-half nest below compiled to 162 instead of 129 VGPRs at C = 256, k = 11, d = 5 and ran 0.58 instead of 0.33 ms.)
 #pragma unroll
-        for (int i = 0; i < PD; ++i)
+        for (int c = 0; c < NCH; ++c) {
+            LdsV xb = base + c * 4 * pitch;
+            int4v b_nxt[NR];
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) bq[i][nr] = base[boff(i < TOTAL ? i : TOTAL - 1) + nr * 32];
+            for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[nr * 32];
 #pragma unroll
-        for (int s = 0; s < TOTAL; ++s) {
-            {
-                const int nstep = s + RD < TOTAL ? s + RD : TOTAL - 1;
+            for (int j = 0; j < KT; ++j)
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) ring[(s + RD) % RS][mr] = load_a(mr, nstep);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int ns = s + PD < TOTAL ? s + PD : TOTAL - 1;  // (past the end: a valid slot, value unused)
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int s = c * STEPS + j * 2 + kk;  // compile time after unrolling
+                    {
+                        const int nstep = s + RD < TOTAL ? s + RD : TOTAL - 1;
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) ring[(s + RD) % RS][mr] = load_a(mr, nstep);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    int4v b_cur[NR];
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
+                    {
+                        const int noff = kk == 0 ? 2 * pitch + j * dstep : (j + 1) * dstep;
 #ifndef VAR_NOB  // (ablations of tools/rb16_micro.hip: VAR_NOB / VAR_NOEPI drop the LDS operand reads / the epilogue)
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) bq[(s + PD) % (PD + 1)][nr] = base[boff(ns) + nr * 32];
+                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[noff + nr * 32];
 #endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
+                    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s % RS][mr], bq[s % (PD + 1)][nr], acc[mr][nr]);
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = mfma(ring[s % RS][mr], b_cur[nr], acc[mr][nr]);
+                }
         }
     };
 
