@@ -48,6 +48,17 @@ def test_bad_inputs_return_null_with_message(pkg):
     assert "failed to open file" in pkg.last_error()  # message of the reference (vits_model_data.cpp:102)
 
 
+def test_arith_and_scope_setters_reject_bad_arguments_without_a_model(pkg):
+    """The mode / arithmetic / scope setters of include/vits.h never dereference a NULL handle and never accept an unknown value: -1 and a
+    message, nothing crosses the boundary (the reference's API has no such setters: /root/reference/src/include/vits.h:87-102)."""
+    L = pkg.lib()
+    assert L.vits_model_set_arith_scope(None, pkg.SCOPE_ALL_CONVS) == -1 and "scope" in pkg.last_error()
+    assert L.vits_model_get_arith_scope(None) == -1
+    assert L.vits_model_set_arith(None, pkg.ARITH_F16) == -1
+    assert L.vits_model_get_arith(None) == -1
+    assert L.vits_model_set_mode(None, pkg.MODE_HF) == -1
+
+
 def test_product_does_not_link_or_load_the_oracle(pkg):
     import subprocess
     out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
