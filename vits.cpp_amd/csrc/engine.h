@@ -115,7 +115,6 @@ struct Knobs {
     bool no_wn_fuse = false;     // VITS_NO_WN_FUSE: WaveNet layer as two launches
     bool no_group16 = false;     // VITS_NO_GROUP16: 16-bit vocoder through the fp32-layout (converter) path
     bool no_fuse16 = false;      // VITS_NO_FUSE16: 16-bit resblock conv pairs as two launches
-    bool no_post_fuse = false;   // VITS_NO_POST_FUSE: conv_post as its own launch also where the last resblock's kernel could run it
     bool no_rbblock16 = false;   // VITS_NO_RBBLOCK16: 16-bit narrow-stage resblocks as three fused pairs instead of one kernel
     bool no_fuse32 = false;      // VITS_NO_FUSE32: fp32 resblock conv pairs as two launches
     bool no_rb_group = false;    // VITS_NO_RB_GROUP: the resblocks of a stage as separate launches (no grouped launch)

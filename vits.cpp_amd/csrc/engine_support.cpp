@@ -32,7 +32,6 @@ void Knobs::read() {
     no_group16 = flag("VITS_NO_GROUP16");
     no_fuse16 = flag("VITS_NO_FUSE16");
     no_rbblock16 = flag("VITS_NO_RBBLOCK16");
-    no_post_fuse = flag("VITS_NO_POST_FUSE");
     no_fuse32 = flag("VITS_NO_FUSE32");
     no_rb_group = flag("VITS_NO_RB_GROUP");
     rb_group_always = flag("VITS_RB_GROUP");

@@ -40,7 +40,6 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
     HIP_OK(launch_to_group16(zwin, d_len[0], B, F, Lw, 1.0f, z16, arith_now_, stream));
     prof.end(stream);
     Ref16 cur16 = R16(s2.h0, hp.up_init, lws);
-    bool post_fused = false;  // conv_post ran inside the last resblock's kernel
     {
         Conv16Call c;
         c.x = z16;
@@ -150,25 +149,11 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                     f.y16 = bsum16;
                     f.y16_slope = i + 1 < n_up ? hp.lrelu : final_slope;
                     bytes += 2.0 * n_out;
-                    // the last resblock of the last stage also runs conv_post + tanh (vits.cpp:638-642) when it holds every channel of
-                    // its columns (C = 32, 7 taps): the stage output is then never stored, and there is no conv_post launch
-                    if (i + 1 == n_up && C == 32 && dec_post_cin_ == C && dec_post_k_ == 7 && !knobs.no_post_fuse) {
-                        f.post_w = dec_post_w_;
-                        f.post_k = dec_post_k_;
-                        f.pre = pre.p;
-                        f.pre_bs = pre.bs;
-                        f.wave = wv.p;
-                        f.wave_bs = wv.bs;
-                        f.emit_lo = emit_lo;
-                        f.emit_hi = emit_hi;
-                        bytes += (4.0 / C - 4.0 - 2.0) * n_out;
-                        post_fused = true;
-                    }
                 }
                 if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));  // (the accumulation is inside the kernel: the resblocks chain)
                 if (prof.on) {
                     char full[160];
-                    std::snprintf(full, sizeof(full), "hifigan_resblock_block%s|k%d|d135|B%d|e0g|c%dx%d", f.post_w ? "_post" : "", R.k, C, C, C);
+                    std::snprintf(full, sizeof(full), "hifigan_resblock_block|k%d|d135|B%d|e0g|c%dx%d", R.k, C, C, C);
                     for (size_t d = 0; d < nd; ++d) bytes += (double)R.c1[d].bytes16 + (double)R.c2[d].bytes16;
                     prof.begin(full, 3.0 * 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], bytes, sj, true);
                 }
@@ -267,11 +252,9 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
         cur16 = bsum16;
     }
-    if (!post_fused) {
-        prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 2.0 * (dec_post_cin_ + 2) * (double)ssum[n_up], stream);
-        HIP_OK(launch_conv_post16(cur16, dec_post_w_, dec_post_cin_, dec_post_k_, pre, wv, d_len[n_up], B, smax[n_up], arith_now_, stream, emit_lo, emit_hi));
-        prof.end(stream);
-    }
+    prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 2.0 * (dec_post_cin_ + 2) * (double)ssum[n_up], stream);
+    HIP_OK(launch_conv_post16(cur16, dec_post_w_, dec_post_cin_, dec_post_k_, pre, wv, d_len[n_up], B, smax[n_up], arith_now_, stream, emit_lo, emit_hi));
+    prof.end(stream);
     (void)TR;
     return 0;
 }

@@ -144,16 +144,6 @@ struct RbBlock16Call {
     float y16_slope = 1.f;
     float scale = 1.f;
     int scale_div = 0;
-    // optional (C = 32, the last resblock of the last stage): conv_post (C -> 1, post_k = 7 taps) + tanh on the stage output inside the kernel;
-    // yg / y16 are then not written. y16_slope is the activation in front of conv_post (vits.cpp:638)
-    const float* post_w = nullptr;
-    int post_k = 0;
-    float* pre = nullptr;
-    int64_t pre_bs = 0;
-    float* wave = nullptr;
-    int64_t wave_bs = 0;
-    int emit_lo = 0;
-    const int* emit_hi = nullptr;
 };
 bool rbblock16_supported(int channels, int kt, const int* dils, int ndil);
 hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s);

@@ -70,14 +70,6 @@ struct RbBlockParams {
     float y16_slope;
     float scale;
     int scale_div;
-    // POST variant (the last resblock of the last stage): conv_post + tanh (vits.cpp:638-642) on the stage output, which is then not stored
-    const float* post_w;  // [C][7]
-    float* pre;           // optional pre-tanh tap [b][pre_bs]
-    int64_t pre_bs;
-    float* wave;          // PCM [b][wave_bs]
-    int64_t wave_bs;
-    int emit_lo;          // vocoder windows: only samples [emit_lo, emit_hi[b]) of the window are emitted
-    const int* emit_hi;
 };
 
 #ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/rb16_micro.hip)
@@ -95,18 +87,13 @@ __device__ unsigned long long vits_rbb_phase[16 * 65536];
 
 // Block = NSTRIP column strips x C / (32 MRW) row groups of waves; wave (strip, rg) owns the MRW row tiles [MRW rg, MRW rg + MRW) (32 rows each)
 // of the NRW 32-column tiles of its strip.
-// POST (C = 32, the last resblock of the last stage): the block also runs conv_post (C -> 1, 7 taps) + tanh on the stage output it has just
-// finished — its waves hold all 32 channels of their columns — and writes PCM instead of the stage output: the 4 B + 2 B per element of the
-// stage output, their re-read by conv_post16_kernel and that launch disappear. Three more halo columns per side.
-template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF, bool POST = false>
+template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF>
 __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : 1) void rbblock16_kernel(const RbBlockParams p) {
     using namespace rbb;
     constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
     constexpr int P2 = (KT - 1) / 2;
     constexpr int DMAX = D0 > D1 ? (D0 > D2 ? D0 : D2) : (D1 > D2 ? D1 : D2);
-    constexpr int PK = 7, PP = POST ? PK / 2 : 0;     // conv_post taps / its halo
-    constexpr int H = P2 * (3 + D0 + D1 + D2) + PP;   // halo per side: every pair costs P2 (second conv) + P2 * D_p (first conv)
-    static_assert(!POST || (C == 32 && MRW == 1), "conv_post needs every channel of a column in one wave's row tile");
+    constexpr int H = P2 * (3 + D0 + D1 + D2);  // halo per side: every pair costs P2 (second conv) + P2 * D_p (first conv)
     constexpr int BO = W - 2 * H;               // output columns per block
     constexpr int PADX = P2 * DMAX;             // the first conv of a pair reads up to P2 * D_p columns beyond a tile column
     constexpr int PITCH = (W + 2 * PADX + 7) / 8 * 8;
@@ -284,80 +271,6 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     pair(2, D2, true);
     RBB_STAMP(4);
 
-    if constexpr (POST) {
-        // ---- the stage output (sum of the resblocks, scaled) for EVERY tile column, activated with the final slope and rounded as the 16-bit
-        // copy conv_post16_kernel reads, into the LDS tile; then conv_post + tanh in conv_post16_kernel's order (group, tap, channel) ----
-        const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
-        float* wpost = reinterpret_cast<float*>(tile + (C / 8) * PITCH);  // [C][PK], rounded to the arithmetic type like conv_post16_kernel's
-        for (int i = tid; i < C * PK; i += blockDim.x) {
-            const unsigned r = pack16<BF>(p.post_w[i], 0.f) & 0xffffu;
-            if constexpr (BF) wpost[i] = __builtin_bit_cast(float, r << 16);
-            else wpost[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)r);
-        }
-        __syncthreads();  // every wave is done with t_2
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int nr = 0; nr < NRW; ++nr) {
-                const int u = u0 + 32 * nr, t = tg0 + u;
-                const bool inside = t >= 0 && t < len;
-                int2v w[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * k + q;
-                    const int ch0 = rt0 * 32 + 8 * g + 4 * h;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = yv[0][nr][4 * g + e];
-                    if (ag && inside) {
-                        const float4v a4 = *reinterpret_cast<const float4v*>(ag + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = a4[e] + v[e];
-                            v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(v[e], v[e] * p.y16_slope);
-                        if (!inside) v[e] = 0.f;
-                    }
-                    w[q].x = (int)pack16<BF>(v[0], v[1]);
-                    w[q].y = (int)pack16<BF>(v[2], v[3]);
-                }
-                *((LdsS)(tile + (rt0 * 4 + 2 * k + h) * PITCH + PADX + u)) = slot_pair(w[0], w[1]);
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int hi = p.emit_hi ? p.emit_hi[b] : len;
-        for (int u = H + tid; u < H + BO; u += blockDim.x) {
-            const int t = tg0 + u;
-            if (t >= len || t < p.emit_lo || t >= hi) continue;
-            float a = 0.f;
-            for (int g = 0; g < C / 8; ++g)
-                for (int j = 0; j < PK; ++j) {
-                    const int tt = t + j - PK / 2;
-                    if (tt < 0 || tt >= len) continue;
-                    const int4v q = tile[g * PITCH + PADX + u + j - PK / 2];
-                    const unsigned uu[4] = {(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo, hi16;
-                        if constexpr (BF) {
-                            lo = __builtin_bit_cast(float, (uu[e] & 0xffffu) << 16);
-                            hi16 = __builtin_bit_cast(float, uu[e] & 0xffff0000u);
-                        } else {
-                            lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(uu[e] & 0xffffu));
-                            hi16 = (float)__builtin_bit_cast(_Float16, (unsigned short)(uu[e] >> 16));
-                        }
-                        a += wpost[(g * 8 + 2 * e) * PK + j] * lo;
-                        a += wpost[(g * 8 + 2 * e + 1) * PK + j] * hi16;
-                    }
-                }
-            if (p.pre) p.pre[(int64_t)b * p.pre_bs + t] = a;
-            p.wave[(int64_t)b * p.wave_bs + t] = tanhf(a);
-        }
-    } else {
     // ---- epilogue (as the last pair's in rbpair16_kernel): resblock sum / scale, fp32 output + 16-bit copy, the BO owned columns only ----
     {
         float* yg = p.yg + (int64_t)b * p.g_bs;
@@ -396,25 +309,23 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                 }
             }
     }
-    }
     RBB_STAMP(5);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF, bool POST = false>
+template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
 static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
     constexpr int D0 = 1, D1 = 3, D2 = 5;
-    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2) + (POST ? 3 : 0), BO = W - 2 * H, PADX = P2 * D2,
-                  PITCH = (W + 2 * PADX + 7) / 8 * 8;
-    const size_t lds = (size_t)(C / 8) * PITCH * 16 + (POST ? (size_t)C * 7 * sizeof(float) : 0);
+    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
+    const size_t lds = (size_t)(C / 8) * PITCH * 16;
     static std::atomic<bool> big_lds_set{false};
     if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF, POST>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
+    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -442,7 +353,7 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
         p.b2[i] = c2[i]->bias;
     }
     const int dils[3] = {1, 3, 5};
-    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || (!c.yg && !c.post_w)) return hipErrorInvalidValue;
+    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || !c.yg) return hipErrorInvalidValue;
     p.y0 = c.y0;
     p.lens = c.lens;
     p.tmax = c.tmax;
@@ -457,24 +368,7 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
     p.y16_slope = c.y16_slope;
     p.scale = c.scale;
     p.scale_div = c.scale_div;
-    p.post_w = c.post_w;
-    p.pre = c.pre;
-    p.pre_bs = c.pre_bs;
-    p.wave = c.wave;
-    p.wave_bs = c.wave_bs;
-    p.emit_lo = c.emit_lo;
-    p.emit_hi = c.emit_hi;
     const bool bf = arith == VITS_ARITH_BF16;
-    if (c.post_w) {  // conv_post folded into the last resblock of the last stage (C = 32, 7 taps)
-        if (C != 32 || c.post_k != 7 || !c.wave) return hipErrorInvalidValue;
-#define VITS_RBB_POST(K) \
-    if (kt == K) return bf ? launch_rbb<K, 32, 4, 3, 1, true, true>(p, c.batch, s) : launch_rbb<K, 32, 4, 3, 1, false, true>(p, c.batch, s)
-        VITS_RBB_POST(3);
-        VITS_RBB_POST(7);
-        VITS_RBB_POST(11);
-#undef VITS_RBB_POST
-        return hipErrorInvalidValue;
-    }
     // tile shape (column strips x 32-column tiles per wave): 4 x 3 = 384 columns. Measured alternatives (batch 64 x 128 ids, f16): C = 32 with
     // 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 6 x 2 (twelve waves) +-0, as 8 x 2 = 512 columns
     // (sixteen waves at 128 VGPRs, spills) -5 % on k = 11 only.
