@@ -415,9 +415,7 @@ __global__ __launch_bounds__(320) void conv16_kernel(const Conv16Params p) {
             for (int nr = 0; nr < NR; ++nr) {
                 const int t = colbase + nr * 32;
                 if (t >= ncols) continue;
-                const float ta = tanhf(acc[0][nr][r] + b0);
-                const float sg = 1.0f / (1.0f + expf(-(acc[MR - 1][nr][r] + b1)));
-                yb[(int64_t)ch * p.y_cs + t] = ta * sg;
+                yb[(int64_t)ch * p.y_cs + t] = wavenet_gate(acc[0][nr][r] + b0, acc[MR - 1][nr][r] + b1);
             }
         }
     } else {  // transposed conv: GEMM row rho = phase * cout + co (phase-major), column q; output sample n = s*q + phase - crop

@@ -760,10 +760,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                     const int ch = chbase + 8 * g + qi + rowoff;
                     const float b0 = bias_w[0][g], b1 = MR == 1 ? bias_s[g] : bias_w[MR - 1][g];
                     float4 o;
-                    o.x = tanhf(a0 + b0) * (1.0f / (1.0f + expf(-(s0 + b1))));
-                    o.y = tanhf(a1 + b0) * (1.0f / (1.0f + expf(-(s1 + b1))));
-                    o.z = tanhf(a2 + b0) * (1.0f / (1.0f + expf(-(s2 + b1))));
-                    o.w = tanhf(a3 + b0) * (1.0f / (1.0f + expf(-(s3 + b1))));
+                    o.x = wavenet_gate(a0 + b0, s0 + b1);
+                    o.y = wavenet_gate(a1 + b0, s1 + b1);
+                    o.z = wavenet_gate(a2 + b0, s2 + b1);
+                    o.w = wavenet_gate(a3 + b0, s3 + b1);
                     *reinterpret_cast<float4*>(yb + (int64_t)ch * p.y_cs + tcol) = o;
                 }
             }
@@ -777,9 +777,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
             for (int nr = 0; nr < NR; ++nr) {
                 const int t = colbase + nr * 32;
                 if (t >= ncols) continue;
-                const float ta = tanhf(acc[0][nr][r] + b0);
-                const float sg = 1.0f / (1.0f + expf(-(sreg[nr][r] + b1)));
-                yb[(int64_t)ch * p.y_cs + t] = ta * sg;
+                yb[(int64_t)ch * p.y_cs + t] = wavenet_gate(acc[0][nr][r] + b0, sreg[nr][r] + b1);
             }
         }
     } else {  // EPI_CONVT: GEMM row rho = co*s + phase, column q; output sample n = s*q + phase - crop

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet32_kernel(const WaveNet32Para
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
-            const float v = tanhf(acc[0][nr][r] + bt[r]) * (1.0f / (1.0f + expf(-(acc[1][nr][r] + bs[r]))));
+            const float v = wavenet_gate(acc[0][nr][r] + bt[r], acc[1][nr][r] + bs[r]);
             ts[ch * TWP + nr * 32 + col] = inside ? v : 0.f;
         }
     }
@@ -191,7 +191,32 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet32_kernel(const WaveNet32Para
     conv(p.w_rs, 2 * gw, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsF)(ts + krow * TWP + col), TWP);
 
     // ---- epilogue: rows < H of a 2H-row layer -> h' = h + rs; the other rows -> outputs += rs ----
+    // Two passes: every addend (the residual h or the running `outputs`) and bias is loaded FIRST, then everything is stored. Written as
+    // load / add / store per element the compiler has to keep each read-modify-write of `outputs` behind the previous store (the pointers
+    // may alias for all it knows): 32 dependent HBM round trips per lane, 15 of the 48 us of a layer in the 16-bit kernel (tools/wn16_micro.hip).
     const bool two = p.rs_rows > H;
+    float addv[NR][2][16], biasv[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+            biasv[m][r] = 2 * gw + m < ntiles2 ? p.b_rs[row] : 0.f;
+        }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int t = t0 + nr * 32 + col;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                float a = 0.f;
+                if (t < len && 2 * gw + m < ntiles2)
+                    a = (two && row < H) ? hb[(int64_t)row * p.h_cs + t] : p.outputs[(int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t];
+                addv[nr][m][r] = a;
+            }
+    }
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int t = t0 + nr * 32 + col;
@@ -202,14 +227,10 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet32_kernel(const WaveNet32Para
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
-                float v = acc[m][nr][r] + p.b_rs[row];
-                if (two && row < H) {
-                    v = hb[(int64_t)row * p.h_cs + t] + v;
-                    p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
-                } else {
-                    float* op = p.outputs + (int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t;
-                    *op = *op + v;
-                }
+                float v = acc[m][nr][r] + biasv[m][r];
+                v = addv[nr][m][r] + v;
+                if (two && row < H) p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
+                else p.outputs[(int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t] = v;
             }
         }
     }
@@ -242,15 +263,32 @@ __device__ __forceinline__ uint16_t wn_round16(float v) {
     }
 }
 
-template <int H, int KT, bool BF>
-__global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Params pp) {
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/wn16_micro.hip)
+__device__ unsigned long long vits_wn_phase[8 * 65536];
+#define WN_STAMP(k)                                                                                      \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;                                    \
+            if (lin < 65536) vits_wn_phase[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();            \
+        }                                                                                                \
+    } while (0)
+#else
+#define WN_STAMP(k)
+#endif
+
+// NCW: 32-frame column tiles per wave. 1 = twelve waves, one (channel group, column tile) each; 2 = six waves that own BOTH column tiles of
+// their channel group. The gated conv of a block is bound by the weight-fragment traffic through the CU's vector memory path: twelve waves x
+// 120 KB = 1.44 MB at 64 B per clock = 11.8 us (measured 15 us for 6 us of MFMA work; tools/wn16_micro.hip); with NCW = 2 every fragment
+// feeds two MFMAs per row tile and the traffic halves.
+template <int H, int KT, bool BF, int NCW>
+__global__ __launch_bounds__(4 * H / NCW, 1) void wavenet16_kernel(const WaveNet16Params pp) {
     const WaveNet32Params& p = pp.f;
-    constexpr int NG = H / 32, NC = 2, NW = NG * NC;
+    constexpr int NG = H / 32, NC = 2, NW = NG * NC / NCW;
     constexpr int NCH = H / 32;
     constexpr int BM = NC * 32;
     constexpr int P = (KT - 1) / 2;
     constexpr int XS = BM + KT - 1;  // slots per group row of the h tile
-    constexpr int TOTAL1 = NCH * KT * 2, TOTAL2 = NCH * 2;  // A-fragment steps (one MFMA each) per row tile
+    constexpr int TOTAL1 = NCH * KT * 2, TOTAL2 = NCH * 2;  // A-fragment steps per row tile
     extern __shared__ __attribute__((aligned(16))) wn_int4v l16[];
     wn_int4v* xs = l16;  // [G][XS]
     wn_int4v* ts = l16;  // [G][BM]  (acts take the h tile's place)
@@ -261,27 +299,35 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Para
     const int len = p.lens ? p.lens[b] : p.tmax;
     const int t0 = blockIdx.x * BM;
     if (t0 >= len) return;
+    WN_STAMP(0);
     const int krow = lane >> 5;
-    const int gw = wid % NG, col = (wid / NG) * 32 + (lane & 31);
+    const int gw = wid % NG, col0 = (wid / NG) * (NCW * 32) + (lane & 31);  // this lane's column of its column tile n: col0 + 32 n
     const float* hb = p.h + (int64_t)b * p.h_bs;
 
-    // ---- the h tile through registers: rounded, group layout; zero outside the sequence ----
+    // ---- the h tile through registers: rounded, group layout; zero outside the sequence. A thread owns whole 16-byte slots (8 channels of
+    // one frame: eight coalesced dword loads, one ds_write_b128) — as 2-byte LDS writes this phase was 13k conflicting ds_write_b16 per block ----
     {
-        constexpr int NTH = 64 * NW, TOTALX = H * XS, PER = (TOTALX + NTH - 1) / NTH;
-        float v[PER];
+        constexpr int NTH = 64 * NW, NSLOT = (H / 8) * XS, PER = (NSLOT + NTH - 1) / NTH;
+        float v[PER][8];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int idx = tid + u * NTH;
-            const int c = idx / XS, i = idx - c * XS;
+            const int g = idx / XS, i = idx - g * XS;
             const int t = t0 - P + i;
-            v[u] = (idx < TOTALX && t >= 0 && t < len) ? hb[(int64_t)c * p.h_cs + t] : 0.f;
+            const bool ok = idx < NSLOT && t >= 0 && t < len;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u][e] = ok ? hb[(int64_t)(g * 8 + e) * p.h_cs + t] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int idx = tid + u * NTH;
-            if (idx < TOTALX) {
-                const int c = idx / XS, i = idx - c * XS;
-                reinterpret_cast<uint16_t*>(xs + (c >> 3) * XS + i)[c & 7] = wn_round16<BF>(v[u]);
+            if (idx < NSLOT) {
+                wn_int4v q;
+                q.x = (int)((unsigned)wn_round16<BF>(v[u][0]) | ((unsigned)wn_round16<BF>(v[u][1]) << 16));
+                q.y = (int)((unsigned)wn_round16<BF>(v[u][2]) | ((unsigned)wn_round16<BF>(v[u][3]) << 16));
+                q.z = (int)((unsigned)wn_round16<BF>(v[u][4]) | ((unsigned)wn_round16<BF>(v[u][5]) << 16));
+                q.w = (int)((unsigned)wn_round16<BF>(v[u][6]) | ((unsigned)wn_round16<BF>(v[u][7]) << 16));
+                xs[idx] = q;  // (slot index g * XS + i == idx)
             }
         }
     }
@@ -293,20 +339,23 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Para
         bs[r] = p.b_in[H + ch];
     }
     __syncthreads();
+    WN_STAMP(1);
 
     typedef const __attribute__((address_space(3))) wn_int4v* LdsV;
-    wn_floatx16 acc[2];
+    wn_floatx16 acc[2][NCW];
     auto mfma = [&](wn_int4v a, wn_int4v bq, wn_floatx16 c) __attribute__((always_inline)) -> wn_floatx16 {
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, bq), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_half8, a), __builtin_bit_cast(wn_half8, bq), c, 0, 0, 0);
     };
-    // one conv for this wave's two row tiles mt0, mt0 + 1: order per output = chunk, tap, k-half (conv16.hip's)
+    // one conv for this wave's two row tiles mt0, mt0 + 1 and its NCW column tiles: order per output = chunk, tap, k-half (conv16.hip's)
     auto conv = [&](const uint16_t* wp, int mt0, auto total_c, auto taps_c, LdsV base, const int pitch) __attribute__((always_inline)) {
         constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
         int wvoff[2];
 #pragma unroll
@@ -314,69 +363,122 @@ __global__ __launch_bounds__(4 * H, 1) void wavenet16_kernel(const WaveNet16Para
         auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_int4v {
             return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
         };
-        // (a step is ONE 32-cycle MFMA per row tile: eight slots, six steps of look-ahead — two steps, as in the fp32 kernels whose
-        // steps are 16 times longer, left the loop waiting for L2)
         constexpr int RS = 8, RD = 6;
         wn_int4v ring[RS][2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int i = 0; i < RD; ++i) ring[i][m] = load_a(m, i < TOTAL ? i : TOTAL - 1);
+        auto bslot = [&](int s) __attribute__((always_inline)) -> int {
+            const int kk = s & 1, cj = s >> 1, j = cj % TAPS, c = cj / TAPS;
+            return (c * 4 + 2 * kk) * pitch + j;
+        };
+        wn_int4v b_nxt[NCW];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+        for (int n = 0; n < NCW; ++n) b_nxt[n] = base[bslot(0) + 32 * n];
 #pragma unroll
-            for (int j = 0; j < TAPS; ++j)
+        for (int s = 0; s < TOTAL; ++s) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int s = (c * TAPS + j) * 2 + kk;  // compile time after unrolling
+            for (int m = 0; m < 2; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            wn_int4v bq[NCW];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const wn_int4v bq = base[(c * 4 + 2 * kk) * pitch + j];
+            for (int n = 0; n < NCW; ++n) {
+                bq[n] = b_nxt[n];
+                b_nxt[n] = base[bslot(s + 1 < TOTAL ? s + 1 : TOTAL - 1) + 32 * n];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = mfma(ring[s % RS][m], bq, acc[m]);
-                }
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NCW; ++n) acc[m][n] = mfma(ring[s % RS][m], bq[n], acc[m][n]);
+        }
     };
 
     // ---- gated conv ----
-    conv(pp.w_in16, 2 * gw, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsV)(xs + krow * XS + col), XS);
+    conv(pp.w_in16, 2 * gw, std::integral_constant<int, TOTAL1>{}, std::integral_constant<int, KT>{}, (LdsV)(xs + krow * XS + col0), XS);
+    WN_STAMP(2);
     __syncthreads();
-    {
-        const bool inside = t0 + col < len;
+    WN_STAMP(6);
+    // acts, rounded, as whole slots: lane l holds channels 4 krow .. 4 krow + 3 of each of the 4 channel groups of its row tile at its frame;
+    // v_permlane32_swap trades halves between two groups so that every lane writes one 16-byte slot (2-byte writes: an 8-way bank conflict)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
-            float v = tanhf(acc[0][r] + bt[r]) * (1.0f / (1.0f + expf(-(acc[1][r] + bs[r]))));
-            asm volatile("" : "+v"(v));  // (two roundings, as the two-launch path: fp32 acts to memory, 16-bit at the converter)
-            reinterpret_cast<uint16_t*>(ts + (ch >> 3) * BM + col)[ch & 7] = inside ? wn_round16<BF>(v) : (uint16_t)0;
+    for (int n = 0; n < NCW; ++n) {
+        const int col = col0 + 32 * n;
+        const bool inside = t0 + col < len;
+        unsigned w[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned short q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float v = wavenet_gate(acc[0][n][r] + bt[r], acc[1][n][r] + bs[r]);
+                asm volatile("" : "+v"(v));  // (two roundings, as the two-launch path: fp32 acts to memory, 16-bit at the converter)
+                q[e] = inside ? wn_round16<BF>(v) : (unsigned short)0;
+            }
+            w[g][0] = (unsigned)q[0] | ((unsigned)q[1] << 16);
+            w[g][1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const auto x = __builtin_amdgcn_permlane32_swap(w[2 * k][0], w[2 * k + 1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(w[2 * k][1], w[2 * k + 1][1], false, false);
+            ts[(gw * 4 + 2 * k + krow) * BM + col] = wn_int4v{(int)x[0], (int)y[0], (int)x[1], (int)y[1]};
         }
     }
+    WN_STAMP(7);
     __syncthreads();
+    WN_STAMP(3);
 
     // ---- 1x1 res/skip conv ----
     const int ntiles2 = p.rs_rows >> 5;
     if (2 * gw >= ntiles2) return;
-    conv(pp.w_rs16, 2 * gw, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col), BM);
+    conv(pp.w_rs16, 2 * gw, std::integral_constant<int, TOTAL2>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col0), BM);
+    WN_STAMP(4);
 
-    const int t = t0 + col;
-    if (t >= len) return;
+    // (two passes — every addend and bias loaded first, then everything stored: see the fp32 kernel's epilogue)
     const bool two = p.rs_rows > H;
+    float addv[NCW][2][16], biasv[2][16];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (2 * gw + m >= ntiles2) continue;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
-            float v = acc[m][r] + p.b_rs[row];
-            if (two && row < H) {
-                v = hb[(int64_t)row * p.h_cs + t] + v;
-                p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
-            } else {
-                float* op = p.outputs + (int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t;
-                *op = *op + v;
+            biasv[m][r] = 2 * gw + m < ntiles2 ? p.b_rs[row] : 0.f;
+        }
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) {
+        const int t = t0 + col0 + 32 * n;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                float a = 0.f;
+                if (t < len && 2 * gw + m < ntiles2)
+                    a = (two && row < H) ? hb[(int64_t)row * p.h_cs + t] : p.outputs[(int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t];
+                addv[n][m][r] = a;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) {
+        const int t = t0 + col0 + 32 * n;
+        if (t >= len) continue;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (2 * gw + m >= ntiles2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (2 * gw + m) * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                float v = acc[m][n][r] + biasv[m][r];
+                v = addv[n][m][r] + v;
+                if (two && row < H) p.h_out[(int64_t)b * p.ho_bs + (int64_t)row * p.ho_cs + t] = v;
+                else p.outputs[(int64_t)b * p.o_bs + (int64_t)(two ? row - H : row) * p.o_cs + t] = v;
             }
         }
     }
+    WN_STAMP(5);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -448,8 +550,14 @@ hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const Wa
     p.w_rs16 = rs.wp16;
     const size_t ldsz = (size_t)(H / 8) * (64 + KT - 1) * 16;
     dim3 grid((c.tmax + 63) / 64, c.batch);
-    if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true>), grid, dim3(4 * H), ldsz, s, p);
-    else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false>), grid, dim3(4 * H), ldsz, s, p);
+    static const int ncw = getenv("VITS_WN16_NCW") ? atoi(getenv("VITS_WN16_NCW")) : 1;  // (2: six waves, both column tiles each — measured 40.6 vs 38.4 us per layer)
+    if (ncw == 1) {
+        if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true, 1>), grid, dim3(4 * H), ldsz, s, p);
+        else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false, 1>), grid, dim3(4 * H), ldsz, s, p);
+    } else {
+        if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true, 2>), grid, dim3(2 * H), ldsz, s, p);
+        else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false, 2>), grid, dim3(2 * H), ldsz, s, p);
+    }
     return hipGetLastError();
 }
 
