@@ -272,10 +272,29 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     RBB_STAMP(4);
 
     // ---- epilogue (as the last pair's in rbpair16_kernel): resblock sum / scale, fp32 output + 16-bit copy, the BO owned columns only ----
+    // Two passes: the accumulator of the previous resblocks is read in place (accg == yg), so a load / add / store per element is a chain of
+    // dependent HBM round trips — the compiler may not move a later load above an earlier store that could alias it (the WaveNet kernels
+    // spent 15 of 48 us that way). All addends first (the conv accumulators are dead: their registers hold them), then every store.
     {
         float* yg = p.yg + (int64_t)b * p.g_bs;
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
+        float4v av[MRW][4][NRW];
+        __builtin_amdgcn_sched_barrier(0);  // (not above the last conv: its accumulators have to be dead for these registers)
+        if (ag) {
+#pragma unroll
+            for (int m = 0; m < MRW; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch0 = (rt0 + m) * 32 + 8 * g + 4 * h;
+#pragma unroll
+                    for (int nr = 0; nr < NRW; ++nr) {
+                        const int u = u0 + 32 * nr, t = tg0 + u;
+                        av[m][g][nr] = float4v{0.f, 0.f, 0.f, 0.f};
+                        if (u >= H && u < H + BO && t < len) av[m][g][nr] = *reinterpret_cast<const float4v*>(ag + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+                    }
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MRW; ++m)
 #pragma unroll
@@ -290,10 +309,9 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = yv[m][nr][4 * g + e];
                     if (ag) {
-                        const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = a4[e] + v[e];
+                            v[e] = av[m][g][nr][e] + v[e];
                             v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
                         }
                     }

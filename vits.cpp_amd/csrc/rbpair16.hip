@@ -308,28 +308,38 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
 #define VITS_RB16_ERD (ROWS ? 2 : 3)
 #endif
         constexpr int RD = VITS_RB16_ERD;  // residual look-ahead ring (row split: NR = 4 float4 per entry, and 208 VGPRs with three of them)
-        float4v rv[RD][NR];
+        // (the accumulator of the resblock sum — last pair of resblocks 1 and 2, read in place: accg == yg — travels in the same look-ahead ring
+        // as the residual: read inside the store loop, every read waits behind the previous store it might alias — 16 dependent round trips)
+        // (not in the instantiations compiled for four waves per SIMD, C = 256 with short tiles: 128 VGPRs, the ring would spill 50 of them)
+        constexpr bool AVRING = !(C >= 256 && (KT - 1) * DIL <= 32);
+        float4v rv[RD][NR], av[AVRING ? RD : 1][NR];
         auto col_ok = [&](int nr, int& t) __attribute__((always_inline)) -> bool {
             const int o = cb + nr * 32 + (lane & 31);
             t = t0 + o;
             return o < BO && t < len;
         };
-        auto load_res = [&](int it, float4v* dst) __attribute__((always_inline)) {
+        auto load_res = [&](int it, float4v* dst, float4v* adst) __attribute__((always_inline)) {
             const int ch0 = (rt0 + it / 4) * 32 + 8 * (it & 3) + 4 * h;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 int t;
                 dst[nr] = float4v{0.f, 0.f, 0.f, 0.f};
-                if (rg && col_ok(nr, t)) dst[nr] = *reinterpret_cast<const float4v*>(rg + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+                if constexpr (AVRING) adst[nr] = float4v{0.f, 0.f, 0.f, 0.f};
+                if (!col_ok(nr, t)) continue;
+                const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+                if (rg) dst[nr] = *reinterpret_cast<const float4v*>(rg + go);
+                if constexpr (AVRING) {
+                    if (ag) adst[nr] = *reinterpret_cast<const float4v*>(ag + go);
+                }
             }
         };
 #pragma unroll
         for (int i = 0; i < RD - 1; ++i)
-            if (i < NGR) load_res(i, rv[i]);
+            if (i < NGR) load_res(i, rv[i], av[AVRING ? i : 0]);
 #pragma unroll
         for (int it = 0; it < NGR; ++it) {
             const int mr = it / 4, g = it & 3;
-            if (it + RD - 1 < NGR) load_res(it + RD - 1, rv[(it + RD - 1) % RD]);
+            if (it + RD - 1 < NGR) load_res(it + RD - 1, rv[(it + RD - 1) % RD], av[AVRING ? (it + RD - 1) % RD : 0]);
             __builtin_amdgcn_sched_barrier(0);
             const int ch0 = (rt0 + mr) * 32 + 8 * g + 4 * h;
             const float4v bias = *reinterpret_cast<const float4v*>(p.b2 + ch0);
@@ -345,7 +355,9 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
                     if (rg) v[e] = rv[it % RD][nr][e] + v[e];
                 }
                 if (ag) {
-                    const float4v a4 = *reinterpret_cast<const float4v*>(ag + go);
+                    float4v a4;
+                    if constexpr (AVRING) a4 = av[it % RD][nr];
+                    else a4 = *reinterpret_cast<const float4v*>(ag + go);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = a4[e] + v[e];
