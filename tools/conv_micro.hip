@@ -28,6 +28,9 @@ using namespace vits;
 #ifndef CIN_
 #define CIN_ 128
 #endif
+#ifndef COUT_
+#define COUT_ CIN_
+#endif
 #ifndef T_
 #define T_ 14400
 #endif
@@ -35,19 +38,19 @@ using namespace vits;
 #define B_ 64
 #endif
 int main() {
-    const int C = CIN_, K = KT_, T = T_, B = B_;
-    std::vector<float> w((size_t)C * C * K, 0.01f), bias(C, 0.1f);
-    PackedConv pc; pc.cin = C; pc.cout = C; pc.kt = K; pc.epi = EPI_STD;
-    auto packed = pack_conv_weights(w.data(), C, C, K, EPI_STD, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
+    const int C = CIN_, CO = COUT_, K = KT_, T = T_, B = B_;
+    std::vector<float> w((size_t)C * CO * K, 0.01f), bias(CO, 0.1f);
+    PackedConv pc; pc.cin = C; pc.cout = CO; pc.kt = K; pc.epi = EPI_STD;
+    auto packed = pack_conv_weights(w.data(), CO, C, K, EPI_STD, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
     float *dw, *db, *dx, *dy;
     hipMalloc(&dw, packed.size() * 4); hipMemcpy(dw, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
-    hipMalloc(&db, C * 4); hipMemcpy(db, bias.data(), C * 4, hipMemcpyHostToDevice);
+    hipMalloc(&db, CO * 4); hipMemcpy(db, bias.data(), CO * 4, hipMemcpyHostToDevice);
     size_t n = (size_t)B * C * T;
-    hipMalloc(&dx, n * 4); hipMalloc(&dy, n * 4);
+    hipMalloc(&dx, n * 4); hipMalloc(&dy, (size_t)B * CO * T * 4);
     std::vector<float> hx(n); for (size_t i = 0; i < n; ++i) hx[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(dx, hx.data(), n * 4, hipMemcpyHostToDevice);
     pc.wp = dw; pc.bias = db;
-    ConvCall c; c.x.p = dx; c.x.cs = T; c.x.bs = (int64_t)C * T; c.y.p = dy; c.y.cs = T; c.y.bs = (int64_t)C * T;
+    ConvCall c; c.x.p = dx; c.x.cs = T; c.x.bs = (int64_t)C * T; c.y.p = dy; c.y.cs = T; c.y.bs = (int64_t)CO * T;
 #ifdef WITH_RES
     c.res = c.x;
 #endif
@@ -60,7 +63,7 @@ int main() {
     for (int i = 0; i < reps; ++i) launch_conv(pc, c, nullptr);
     hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-    double fl = 2.0 * C * C * K * (double)B * T;
+    double fl = 2.0 * C * CO * K * (double)B * T;
     {
         int nb_occ = -1;
 #if CIN_ <= 32
@@ -156,6 +159,18 @@ int main() {
             printf("per chunk (cycles): ");
             for (int c = 0; c < 4; ++c) printf(" c%d compute %.0f barrier-wait %.0f |", c, comp[c] / n, bar[c] / n);
             printf(" ideal compute %d\n", KT_ * 16 * 4 * 64);
+        }
+        {
+            std::vector<unsigned long long> pb(4 * 65536);
+            hipMemcpyFromSymbol(pb.data(), HIP_SYMBOL(vits_prod_buf), pb.size() * 8);
+            double s4[4] = {0, 0, 0, 0}; size_t n = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                if (!pb[4 * i + 3]) continue;
+                for (int k = 0; k < 4; ++k) s4[k] += (double)pb[4 * i + k];
+                ++n;
+            }
+            const int nch = (CIN_ + 31) / 32 - 1;
+            if (n) printf("producer per chunk (cycles, 3-buffer path): issue %.0f | DMA wait %.0f | post-process %.0f | barrier %.0f\n", s4[0] / n / nch, s4[1] / n / nch, s4[2] / n / nch, s4[3] / n / nch);
         }
         std::sort(kls.begin(), kls.end());
         printf("phases over %zu blocks (tile %dx%d), 10 ns ticks -> us: prologue %.2f  k-loop %.2f (p10 %.2f p90 %.2f)  epilogue %.2f; span %.1f us; blocks*life/span = %.1f resident; shader clock in the K loop %.3f GHz, MFMA issue efficiency of the K loop %.3f\n",

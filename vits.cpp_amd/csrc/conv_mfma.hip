@@ -91,6 +91,7 @@ struct ConvParams {
 //     producer on boundary tiles only. DESIGN.md section 4.1 has the measurements behind each of these choices.
 #ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/conv_micro.hip): per-block phase timestamps, 100 MHz clock
 __device__ unsigned long long vits_phase_buf[8 * 65536];  // [block][0..3] 100 MHz stamps, [4..5] shader clock around the K loop, [6..7] HW_ID / XCC_ID
+__device__ unsigned long long vits_prod_buf[4 * 65536];  // [block][0..3]: producer wave, shader cycles in issue / DMA wait / post-processing / barrier
 __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]: shader clock at the end of chunk c < 4 and behind its barrier
 #define VITS_STAMP(k)                                                                                               \
     do {                                                                                                            \
@@ -116,6 +117,22 @@ __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]
 #ifndef VITS_WAVES_ATTR
 #define VITS_WAVES_ATTR
 #endif
+// Zero the columns of a landed 32-row LDS tile (row pitch XWP, column 0 = global time ts) that lie outside [0, len): the left
+// columns [0, -ts) and the right columns [len - ts, XWP). A lane owns a row (two lanes per row) and walks the few columns concerned:
+// a boundary tile costs the producer ~(columns outside) / 2 stores. (A predicated store per (row, 64-column piece) — 96 branches for
+// mostly one or two active lanes each — took 7.5-14k cycles per chunk: at 128 tokens per utterance EVERY tile is a boundary tile, and
+// the compute waves of the encoder's FFN convs waited for that loop half of the time.)
+template <int XWP>
+__device__ __forceinline__ void zero_oob_columns(float* lbase, int ts, int len, int lane) {
+    int nl = -ts;
+    nl = nl < 0 ? 0 : (nl > XWP ? XWP : nl);
+    int rs = len - ts;
+    rs = rs < nl ? nl : (rs > XWP ? XWP : rs);
+    const int noob = nl + XWP - rs;
+    float* row = lbase + (lane & 31) * XWP;
+    for (int k = lane >> 5; k < noob; k += 2) row[k < nl ? k : rs + (k - nl)] = 0.f;
+}
+
 // The kernel body as a device function of the block's (column tile, row-tile group, utterance) coordinates and the block's dynamic
 // LDS: conv_mfma_kernel runs it for one convolution; conv_group_kernel (below) runs the bodies of up to three convolutions with
 // different tap counts in ONE launch.
@@ -256,7 +273,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                     }
                 }
                 // ... then zero what lies outside the sequence (boundary tiles) or beyond the last input channel
-                if (!interior || (c + 1) * CK > p.cin) {
+                if ((c + 1) * CK > p.cin) {
 #pragma unroll 4
                     for (int r = 0; r < CK; ++r) {
                         const bool chbad = c * CK + r >= p.cin;
@@ -264,6 +281,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                         for (int m = 0; m < NMP; ++m)
                             if ((oob[m] || chbad) && (XWP % 64 == 0 || 64 * m + lane < XWP)) lbase[r * XWP + 64 * m + lane] = 0.f;
                     }
+                } else if (!interior) {
+                    zero_oob_columns<XWP>(lbase, ts, len_in, lane);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS writes of this wave done before the barrier
             };
@@ -304,16 +323,39 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                 finish(0, 0);
                 __syncthreads();
                 int b1 = 1, b2 = 2;  // buffers of chunks c + 1 and c + 2
+#ifdef VITS_PHASE_TIMING
+                unsigned long long pt[4] = {0, 0, 0, 0};
+#define PSTAMP(k)                                              \
+    do {                                                       \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        pt[k] += now - pprev;                                  \
+        pprev = now;                                           \
+    } while (0)
+                unsigned long long pprev = __builtin_amdgcn_s_memtime();
+#else
+#define PSTAMP(k)
+#endif
                 for (int c = 0; c + 1 < n; ++c) {
                     const bool more = c + 2 < n;
                     if (more) issue(c + 2, b2);  // last read during chunk c - 1, which every compute wave left before B(c)
+                    PSTAMP(0);
                     if (more && x4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI4) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PSTAMP(1);
                     finish(c + 1, b1);
+                    PSTAMP(2);
                     __syncthreads();
+                    PSTAMP(3);
                     b1 = b2;
                     b2 = b2 == 2 ? 0 : b2 + 1;
                 }
+#ifdef VITS_PHASE_TIMING
+                if (lane == 0) {
+                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+                    if (lin < 65536)
+                        for (int k = 0; k < 4; ++k) vits_prod_buf[4 * lin + k] = pt[k];
+                }
+#endif
             }
             if (wid == 4) return;
         }
@@ -528,7 +570,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                             l4[i] = v;
                         }
                     }
-                    if (!interior || (c + 1) * CK > p.cin) {
+                    if ((c + 1) * CK > p.cin) {
 #pragma unroll 4
                         for (int r = 0; r < CK; ++r) {
                             const bool chbad = c * CK + r >= p.cin;
@@ -536,6 +578,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                             for (int m = 0; m < NMP; ++m)
                                 if ((oob[m] || chbad) && (XWP % 64 == 0 || 64 * m + lane < XWP)) lbase[r * XWP + 64 * m + lane] = 0.f;
                         }
+                    } else if (!interior) {
+                        zero_oob_columns<XWP>(lbase, ts, len_in, lane);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
