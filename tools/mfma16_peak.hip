@@ -20,10 +20,24 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_loop(float* out, int iters, i
         int* pa = (int*)&a[i];
         int* pb = (int*)&b[i];
         for (int e = 0; e < 4; ++e) {
-            h = h * 1664525u + 1013904223u;
-            pa[e] = zero ? 0 : (int)((h & 0x03ff03ffu) | 0x30003000u);  // two finite 16-bit values of magnitude ~0.1-0.25
-            h = h * 1664525u + 1013904223u;
-            pb[e] = zero ? 0 : (int)((h & 0x03ff03ffu) | 0x30003000u);
+            // zero == 0: two finite 16-bit values of magnitude ~0.1-0.25 (random mantissa, one sign, one exponent);
+            // zero == 2: random sign, magnitudes spread over 2^-7 .. 2^0 (what activations and weights look like)
+            auto gen = [&]() -> int {
+                h = h * 1664525u + 1013904223u;
+                if (zero == 1) return 0;
+                if (zero == 0) return (int)((h & 0x03ff03ffu) | 0x30003000u);
+                unsigned v = 0;
+                for (int k = 0; k < 2; ++k) {
+                    h = h * 1664525u + 1013904223u;
+                    const unsigned r = h >> 8;
+                    const unsigned sign = (r >> 20) & 1u, ex = (r >> 16) & 7u;
+                    const unsigned bits = BF ? (sign << 15) | ((120u + ex) << 7) | (r & 0x7fu) : (sign << 15) | ((8u + ex) << 10) | (r & 0x3ffu);
+                    v |= bits << (16 * k);
+                }
+                return (int)v;
+            };
+            pa[e] = gen();
+            pb[e] = gen();
         }
     }
     unsigned long long t0 = 0, r0 = 0;
@@ -80,5 +94,7 @@ int main() {
     run<4, false>("random", 0, d, 12);
     run<4, true>("random", 0, d, 8);
     run<4, false>("zeros ", 1, d, 8);
+    run<4, false>("signed, spread exponents", 2, d, 8);
+    run<4, true>("signed, spread exponents", 2, d, 8);
     return 0;
 }

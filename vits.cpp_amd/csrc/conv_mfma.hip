@@ -831,8 +831,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         const int out_len = p.len_out ? p.len_out[b] : p.t_out;
         // stride 8: the 4 registers of a group are phases 4h..4h+3 of ONE output channel at one input position, i.e. 4
         // consecutive output samples -> one dwordx4 store (interior tiles; crop is 0 or 4 so the address stays 16-B aligned)
-        const bool wide8 = s == 8 && (p.ct_crop & 3) == 0 && (t0 + BN <= ncols - 1) && t0 > 0 && ((mt0 + MR) * 32 <= p.rows) &&
-                           ((p.y_cs & 3) == 0) && ((((uintptr_t)yb | (uintptr_t)y2b) & 15) == 0);
+        // (boundary tiles too: at ~225 frames per utterance the first upsampler has no interior tile at all, and the scalar path below
+        // is 128 dword stores per lane; columns past the last one and the few samples outside [0, out_len) are guarded per group)
+        const bool wide8 = s == 8 && (p.ct_crop & 3) == 0 && ((mt0 + MR) * 32 <= p.rows) && ((p.y_cs & 3) == 0) &&
+                           ((((uintptr_t)yb | (uintptr_t)y2b) & 15) == 0);
+        // stride 2: the 4 registers of a group are (channel, phase) = (c, 0), (c, 1), (c + 1, 0), (c + 1, 1) at one input position, i.e. two
+        // consecutive output samples of two channels -> two 8-byte stores
+        const bool wide2 = s == 2 && (p.ct_crop & 1) == 0 && ((mt0 + MR) * 32 <= p.rows) && ((p.y_cs & 1) == 0) &&
+                           ((((uintptr_t)yb | (uintptr_t)y2b) & 7) == 0);
         auto lr = [&](float v) __attribute__((always_inline)) { return fmaxf(v, v * p.post_slope); };
         if (wide8) {
 #pragma unroll
@@ -844,18 +850,56 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr) {
                         const int q = colbase + nr * 32;
+                        if (q >= ncols) continue;
                         const int n = 8 * q + rowoff - p.ct_crop;
                         const float o0 = acc[mr][nr][4 * g] + bias, o1 = acc[mr][nr][4 * g + 1] + bias, o2 = acc[mr][nr][4 * g + 2] + bias,
                                     o3 = acc[mr][nr][4 * g + 3] + bias;
-                        if (n + 3 < out_len) {
+                        if (n >= 0 && n + 3 < out_len) {
                             *reinterpret_cast<float4*>(yb + (int64_t)co * p.y_cs + n) = make_float4(o0, o1, o2, o3);
                             if (y2b) *reinterpret_cast<float4*>(y2b + (int64_t)co * p.y_cs + n) = make_float4(lr(o0), lr(o1), lr(o2), lr(o3));
                         } else {
                             const float o[4] = {o0, o1, o2, o3};
                             for (int e = 0; e < 4; ++e)
-                                if (n + e < out_len) {
+                                if (n + e >= 0 && n + e < out_len) {
                                     yb[(int64_t)co * p.y_cs + n + e] = o[e];
                                     if (y2b) y2b[(int64_t)co * p.y_cs + n + e] = lr(o[e]);
+                                }
+                        }
+                    }
+                }
+        } else if (wide2) {
+            float b2[MR][4][2];  // every bias before the first store (a load behind stores waits for them: one in-order vmcnt)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (mt0 + mr) * 16 + 4 * g + 2 * (lane >> 5);
+                    b2[mr][g][0] = p.bias ? p.bias[co] : 0.f;
+                    b2[mr][g][1] = p.bias ? p.bias[co + 1] : 0.f;
+                }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (mt0 + mr) * 16 + 4 * g + 2 * (lane >> 5);  // rows 32 (mt0 + mr) + 8 g + 4 h + {0..3} = channels co, co + 1
+                    const float bias0 = b2[mr][g][0], bias1 = b2[mr][g][1];
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int q = colbase + nr * 32;
+                        if (q >= ncols) continue;
+                        const int n = 2 * q - p.ct_crop;
+                        const float o[4] = {acc[mr][nr][4 * g] + bias0, acc[mr][nr][4 * g + 1] + bias0, acc[mr][nr][4 * g + 2] + bias1, acc[mr][nr][4 * g + 3] + bias1};
+                        if (n >= 0 && n + 1 < out_len) {
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                *reinterpret_cast<float2*>(yb + (int64_t)(co + c2) * p.y_cs + n) = make_float2(o[2 * c2], o[2 * c2 + 1]);
+                                if (y2b) *reinterpret_cast<float2*>(y2b + (int64_t)(co + c2) * p.y_cs + n) = make_float2(lr(o[2 * c2]), lr(o[2 * c2 + 1]));
+                            }
+                        } else {
+                            for (int e = 0; e < 4; ++e)
+                                if (n + (e & 1) >= 0 && n + (e & 1) < out_len) {
+                                    yb[(int64_t)(co + (e >> 1)) * p.y_cs + n + (e & 1)] = o[e];
+                                    if (y2b) y2b[(int64_t)(co + (e >> 1)) * p.y_cs + n + (e & 1)] = lr(o[e]);
                                 }
                         }
                     }
