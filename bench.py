@@ -564,10 +564,12 @@ def main():
             else:  # 16-bit operands: 16x the MFMA rate, the same bytes -> the conv is bound by HBM, not by the matrix cores
                 res["roofline"] = {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
             if args.arith != "f32":
-                # context for the 16-bit fractions: a register-only loop of v_mfma_f32_32x32x16_f16 on random operands sustains
-                # 1.96 PFLOP/s at 1.9-1.96 GHz on this chip (tools/mfma16_peak.hip) - the power budget, not the issue rate, sets the ceiling
-                res["roofline"]["sustained_mfma16_tflops_measured"] = 1960.0
-                res["roofline"]["sustained_note"] = "tools/mfma16_peak.hip, random operands, no memory traffic; `peak` stays the guide's dense figure"
+                # context for the 16-bit fractions: a register-only loop of v_mfma_f32_32x32x16_{f16,bf16} sustains 1.67 (f16) /
+                # 1.80 (bf16) PFLOP/s at 1.63 / 1.78 GHz on operands with random signs and exponents spread over 2^-7..2^0, 1.96 PFLOP/s on
+                # same-sign same-exponent operands (tools/mfma16_peak.hip) - the power budget, not the issue rate, sets the ceiling
+                res["roofline"]["sustained_mfma16_tflops_measured"] = 1800.0 if args.arith == "bf16" else 1670.0
+                res["roofline"]["sustained_note"] = ("tools/mfma16_peak.hip, operands with random signs and spread exponents, no memory traffic; "
+                                                     "`peak` stays the guide's dense figure")
             res["roofline"].update({"traffic": None, "kernel": dom_key, "avg_launch_ms": avg_ms, "launches": dom["calls"],
                                     "share_of_gpu_time": dom["ms"] / all_ms,
                                     "flop_accounting": "algorithmic: 2 * rows * c_in * taps * (sum over utterances of the real output length), not the padded grid",
