@@ -249,30 +249,57 @@ __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float*
 // ---------------------------------------------------------------------------------------------------------
 // The same attention core on the matrix cores (head_dim a multiple of 16): scores S = Q K^T and O = P V as 16 x 16 x 4 fp32 MFMAs
 // (v_mfma_f32_16x16x4_f32: the 16 queries of a block are M), softmax and the 2w+1 relative terms as above. The VALU kernel does
-// one LDS read per FMA and, for 1024-id inputs (2049 tokens), was the longest single entry of a 16-bit step.
+// one LDS read per FMA and, for 1024-id inputs, was the longest single entry of a 16-bit step.
 //   operand layouts (lane l): A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16], D[m = 4 * (l / 16) + r][n = l % 16], r = 0..3
-// Block = (utterance, head, 16 queries), 4 waves. Scores: wave w owns key tiles w, w + 4, ...; P V: wave w owns d tiles w, w + 4.
-// Every sum has ONE order for every grid (key tiles of 16, k-steps of 4 ascending), so results do not depend on the batch.
-// LDS: Q^T [hd][16] | q.Ek [16][nrel] | scores [16][lp], lp = 4 mod 64 (conflict-free A reads of P) | V chunk [hd][vc + 4].
+// Block = (utterance, head, 16 queries), NW = 4 or 8 waves (chosen by the launch, see launch_rel_attention). Scores: wave w owns key
+// tiles w, w + NW, ... and fetches the K operands of its next TWO tiles while it multiplies the current one (a tile is 24 x 32 cycles of
+// MFMA work, a load round trip several times that). P V: wave w owns d tiles w, w + NW and walks the keys in groups of 16: MFMA k-step 4 g + i of group g takes
+// keys 16 g + 4 (l / 16) + i, so that a lane's four k-steps are ONE 16-byte load of V (its row, 4 consecutive keys) and ONE
+// ds_read_b128 of P, four groups in flight. (Round 2: one K tile of look-ahead, a dword load of V per k-step consumed right behind its
+// issue, V staged through LDS for short inputs; per-block stamps at 1024 ids — tools/att_micro.hip — 28 us of scores and 61 us of P V
+// for 5 + 7 us of MFMA work, now 21 + 11.)
+// Every sum has ONE order for every grid, so results do not depend on the batch.
+// LDS: Q^T [hd][16] | q.Ek [16][nrel] | scores [16][lp], lp = 4 mod 64 (conflict-free A reads of P).
 // ---------------------------------------------------------------------------------------------------------
 typedef float att_float4v __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int att_lp(int len) { return (len + 63) / 64 * 64 + 4; }  // >= len + 4, = 4 (mod 64)
 
-__global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
-                                                                 int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
-                                                                 int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift) {
+#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/att_micro.hip): per-block phase stamps, 100 MHz clock
+__device__ unsigned long long vits_att_phase[8 * 65536];
+#define ATT_STAMP(k)                                                                                             \
+    do {                                                                                                         \
+        if (threadIdx.x == 0) {                                                                                  \
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
+            if (lin < 65536) vits_att_phase[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                   \
+        }                                                                                                        \
+    } while (0)
+#else
+#define ATT_STAMP(k)
+#endif
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 3) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+                                                                     int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
+                                                                     int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int v16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
+    constexpr int NT = 64 * NW;
+    // XCD-aware order: the dispatcher deals workgroups to the 8 XCDs round-robin by linear id and every XCD has its own L2. All query
+    // tiles of one (utterance, head) read the same K and V: every XCD gets a contiguous range of the order (query tile fastest, then
+    // head, then utterance), so that its L2 holds the K / V of a few (utterance, head) pairs instead of all of them (1024 ids: -10 %).
+    const unsigned gx = gridDim.x, gy = gridDim.y, nblk = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xc = lin & 7, slot = lin >> 3, qd = nblk >> 3, rm = nblk & 7;
+    const unsigned lg = xc * qd + (xc < rm ? xc : rm) + slot;
+    const int b = lg / (gx * gy), h = (lg / gx) % gy, i0 = (lg % gx) * ATT_Q;
     const int len = lens ? lens[b] : tmax;
     if (i0 >= len) return;
+    ATT_STAMP(0);
     const int hd = head_dim, nrel = 2 * window + 1;
     const int lp = att_lp(len);
-    float* qt = sm;                      // [hd][16]  (scaled)
-    float* qe = qt + hd * ATT_Q;         // [16][nrel]
-    float* sc = qe + ATT_Q * nrel;       // [16][lp]
-    const int vc = 1 << vshift, vp = vc + 4;
-    float* vt = sc + ATT_Q * att_lp(tmax);  // [hd][vp]
+    float* qt = sm;                 // [hd][16]  (scaled)
+    float* qe = qt + hd * ATT_Q;    // [16][nrel]
+    float* sc = sm + ((hd * ATT_Q + ATT_Q * nrel + 3) & ~3);  // [16][lp], 16-byte aligned rows (ds_read_b128 of P)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const float* qb = q + (int64_t)b * q_bs + (int64_t)h * hd * q_cs;
@@ -282,13 +309,13 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
         float tq[8];  // (head_dim <= 128: at most 8 elements per thread, all loads in flight)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             const int d = idx / ATT_Q, i = i0 + idx % ATT_Q;
             tq[u] = (idx < ATT_Q * hd && i < len) ? qb[(int64_t)d * q_cs + i] * q_scale : 0.f;  // scaling: vits.cpp:296-297
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (tid + u * 256 < ATT_Q * hd) qt[tid + u * 256] = tq[u];  // (idx = d * 16 + qi is the Q^T index)
+            if (tid + u * NT < ATT_Q * hd) qt[tid + u * NT] = tq[u];  // (idx = d * 16 + qi is the Q^T index)
     }
     __syncthreads();
     const int nsteps = hd >> 2;
@@ -300,7 +327,7 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
     for (int s2 = 0; s2 < MAXS; ++s2) qa[s2] = s2 < nsteps ? qt[(4 * s2 + lk) * ATT_Q + ln] : 0.f;
     // q_i . Ek[r] for the 2w+1 relative positions: one more 16 x 16 product per tile of 16 relative positions (one tile — wave 0 — for
     // windows up to 7, the MMS-TTS architecture has 4; wider windows take further tiles on the other waves)
-    for (int ct = wid; ct * 16 < nrel; ct += 4) {
+    for (int ct = wid; ct * 16 < nrel; ct += NW) {
         const int rcol = ct * 16 + ln;
         att_float4v acc = {0.f, 0.f, 0.f, 0.f};
         const float* rp = rel_k + (int64_t)(rcol < nrel ? rcol : 0) * hd + lk;
@@ -319,25 +346,22 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
         }
     }
     __syncthreads();
-    // ---- scores: S[16 q][16 keys] per key tile, K = hd ----
-    // (the K operands of key tile n + 4 are fetched while tile n is multiplied: a block of a 2049-token utterance is alone on its CU —
-    // one wave per SIMD — and a load -> MFMA sequence per tile exposed the memory latency 32 times per wave)
+    ATT_STAMP(1);
+    // ---- scores: S[16 q][16 keys] per key tile, K = hd; the K operands of this wave's next two tiles are in flight ----
     {
-        float bcur[MAXS], bnxt[MAXS];
+        float k0[MAXS], k1[MAXS], k2[MAXS];
         auto load_tile = [&](int n, float* dst) __attribute__((always_inline)) {
-            const int key = n * 16 + ln;
+            const int nc = n < ntiles ? n : ntiles - 1;  // (past the last tile: a valid address, values unused)
+            const int key = nc * 16 + ln;
             const float* kp = kb + (int64_t)lk * k_cs + (key < len ? key : len - 1);
 #pragma unroll
             for (int s2 = 0; s2 < MAXS; ++s2) dst[s2] = s2 < nsteps ? kp[(int64_t)(4 * s2) * k_cs] : 0.f;
         };
-        if (wid < ntiles) load_tile(wid, bcur);
-        for (int n = wid; n < ntiles; n += 4) {
-            const bool more = n + 4 < ntiles;
-            if (more) load_tile(n + 4, bnxt);
+        auto tile = [&](int n, const float* kop) __attribute__((always_inline)) {
             att_float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < MAXS; ++s2)
-                if (s2 < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s2], bcur[s2], acc, 0, 0, 0);
+                if (s2 < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s2], kop[s2], acc, 0, 0, 0);
             const int key = n * 16 + ln;
             if (key < len) {
 #pragma unroll
@@ -349,15 +373,33 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
                     sc[qi * lp + key] = sv;
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int s2 = 0; s2 < MAXS; ++s2) bcur[s2] = bnxt[s2];
-            }
+        };
+        int n = wid;
+        if (n < ntiles) {
+            load_tile(n, k0);
+            load_tile(n + NW, k1);
+        }
+        while (n < ntiles) {
+            load_tile(n + 2 * NW, k2);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(n, k0);
+            n += NW;
+            if (n >= ntiles) break;
+            load_tile(n + 2 * NW, k0);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(n, k1);
+            n += NW;
+            if (n >= ntiles) break;
+            load_tile(n + 2 * NW, k1);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(n, k2);
+            n += NW;
         }
     }
     __syncthreads();
-    // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole chunks) ----
-    {
+    ATT_STAMP(2);
+    // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole groups) ----
+    if (tid < 16 * ATT_Q) {
         const int qi = tid >> 4, l16 = tid & 15;
         float mx = -INFINITY;
         for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
@@ -374,87 +416,62 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
         for (int j = len + l16; j < lp; j += 16) sc[qi * lp + j] = 0.f;
     }
     __syncthreads();
-    // ---- O[16 q][hd] = P V: d tiles of 16, K = keys, V staged through LDS in chunks of vc keys ----
+    ATT_STAMP(3);
+    // ---- O[16 q][hd] = P V: d tile dt, K = keys in groups of 16 (see the head comment), four groups in flight ----
     const int ndt = hd >> 4;
-    att_float4v oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d tiles wid and wid + 4 (head_dim <= 128)
-    if (vshift < 5) {
-        // long sequences (the scores of 2049 tokens leave LDS for 8-16 keys of V per chunk: two barriers per 4 MFMA steps): V operands
-        // straight from memory instead — lane (k = key 4s + lk, n = d) reads v[d][key], 16 rows x 16 bytes per instruction, eight
-        // k-steps in flight. The same MFMA sequence as the staged loop (k-steps of 4 keys, ascending): same bits.
-        const int kst = (len + 3) >> 2;
+    const int ng = (len + 15) >> 4;
+    const int klast4 = (len - 1) & ~3;  // the last 16-byte piece of a row that starts inside the sequence (rows are padded to x4)
+    att_float4v oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d tiles wid and wid + NW (NW >= 4, head_dim <= 128)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int dt = wid + 4 * u;
-            if (dt < ndt) {
-                const float* pa = sc + ln * lp + lk;
-                const float* vrow = vb + (int64_t)(dt * 16 + ln) * v_cs;
-                att_float4v a4 = oacc[u];
-                for (int s0 = 0; s0 < kst; s0 += 8) {
-                    float av[8], bv[8];
+    for (int u = 0; u < 2; ++u) {
+        const int dt = wid + NW * u;
+        if (dt < ndt) {
+            const float* prow = sc + ln * lp + 4 * lk;
+            const float* vrow = vb + (int64_t)(dt * 16 + ln) * v_cs;
+            att_float4v pr[4], vr[4];
+            auto load_group = [&](int g, att_float4v& pa, att_float4v& vv) __attribute__((always_inline)) {
+                const int gc = g < ng ? g : ng - 1;
+                pa = *reinterpret_cast<const att_float4v*>(prow + 16 * gc);
+                const int key0 = 16 * gc + 4 * lk;
+                if (v16) {
+                    const att_float4v t = *reinterpret_cast<const att_float4v*>(vrow + (key0 < klast4 ? key0 : klast4));
+                    vv[0] = key0 < len ? t[0] : 0.f;
+                    vv[1] = key0 + 1 < len ? t[1] : 0.f;
+                    vv[2] = key0 + 2 < len ? t[2] : 0.f;
+                    vv[3] = key0 + 3 < len ? t[3] : 0.f;
+                } else {  // rows not 16-byte aligned (never in the engine; the operator entry point takes any stride): same values, four loads
 #pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8) {
-                        const int sx = s0 + w8 < kst ? s0 + w8 : kst - 1;
-                        const int key = 4 * sx + lk;
-                        av[w8] = pa[4 * sx];
-                        bv[w8] = key < len ? vrow[key] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = vrow[key0 + e < len ? key0 + e : len - 1];
+                        vv[e] = key0 + e < len ? t : 0.f;
                     }
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8)
-                        if (s0 + w8 < kst) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[w8], bv[w8], a4, 0, 0, 0);
                 }
-                oacc[u] = a4;
-            }
-        }
-    } else
-    for (int j0 = 0; j0 < len; j0 += vc) {
-        const int nj = len - j0 < vc ? len - j0 : vc;
-        for (int base = tid; base < (hd << vshift); base += 8 * 256) {  // eight loads in flight per thread
-            float tv[8];
+            };
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256;
-                const int d = idx >> vshift, jj = idx & (vc - 1);
-                tv[u] = (idx < (hd << vshift) && jj < nj) ? vb[(int64_t)d * v_cs + j0 + jj] : 0.f;
-            }
+            for (int i = 0; i < 4; ++i) load_group(i, pr[i], vr[i]);
+            att_float4v a4 = oacc[u];
+            for (int g = 0; g < ng; g += 4) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256;
-                if (idx < (hd << vshift)) vt[(idx >> vshift) * vp + (idx & (vc - 1))] = tv[u];
-            }
-        }
-        __syncthreads();
-        const int ks = (nj + 3) >> 2;  // k-steps of this chunk (P is zero beyond len, V is zero beyond nj)
+                for (int i = 0; i < 4; ++i) {
+                    const att_float4v pa = pr[i], vv = vr[i];
+                    load_group(g + 4 + i, pr[i], vr[i]);
+                    if (g + i < ng) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int dt = wid + 4 * u;
-            if (dt < ndt) {
-                const float* pa = sc + ln * lp + j0 + lk;
-                const float* pb = vt + (dt * 16 + ln) * vp + lk;
-                att_float4v a4 = oacc[u];
-                for (int s0 = 0; s0 < ks; s0 += 8) {
-                    float av[8], bv[8];
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8) {
-                        const int sx = s0 + w8 < ks ? s0 + w8 : ks - 1;
-                        av[w8] = pa[4 * sx];
-                        bv[w8] = pb[4 * sx];
+                        for (int e = 0; e < 4; ++e) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], vv[e], a4, 0, 0, 0);
                     }
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8)
-                        if (s0 + w8 < ks) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[w8], bv[w8], a4, 0, 0, 0);
                 }
-                oacc[u] = a4;
             }
+            oacc[u] = a4;
         }
-        __syncthreads();
     }
+    ATT_STAMP(4);
     // ---- + windowed relative-value term: O += Pwin[16 q][r] . Ev[r][d] with Pwin[q][r] = P[q][i_q + r - w] (zero outside the sequence
     // and for r >= 2w+1): (2w+1+3)/4 more k-steps per d tile ----
     {
         const int rsteps = (nrel + 3) >> 2;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int dt = wid + 4 * u;
+            const int dt = wid + NW * u;
             if (dt < ndt) {
                 att_float4v a4 = oacc[u];
                 for (int s = 0; s < rsteps; ++s) {
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
     float* ob = out + (int64_t)b * o_bs + (int64_t)h * hd * o_cs;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int dt = wid + 4 * u;
+        const int dt = wid + NW * u;
         if (dt >= ndt) continue;
         const int d = dt * 16 + ln;
 #pragma unroll
@@ -481,27 +498,35 @@ __global__ __launch_bounds__(256) void rel_attention_mfma_kernel(const float* q,
             if (i < len) ob[(int64_t)d * o_cs + i] = oacc[u][r];
         }
     }
+    ATT_STAMP(5);
 }
 
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
                                 int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s) {
     static const bool valu_only = getenv("VITS_ATT_VALU") != nullptr;
+    // matrix-core version. The number of waves (= how the key tiles and the d tiles are dealt out) does not change a single sum, so it may
+    // depend on the launch: four waves while two or more blocks fit the LDS of a CU (up to ~1200 tokens: 1024 ids 0.178 ms against 0.222
+    // with six waves), eight once the scores of a block leave room for one block only (2049 tokens: 0.87 against 1.29 ms with four)
+    const bool v_aligned = (v.cs & 3) == 0 && (v.bs & 3) == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
     if (!valu_only && (head_dim & 15) == 0 && head_dim <= 128) {
-        // matrix-core version (same kernel for every grid: results do not depend on the batch)
-        size_t ldsm = 0;
-        int vsh = 6;
-        for (; vsh >= 3; --vsh) {
-            ldsm = sizeof(float) * ((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + (size_t)ATT_Q * att_lp(tmax) + (size_t)head_dim * ((1 << vsh) + 4));
-            if (ldsm <= 150 * 1024) break;
-        }
-        if (ldsm <= 150 * 1024) {
-            if (ldsm > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
-                if (e != hipSuccess) return e;
-            }
+        const size_t ldsm = sizeof(float) * ((((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + 3) & ~(size_t)3) + (size_t)ATT_Q * att_lp(tmax));
+        if (ldsm <= 160 * 1024) {
             dim3 gridm((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
-            hipLaunchKernelGGL(rel_attention_mfma_kernel, gridm, dim3(256), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, out.cs,
-                               lens, head_dim, tmax, window, q_scale, vsh);
+            static const int nw_env = getenv("VITS_ATT_NW") ? atoi(getenv("VITS_ATT_NW")) : 0;
+            int nw = 2 * ldsm > 160 * 1024 ? 8 : 4;
+            if (nw_env == 4 || nw_env == 8) nw = nw_env;
+#define VITS_ATTM_LAUNCH(NW)                                                                                                                     \
+    do {                                                                                                                                         \
+        if (ldsm > 64 * 1024) {                                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
+            if (e != hipSuccess) return e;                                                                                                       \
+        }                                                                                                                                        \
+        hipLaunchKernelGGL(rel_attention_mfma_kernel<NW>, gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
+                           out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0);                                            \
+    } while (0)
+            if (nw == 4) VITS_ATTM_LAUNCH(4);
+            else VITS_ATTM_LAUNCH(8);
+#undef VITS_ATTM_LAUNCH
             return hipGetLastError();
         }
     }
