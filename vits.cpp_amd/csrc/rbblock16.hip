@@ -1,5 +1,5 @@
 // rbblock16.hip — one WHOLE HiFiGAN ResBlock (three conv pairs, dilations D0 / D1 / D2) as a single kernel, 16-bit-operand modes, the
-// narrow vocoder stages (C = 32 / 64):
+// narrow vocoder stages (C = 32 / 64; C = 128 for k = 3):
 //     y_{p+1} = y_p + Conv_{k,1}( leaky_relu( Conv_{k,D_p}( leaky_relu(y_p) ) + b1_p ) ) + b2_p ,  p = 0, 1, 2     (/root/reference/src/vits.cpp:545-581)
 //     out     = [sum of the previous resblocks +] y_3 [ * 1/num_kernels ]                                             (vits.cpp:622-635)
 // Why: in the 16-bit modes these stages are bound by HBM bytes (and, through the power budget, by the clock those bytes leave the matrix
@@ -9,7 +9,8 @@
 // tile for its 96 columns), the 16-bit conv inputs x_p = round(leaky_relu(y_p)) and t_p live in ONE LDS tile that the phases take turns
 // in, and HBM sees the stage input once (4 B, + halo) and the resblock output once (4 B, + 4 B accumulator, + 2 B 16-bit copy on the last
 // resblock): 10-14 B per element and resblock instead of 36. The price is the halo: a tile of W = 384 columns yields W - 24 (k - 1) / 2
-// outputs (k = 3: 360, 7: 312, 11: 264), i.e. 1.07 / 1.23 / 1.45 x the MFMA work, which these stages have to spare.
+// outputs (k = 3: 360, 7: 312, 11: 264), i.e. 1.07 / 1.23 / 1.45 x the MFMA work, which these stages have to spare (C = 64 runs 256-column
+// tiles on four waves, 1.10 / 1.39 x, so that two blocks share a CU: see launch_rbblock16).
 // Same operands, rounding points and k-order of accumulation (chunk, tap, k-half) as rbpair16_kernel / conv16_kernel: bit-identical to
 // the pair path (GPU test), which stays for C >= 128 (MFMA-bound: the halo would cost more than the bytes) and behind VITS_NO_RBBLOCK16=1.
 #include <hip/hip_runtime.h>
@@ -88,7 +89,7 @@ __device__ unsigned long long vits_rbb_phase[16 * 65536];
 // Block = NSTRIP column strips x C / (32 MRW) row groups of waves; wave (strip, rg) owns the MRW row tiles [MRW rg, MRW rg + MRW) (32 rows each)
 // of the NRW 32-column tiles of its strip.
 template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF>
-__global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : 1) void rbblock16_kernel(const RbBlockParams p) {
+__global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : (C / (32 * MRW) * NSTRIP <= 4 ? 2 : 1)) void rbblock16_kernel(const RbBlockParams p) {
     using namespace rbb;
     constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
     constexpr int P2 = (KT - 1) / 2;
@@ -387,18 +388,23 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
     p.scale = c.scale;
     p.scale_div = c.scale_div;
     const bool bf = arith == VITS_ARITH_BF16;
-    // tile shape (column strips x 32-column tiles per wave): 4 x 3 = 384 columns. Measured alternatives (batch 64 x 128 ids, f16): C = 32 with
-    // 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 6 x 2 (twelve waves) +-0, as 8 x 2 = 512 columns
-    // (sixteen waves at 128 VGPRs, spills) -5 % on k = 11 only.
+    // tile shape (column strips x 32-column tiles per wave): C = 32: 4 x 3 = 384 columns, three blocks per CU. Measured alternatives (batch
+    // 64 x 128 ids, f16): C = 32 with 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 4 x 3 (eight waves, one
+    // block per CU: round 3's first version), as 6 x 2 (twelve waves) +-0, as 8 x 2 = 512 columns (sixteen waves at 128 VGPRs, spills) -5 %
+    // on k = 11 only, as 2 x 5 (spills) worse than 2 x 4.
 #define VITS_RBB_GO(K, CC, NS, NRW_, MRW_)                                                              \
     if (kt == K && C == CC) return bf ? launch_rbb<K, CC, NS, NRW_, MRW_, true>(p, c.batch, s) : launch_rbb<K, CC, NS, NRW_, MRW_, false>(p, c.batch, s)
     VITS_RBB_GO(3, 32, 4, 3, 1);
     VITS_RBB_GO(7, 32, 4, 3, 1);
     VITS_RBB_GO(11, 32, 4, 3, 1);
-    VITS_RBB_GO(3, 64, 4, 3, 1);
-    VITS_RBB_GO(7, 64, 4, 3, 1);
+    // C = 64: four waves (two strips of four column tiles, 256 columns) instead of eight (4 x 3): at 236 VGPRs two blocks share a CU and
+    // one's loads, tile writes and epilogue overlap the other's MFMA phases — with eight waves a CU ran ONE block at a time, its matrix
+    // pipes 30 % busy at 1.4 TB/s: k = 3 0.70 -> 0.55 ms, k = 7 1.09 -> 1.05 (the narrower tile costs 1.39 x instead of 1.23 x the MFMA work there)
+    VITS_RBB_GO(3, 64, 2, 4, 1);
+    VITS_RBB_GO(7, 64, 2, 4, 1);
     VITS_RBB_GO(11, 64, 4, 3, 1);
-    // C = 128, k = 3: the pairs are HBM-bound (4.4 TB/s); eight waves of two row tiles x two column tiles (256-column tiles, 232 outputs)
+    // C = 128, k = 3: the pairs are HBM-bound (4.4 TB/s); eight waves of two row tiles x two column tiles (256-column tiles, 232 outputs).
+    // (Eight waves of one row tile on 128-column tiles at 128 VGPRs — two blocks per CU —, sixteen waves on 256 columns, eight on 192: +-2 %.)
     VITS_RBB_GO(3, 128, 4, 2, 2);
 #undef VITS_RBB_GO
     return hipErrorInvalidValue;
