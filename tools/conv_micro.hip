@@ -54,6 +54,9 @@ int main() {
 #ifdef WITH_RES
     c.res = c.x;
 #endif
+#ifdef TILE_
+    c.tile = TILE_;
+#endif
     c.batch = B; c.t_in = c.t_out = T; c.dil = DIL_; c.pad_l = (K - 1) * DIL_ / 2; c.pre_act = PRE_; c.slope = 0.1f;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i) launch_conv(pc, c, nullptr);

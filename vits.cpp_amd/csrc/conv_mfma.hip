@@ -1188,7 +1188,10 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
             const int64_t mb = (w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr);
             return nb * mb * c.batch;
         };
-        static const int64_t min_blocks = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 512;
+        // (k <= 3: 1024 — a short K loop costs a small tile little, and e.g. the encoder's 192 -> 768 FFN conv at batch 64 x 128 tokens is
+        // 768 blocks of 64 x 128 = 1.5 rounds of the 512 resident blocks, but 3 even rounds of 32 x 128: 82 -> 74 us)
+        static const int64_t min_blocks_env = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 0;
+        const int64_t min_blocks = min_blocks_env > 0 ? min_blocks_env : (w.kt <= 3 ? 1024 : 512);
         if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
         if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
     }
@@ -1202,7 +1205,11 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
         const TileShape t2 = tile_shape(tile);
         const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
-        if (!no_narrow && shape_ok && nb <= 128) tile = TILE_NARROW;
+        // 1x1 convs on short sequences (QKV / output / projection convs of the encoder, the flow's pre / post convs): the narrow tile on
+        // large grids too — 192 -> 576 at batch 64 x 128 tokens 34 -> 26 us, 192 -> 192 21 -> 13 us (VITS_NARROW_K1=0: small grids only)
+        static const int narrow_k1 = getenv("VITS_NARROW_K1") ? atoi(getenv("VITS_NARROW_K1")) : 256;
+        const bool k1_short = narrow_k1 > 0 && w.epi == EPI_STD && w.kt == 1 && ncols_max <= narrow_k1;
+        if (!no_narrow && shape_ok && (nb <= 128 || k1_short)) tile = TILE_NARROW;
     }
     return tile;
 }
