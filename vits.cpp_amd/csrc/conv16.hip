@@ -507,8 +507,8 @@ __global__ void to_group16_kernel(const float* __restrict__ x, int64_t x_bs, int
 hipError_t launch_to_group16(TensorRef x, const int* lens, int batch, int channels, int tmax, float slope, Ref16 y, int arith, hipStream_t s) {
     if (tmax <= 0 || batch <= 0) return hipSuccess;
     dim3 grid((tmax + 63) / 64, (channels + 7) / 8, batch);
-    if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL(to_group16_kernel<true>, grid, dim3(64), 0, s, x.p, x.bs, x.cs, lens, tmax, channels, slope, y.p, y.bs, y.ts);
-    else hipLaunchKernelGGL(to_group16_kernel<false>, grid, dim3(64), 0, s, x.p, x.bs, x.cs, lens, tmax, channels, slope, y.p, y.bs, y.ts);
+    if (arith == VITS_ARITH_BF16) VITS_KLAUNCH(to_group16_kernel<true>, grid, dim3(64), 0, s, x.p, x.bs, x.cs, lens, tmax, channels, slope, y.p, y.bs, y.ts);
+    else VITS_KLAUNCH(to_group16_kernel<false>, grid, dim3(64), 0, s, x.p, x.bs, x.cs, lens, tmax, channels, slope, y.p, y.bs, y.ts);
     return hipGetLastError();
 }
 
@@ -550,9 +550,9 @@ hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef
     dim3 grid((tmax + 255) / 256, batch);
     const size_t lds = (size_t)cin * k * sizeof(float);
     if (arith == VITS_ARITH_BF16)
-        hipLaunchKernelGGL(conv_post16_kernel<true>, grid, dim3(256), lds, s, x.p, x.bs, x.ts, w, cin, k, pre.p, pre.bs, wave.p, wave.bs, lens, tmax, emit_lo, emit_hi);
+        VITS_KLAUNCH(conv_post16_kernel<true>, grid, dim3(256), lds, s, x.p, x.bs, x.ts, w, cin, k, pre.p, pre.bs, wave.p, wave.bs, lens, tmax, emit_lo, emit_hi);
     else
-        hipLaunchKernelGGL(conv_post16_kernel<false>, grid, dim3(256), lds, s, x.p, x.bs, x.ts, w, cin, k, pre.p, pre.bs, wave.p, wave.bs, lens, tmax, emit_lo, emit_hi);
+        VITS_KLAUNCH(conv_post16_kernel<false>, grid, dim3(256), lds, s, x.p, x.bs, x.ts, w, cin, k, pre.p, pre.bs, wave.p, wave.bs, lens, tmax, emit_lo, emit_hi);
     return hipGetLastError();
 }
 
@@ -649,7 +649,7 @@ static hipError_t launch_tile16(int tile, const Conv16Params& p, int mtiles_used
             if (ea != hipSuccess) return ea;                                                                                         \
             big_lds_set.store(true, std::memory_order_release);                                                                      \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv16_kernel<KT, DIL, WM, WN, MR, NR, EPI, kBF>), grid, dim3(320), lds, s, p);                          \
+        VITS_KLAUNCH((conv16_kernel<KT, DIL, WM, WN, MR, NR, EPI, kBF>), grid, dim3(320), lds, s, p);                          \
     } while (0)
     // which tiles exist for which epilogue: the standard-layout epilogues (stage one, flow, transparent fallback) only come in the
     // 64- and 32-row tiles; the gate needs MR == 2; run-time-dilation variants skip the 128 x 256 tile

@@ -1053,7 +1053,7 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
             if (ea != hipSuccess) return ea;                                                                                          \
             big_lds_set.store(true, std::memory_order_release);                                                                                                 \
         }                                                                                                                             \
-        hipLaunchKernelGGL((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(DB ? 320 : 256), lds, s, p);                             \
+        VITS_KLAUNCH((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(DB ? 320 : 256), lds, s, p);                             \
     } while (0)
     switch (tile) {
         case TILE_128x128:
@@ -1159,7 +1159,7 @@ hipError_t launch_conv_group(const PackedConv* const* w, const ConvCall* c, int 
             if (ea != hipSuccess) return ea;                                                                                              \
             big_lds_set.store(true, std::memory_order_release);                                                                           \
         }                                                                                                                                 \
-        hipLaunchKernelGGL((conv_group_kernel<D>), grid, dim3(320), lds, s, g);                                                           \
+        VITS_KLAUNCH((conv_group_kernel<D>), grid, dim3(320), lds, s, g);                                                           \
     } while (0)
     if (c[0].dil == 1) VITS_GROUP_LAUNCH(1);
     else if (c[0].dil == 3) VITS_GROUP_LAUNCH(3);

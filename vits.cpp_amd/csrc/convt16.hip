@@ -381,7 +381,7 @@ static hipError_t launch_ct(const ConvT16Params& p, int ncols_max, int batch, hi
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((ncols_max + BN - 1) / BN, batch);
-    hipLaunchKernelGGL((convt16_kernel<NR, CSPLIT, RS, BF>), grid, dim3(256), lds, s, p);
+    VITS_KLAUNCH((convt16_kernel<NR, CSPLIT, RS, BF>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -429,7 +429,7 @@ hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int a
                 big_lds_set.store(true, std::memory_order_release);
             }
             dim3 grid((ncols_max + BN - 1) / BN, c.batch);
-            hipLaunchKernelGGL((convt16_lines_kernel<BN, BFv>), grid, dim3(256), lds, s, p);
+            VITS_KLAUNCH((convt16_lines_kernel<BN, BFv>), grid, dim3(256), lds, s, p);
             return hipGetLastError();
         };
         if (w.cin > 256) return bf ? go(std::integral_constant<int, 64>{}, std::true_type{}) : go(std::integral_constant<int, 64>{}, std::false_type{});

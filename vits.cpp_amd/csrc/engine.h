@@ -31,7 +31,9 @@ struct Profiler {
         hipEvent_t a, b;
         double flop, bytes;
         bool a_shared;  // a is the previous record's b (back-to-back launches share one event)
+        hipEvent_t spare = nullptr;  // dispatch-attached stop event that a multi-launch span replaced by a recorded one
     };
+    bool attach = true;  // events ride on the kernel's dispatch packet (kernels.h: LaunchTimer); false: hipEventRecord around every launch
     bool on = false;
     std::vector<std::string> names;
     std::unordered_map<std::string, int> ids;
@@ -119,6 +121,7 @@ struct Knobs {
     bool no_fuse32 = false;      // VITS_NO_FUSE32: fp32 resblock conv pairs as two launches
     bool no_rb_group = false;    // VITS_NO_RB_GROUP: the resblocks of a stage as separate launches (no grouped launch)
     bool rb_group_always = false;  // VITS_RB_GROUP=1: grouped launches also when the three streams are available
+    bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
     void read();
 };
 

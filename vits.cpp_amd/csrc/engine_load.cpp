@@ -217,6 +217,7 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         return false;
     }
     knobs.read();
+    prof.attach = knobs.prof_attach;
     if (knobs.rb_streams > 1 && !dry_run_) {
         bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
         for (auto& s : side_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;

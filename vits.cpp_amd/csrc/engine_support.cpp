@@ -35,6 +35,7 @@ void Knobs::read() {
     no_fuse32 = flag("VITS_NO_FUSE32");
     no_rb_group = flag("VITS_NO_RB_GROUP");
     rb_group_always = flag("VITS_RB_GROUP");
+    if (const char* e = std::getenv("VITS_PROF_ATTACH")) prof_attach = std::atoi(e) != 0;
 }
 
 // ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----
@@ -108,6 +109,13 @@ void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s,
         agg.emplace_back();
     } else
         id = it->second;
+    if (attach) {
+        Rec r{id, get(), get(), flop, bytes, false};
+        recs.push_back(r);
+        vits_launch_timer = LaunchTimer{r.a, r.b, 0};  // the next launch of this thread takes them along
+        last_ok = false;
+        return;
+    }
     const bool share = chain && last_ok && last_s == s;
     Rec r{id, share ? last_b : get(), get(), flop, bytes, share};
     if (!share) hipEventRecord(r.a, s);
@@ -116,6 +124,20 @@ void Profiler::begin(const char* name, double flop, double bytes, hipStream_t s,
 }
 void Profiler::end(hipStream_t s) {
     if (!on || recs.empty()) return;
+    if (attach) {
+        LaunchTimer& lt = vits_launch_timer;
+        Rec& r = recs.back();
+        if (lt.start == r.a && lt.launches != 1) {
+            // several launches in one span: the start is the first kernel's, the stop a recorded event behind the last one (the attached stop
+            // event belongs to the first dispatch). No launch at all: both recorded here (an empty span).
+            if (lt.launches == 0) hipEventRecord(r.a, s);
+            r.spare = r.b;
+            r.b = get();
+            hipEventRecord(r.b, s);
+        }
+        lt = LaunchTimer{};
+        return;
+    }
     hipEventRecord(recs.back().b, s);
     last_b = recs.back().b;
     last_s = s;
@@ -133,6 +155,7 @@ void Profiler::collect() {
         }
         if (!r.a_shared) pool.push_back(r.a);
         pool.push_back(r.b);
+        if (r.spare) pool.push_back(r.spare);
     }
     recs.clear();
     last_ok = false;

@@ -7,11 +7,31 @@
 // behave exactly like the zero padding a batch-1 run sees) and stores beyond it are suppressed.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <vector>
 
 namespace vits {
+
+// Per-launch timing without extra queue packets. The engine's per-kernel profiler (bench.py's instrumented region) used to bracket
+// every launch with hipEventRecord: a barrier packet each, ~300 of them per step, 1.3 ms of a 77 ms step. When the profiler has armed
+// this thread's timer, the next kernel launch carries the two events on its OWN dispatch packet instead (hipExtLaunchKernel: start / end
+// timestamps of the kernel's completion signal — the same clock rocprofv3 reads), and only a span that launches several kernels falls
+// back to a recorded stop event (Profiler::end).
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int launches = 0;
+};
+inline thread_local LaunchTimer vits_launch_timer;
+#define VITS_KLAUNCH(kernel, grid, block, lds, stream, ...)                                                          \
+    do {                                                                                                            \
+        ::vits::LaunchTimer& lt_ = ::vits::vits_launch_timer;                                                       \
+        if (lt_.start && lt_.launches++ == 0)                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, lt_.start, lt_.stop, 0, __VA_ARGS__);           \
+        else                                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
+    } while (0)
 
 #ifdef __HIPCC__
 // The WaveNet gate tanh(a) * sigmoid(s) (vits.cpp:442-450) of every gated-conv epilogue (conv_mfma.hip, conv16.hip, wavenet32.hip), libm's

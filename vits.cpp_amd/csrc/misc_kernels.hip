@@ -28,7 +28,7 @@ __global__ void embed_kernel(const int* ids, int id_stride, const int* lens, con
 hipError_t launch_embed(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, TensorRef x, int batch, int tmax,
                         hipStream_t s) {
     dim3 grid((tmax + 63) / 64, hidden, batch);
-    hipLaunchKernelGGL(embed_kernel, grid, dim3(64), 0, s, ids, id_stride, lens, table, hidden, scale, x.p, x.bs, x.cs, tmax);
+    VITS_KLAUNCH(embed_kernel, grid, dim3(64), 0, s, ids, id_stride, lens, table, hidden, scale, x.p, x.bs, x.cs, tmax);
     return hipGetLastError();
 }
 
@@ -40,7 +40,7 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+    VITS_KLAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
     return hipGetLastError();
 }
 
@@ -521,7 +521,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
             if (e != hipSuccess) return e;                                                                                                       \
         }                                                                                                                                        \
-        hipLaunchKernelGGL(rel_attention_mfma_kernel<NW>, gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
+        VITS_KLAUNCH(rel_attention_mfma_kernel<NW>, gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
                            out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0);                                            \
     } while (0)
             if (nw == 4) VITS_ATTM_LAUNCH(4);
@@ -546,7 +546,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                                                  \
         }                                                                                                                                   \
-        hipLaunchKernelGGL(rel_attention_kernel<T>, grid, dim3(T), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, \
+        VITS_KLAUNCH(rel_attention_kernel<T>, grid, dim3(T), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, \
                            out.cs, lens, head_dim, tmax, window, q_scale, vshift);                                                         \
     } while (0)
     if (small_grid) VITS_ATT_LAUNCH(1024);
@@ -645,7 +645,7 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
         if (e != hipSuccess) return e;
     }
     dim3 grid((tmax + 63) / 64, batch);
-    hipLaunchKernelGGL(add_layer_norm_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
+    VITS_KLAUNCH(add_layer_norm_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
                        add_to.cs, lens, channels, tmax, eps, post_gelu);
     return hipGetLastError();
 }
@@ -739,7 +739,7 @@ hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const 
         if (e != hipSuccess) return e;
     }
     dim3 grid((tmax + 63) / 64, batch);
-    hipLaunchKernelGGL(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
+    VITS_KLAUNCH(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
                        k, dil, eps, arith);
     return hipGetLastError();
 }
@@ -1135,7 +1135,7 @@ hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const f
             if (e != hipSuccess) return e;                                                                                             \
             big.store(true, std::memory_order_release);                                                                                \
         }                                                                                                                              \
-        hipLaunchKernelGGL((dds_layer_kernel<A, M>), grid, dim3(32 * LN_GROUPS), lds, s, p);                                           \
+        VITS_KLAUNCH((dds_layer_kernel<A, M>), grid, dim3(32 * LN_GROUPS), lds, s, p);                                           \
     } while (0)
 #define VITS_DDS_LAUNCH(A)                       \
     do {                                         \
@@ -1166,7 +1166,7 @@ __global__ void pointwise_from1_kernel(const float* z, int64_t z_bs, int z_cs, i
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch, int channels,
                                   int tmax, hipStream_t s, int arith) {
     dim3 grid((tmax + 63) / 64, channels, batch);
-    hipLaunchKernelGGL(pointwise_from1_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, zc, w, bias, cond.p, cond.bs, cond.cs, y.p, y.bs, y.cs, lens, tmax, arith);
+    VITS_KLAUNCH(pointwise_from1_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, zc, w, bias, cond.p, cond.bs, cond.cs, y.p, y.bs, y.cs, lens, tmax, arith);
     return hipGetLastError();
 }
 
@@ -1177,7 +1177,7 @@ __global__ void fill_rows_kernel(float* x, int64_t bs, int cs, float v, int tmax
 }
 hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s) {
     dim3 grid((tmax + 255) / 256, channels, batch);
-    hipLaunchKernelGGL(fill_rows_kernel, grid, dim3(256), 0, s, x.p, x.bs, x.cs, v, tmax);
+    VITS_KLAUNCH(fill_rows_kernel, grid, dim3(256), 0, s, x.p, x.bs, x.cs, v, tmax);
     return hipGetLastError();
 }
 
@@ -1295,7 +1295,7 @@ __global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, 
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode, hipStream_t s) {
     if (bins > MAX_BINS) return hipErrorInvalidValue;
     dim3 grid((tmax + 63) / 64, batch);
-    hipLaunchKernelGGL(spline_kernel, grid, dim3(64), 0, s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt, mode);
+    VITS_KLAUNCH(spline_kernel, grid, dim3(64), 0, s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt, mode);
     return hipGetLastError();
 }
 
@@ -1312,7 +1312,7 @@ __global__ void affine_kernel(float* z, int64_t z_bs, int z_cs, int c_first, con
 hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
                          hipStream_t s) {
     dim3 grid((tmax + 63) / 64, 2, batch);
-    hipLaunchKernelGGL(affine_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, c_first, translate, log_scale, sign, lens, tmax);
+    VITS_KLAUNCH(affine_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, c_first, translate, log_scale, sign, lens, tmax);
     return hipGetLastError();
 }
 
@@ -1325,7 +1325,7 @@ __global__ void noise_dur_kernel(float* z, int64_t z_bs, int z_cs, const int* le
 }
 hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, const int* seed_off, float scale, hipStream_t s) {
     dim3 grid((tmax + 63) / 64, 2, batch);
-    hipLaunchKernelGGL(noise_dur_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, lens, tmax, seed, seed_off, scale);
+    VITS_KLAUNCH(noise_dur_kernel, grid, dim3(64), 0, s, z.p, z.bs, z.cs, lens, tmax, seed, seed_off, scale);
     return hipGetLastError();
 }
 
@@ -1336,7 +1336,7 @@ __global__ void scale_rows_kernel(float* x, int64_t bs, int cs, float scale, int
 }
 hipError_t launch_scale_rows(TensorRef x, int channels, float scale, int batch, int tmax, hipStream_t s) {
     dim3 grid((tmax + 63) / 64, channels, batch);
-    hipLaunchKernelGGL(scale_rows_kernel, grid, dim3(64), 0, s, x.p, x.bs, x.cs, scale, tmax);
+    VITS_KLAUNCH(scale_rows_kernel, grid, dim3(64), 0, s, x.p, x.bs, x.cs, scale, tmax);
     return hipGetLastError();
 }
 
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64
 
 hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
                             int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s) {
-    hipLaunchKernelGGL(durations_kernel, dim3(batch), dim3(256), 0, s, logw.p, logw.bs, logw.cs, c, lens, tmax, length_scale, fixed, dur, cum, frames, stage_lens,
+    VITS_KLAUNCH(durations_kernel, dim3(batch), dim3(256), 0, s, logw.p, logw.bs, logw.cs, c, lens, tmax, length_scale, fixed, dur, cum, frames, stage_lens,
                        n_stage, stage_mul, stage_add, batch);
     return hipGetLastError();
 }
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(256) void zp_kernel(const float* mean, int64_t m_bs
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
                      uint64_t seed, const int* seed_off, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s) {
     dim3 grid((lmax + 255) / 256, batch, 16);
-    hipLaunchKernelGGL(zp_kernel, grid, dim3(256), 0, s, mean.p, mean.bs, mean.cs, logvar.p, logvar.bs, logvar.cs, cum, cum_stride, tok_lens, frames, noise.p,
+    VITS_KLAUNCH(zp_kernel, grid, dim3(256), 0, s, mean.p, mean.bs, mean.cs, logvar.p, logvar.bs, logvar.cs, cum, cum_stride, tok_lens, frames, noise.p,
                        noise.bs, noise.cs, noise_kind, seed, seed_off, noise_scale, zp.p, zp.bs, zp.cs, channels, cum_stride);
     return hipGetLastError();
 }
@@ -1549,7 +1549,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, int64_t 
 hipError_t launch_conv_post(TensorRef x, const float* w, int cin, int k, float slope, TensorRef pre_tanh, TensorRef wave, const int* lens, int batch, int tmax,
                             hipStream_t s, int emit_lo, const int* emit_hi, int arith) {
     dim3 grid((std::max(tmax - emit_lo, 1) + 1023) / 1024, batch);
-    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * cin * k, s, x.p, x.bs, x.cs, w, cin, k, slope, pre_tanh.p, pre_tanh.bs, wave.p, wave.bs,
+    VITS_KLAUNCH(conv_post_kernel, grid, dim3(256), sizeof(float) * cin * k, s, x.p, x.bs, x.cs, w, cin, k, slope, pre_tanh.p, pre_tanh.bs, wave.p, wave.bs,
                        lens, tmax, emit_lo, emit_hi, arith);
     return hipGetLastError();
 }
@@ -1586,7 +1586,7 @@ hipError_t launch_pcm16(const float* src, int64_t src_stride, int16_t* dst, int6
     if (rows <= 0 || cols <= 0) return hipSuccess;
     const int vec = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (src_stride & 3) == 0 && (dst_stride & 7) == 0;
     dim3 grid((unsigned)((cols + 2047) / 2048), rows);
-    hipLaunchKernelGGL(pcm16_kernel, grid, dim3(256), 0, s, src, src_stride, reinterpret_cast<short*>(dst), dst_stride, lens, cols, vec);
+    VITS_KLAUNCH(pcm16_kernel, grid, dim3(256), 0, s, src, src_stride, reinterpret_cast<short*>(dst), dst_stride, lens, cols, vec);
     return hipGetLastError();
 }
 

@@ -344,7 +344,7 @@ static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
+    VITS_KLAUNCH((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
     return hipGetLastError();
 }
 

@@ -395,7 +395,7 @@ static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(ROWS ? 2 * C : 256), lds, s, p);
+    VITS_KLAUNCH((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(ROWS ? 2 * C : 256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -236,7 +236,7 @@ static hipError_t launch_rb32(const RbPair32Params& p, int batch, hipStream_t s)
         big_lds_set.store(true, std::memory_order_release);
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
-    hipLaunchKernelGGL((rbpair32_kernel<KT, DIL, C>), grid, dim3(256), ldsz, s, p);
+    VITS_KLAUNCH((rbpair32_kernel<KT, DIL, C>), grid, dim3(256), ldsz, s, p);
     return hipGetLastError();
 }
 

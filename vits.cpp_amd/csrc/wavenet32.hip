@@ -514,7 +514,7 @@ hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const Wa
     constexpr int XWP = (64 + KT - 1 + 3 + 3) / 4 * 4;
     const size_t ldsz = ((size_t)H * XWP * sizeof(float) + 1023) / 1024 * 1024;
     dim3 grid((c.tmax + 63) / 64, c.batch);
-    hipLaunchKernelGGL((wavenet32_kernel<H, KT>), grid, dim3(4 * H), ldsz, s, p);
+    VITS_KLAUNCH((wavenet32_kernel<H, KT>), grid, dim3(4 * H), ldsz, s, p);
     return hipGetLastError();
 }
 
@@ -552,11 +552,11 @@ hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const Wa
     dim3 grid((c.tmax + 63) / 64, c.batch);
     static const int ncw = getenv("VITS_WN16_NCW") ? atoi(getenv("VITS_WN16_NCW")) : 1;  // (2: six waves, both column tiles each — measured 40.6 vs 38.4 us per layer)
     if (ncw == 1) {
-        if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true, 1>), grid, dim3(4 * H), ldsz, s, p);
-        else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false, 1>), grid, dim3(4 * H), ldsz, s, p);
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((wavenet16_kernel<H, KT, true, 1>), grid, dim3(4 * H), ldsz, s, p);
+        else VITS_KLAUNCH((wavenet16_kernel<H, KT, false, 1>), grid, dim3(4 * H), ldsz, s, p);
     } else {
-        if (arith == VITS_ARITH_BF16) hipLaunchKernelGGL((wavenet16_kernel<H, KT, true, 2>), grid, dim3(2 * H), ldsz, s, p);
-        else hipLaunchKernelGGL((wavenet16_kernel<H, KT, false, 2>), grid, dim3(2 * H), ldsz, s, p);
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((wavenet16_kernel<H, KT, true, 2>), grid, dim3(2 * H), ldsz, s, p);
+        else VITS_KLAUNCH((wavenet16_kernel<H, KT, false, 2>), grid, dim3(2 * H), ldsz, s, p);
     }
     return hipGetLastError();
 }
