@@ -111,6 +111,22 @@ def test_rel_attention_other_window_sizes_match_oracle(pkg, oracle, w):
             assert rel_err(og[i, :, :lens[i]], orf[i, :, :lens[i]]) < TOL, (w, T, i)
 
 
+@pytest.mark.parametrize("hd", [16, 64, 128])
+def test_rel_attention_other_head_sizes_match_oracle(pkg, oracle, hd):
+    """head_dim / 16 = the number of 16-channel d tiles of the P.V product (1, 4, 8): the waves of a block take d tiles w and w + NW, and a
+    16-byte aligned stride (T = 260) takes the vector loads of V, any other one the scalar loads (same values, same order)."""
+    rng = np.random.default_rng(200 + hd)
+    heads, w = 2, 4
+    for T in (9, 260, 1300):
+        q, k, v = rnd(rng, 2, heads * hd, T, scale=0.3), rnd(rng, 2, heads * hd, T, scale=0.3), rnd(rng, 2, heads * hd, T)
+        rk, rv = rnd(rng, 2 * w + 1, hd, scale=0.1), rnd(rng, 2 * w + 1, hd, scale=0.1)
+        lens = np.array([T, max(1, T - 5)], np.int32)
+        og = pkg.op_rel_attention(q, k, v, rk, rv, heads, w, lens=lens)
+        orf = oracle.rel_attention(q, k, v, rk, rv, heads, w, lens=lens)
+        for i in range(2):
+            assert rel_err(og[i, :, :lens[i]], orf[i, :, :lens[i]]) < TOL, (hd, T, i)
+
+
 def test_rel_attention_does_not_depend_on_the_longest_member_of_the_batch(pkg):
     """The attention kernel sizes its LDS by the longest utterance of the batch and, for very long ones, takes the V operands of the
     P.V product straight from memory instead of staging them through LDS: a 300-token utterance must come out bit-identical whether it
