@@ -59,6 +59,8 @@ def test_kernel_names_map_to_the_keys_the_engine_prints():
         "void vits::rbpair32_kernel<3, 5, 32>(vits::RbPair32Params)": "k3|d5|f32|e0",
         "void vits::wavenet32_kernel<192, 5>(vits::WaveNet32Params)": "k5|d1|w192|e1",
         "void vits::wavenet16_kernel<192, 5, false>(vits::WaveNet16Params)": "k5|d1|W192|e1",
+        "void vits::wavenet16_kernel<192, 5, true, 1>(vits::WaveNet16Params)": "k5|d1|W192|e1",
+        "void vits::flow_couple16_kernel<false>(vits::FlowCouple16Params)": "k5|d1|C192|e1",
         "void vits::conv_group_kernel<3>(vits::ConvGroupParams)": "kG|d3|G0|e0",
         "void vits::rbblock16_kernel<11, 64, 1, 3, 5, false>(vits::RbBlockParams)": "k11|d135|B64|e0g",
     }

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1, 4, 1, 1): 4, (4, 1, 1, 1): 5}
 _CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
 _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
-_WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)>")
+_WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)(?:, \d+)?>")
+_COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
 _RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
 _CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\w+)>")
@@ -36,6 +37,9 @@ def bench_key(kernel_name):
     if m:  # `wavenet16_kernel<192, 5, false>` -> `k5|d1|W192|e1`
         h, kt, _ = m.groups()
         return f"k{kt}|d1|W{h}|e1"
+    m = _COUPLE16.search(kernel_name)
+    if m:  # `flow_couple16_kernel<false>` -> `k5|d1|C192|e1` (one whole coupling layer of the flow)
+        return "k5|d1|C192|e1"
     m = _WAVENET32.search(kernel_name)
     if m:  # `wavenet32_kernel<192, 5>` -> `k5|d1|w192|e1`
         h, kt = m.groups()

@@ -121,6 +121,7 @@ struct Knobs {
     bool no_fuse32 = false;      // VITS_NO_FUSE32: fp32 resblock conv pairs as two launches
     bool no_rb_group = false;    // VITS_NO_RB_GROUP: the resblocks of a stage as separate launches (no grouped launch)
     bool rb_group_always = false;  // VITS_RB_GROUP=1: grouped launches also when the three streams are available
+    bool no_flow_fuse = false;   // VITS_NO_FLOW_FUSE: 16-bit modes: a coupling layer of the flow as nine launches instead of one kernel
     bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
     void read();
 };

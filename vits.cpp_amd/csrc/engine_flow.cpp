@@ -165,6 +165,31 @@ int Engine::run_flow(Call& c) {
         const FlowLayerW& Lw = flow_[i];
         const bool flipped = ((hp.n_flows - i) % 2) == 1;
         TensorRef x0 = sub(zp, flipped ? F / 2 : 0), x1 = sub(zp, flipped ? 0 : F / 2);
+        // 16-bit modes: the whole coupling layer as ONE kernel (flow_couple16_kernel, wavenet32.hip; bit-identical to the launches below)
+        if (arith_now_ != VITS_ARITH_F32 && !knobs.no_flow_fuse && (int)Lw.in_layers.size() == hp.wn_layers && (int)Lw.res_skip.size() == hp.wn_layers &&
+            flow_couple16_supported(H, F / 2, hp.wn_k, hp.wn_rate, hp.wn_layers, Lw.pre, Lw.in_layers.data(), Lw.res_skip.data(), Lw.post)) {
+            FlowCouple16Call fc;
+            fc.x0 = x0;
+            fc.x1 = x1;
+            fc.lens = ll;
+            fc.batch = B;
+            fc.tmax = Lmax;
+            fc.hidden = H;
+            fc.half = F / 2;
+            if (prof.on) {
+                char full[160];
+                std::snprintf(full, sizeof(full), "flow_coupling_layer|k%d|d1|C%d|e1|c%dx%d", hp.wn_k, H, F / 2, F / 2);
+                double macs = (double)(F / 2) * H + (double)H * (F / 2), wbytes = (double)Lw.pre.bytes16 + (double)Lw.post.bytes16;
+                for (int l = 0; l < hp.wn_layers; ++l) {
+                    macs += (double)2 * H * H * hp.wn_k + (double)Lw.res_skip[l].cout * H;
+                    wbytes += (double)Lw.in_layers[l].bytes16 + (double)Lw.res_skip[l].bytes16;
+                }
+                prof.begin(full, 2.0 * macs * (double)sum_frames, 4.0 * (double)sum_frames * (F / 2) * 3.0 + wbytes, stream, true);
+            }
+            HIP_OK(launch_flow_couple16(Lw.pre, Lw.in_layers.data(), Lw.res_skip.data(), Lw.post, fc, arith_now_, stream));
+            prof.end(stream);
+            continue;
+        }
         HIP_OK(conv("flow_conv1x1", Lw.pre, mk2(x0, hh)));  // h -> hout[0,H)
         prof.begin("fill_zero", 0, 0, stream);
         HIP_OK(launch_fill_rows(sub(hout, H), H, 0.f, B, Lmax, stream));

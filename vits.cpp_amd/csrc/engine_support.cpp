@@ -35,6 +35,7 @@ void Knobs::read() {
     no_fuse32 = flag("VITS_NO_FUSE32");
     no_rb_group = flag("VITS_NO_RB_GROUP");
     rb_group_always = flag("VITS_RB_GROUP");
+    no_flow_fuse = flag("VITS_NO_FLOW_FUSE");
     if (const char* e = std::getenv("VITS_PROF_ATTACH")) prof_attach = std::atoi(e) != 0;
 }
 

@@ -196,6 +196,15 @@ bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, cons
 hipError_t launch_wavenet32(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, hipStream_t s);
 bool wavenet16_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs);  // the same layer on 16-bit operands
 hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const WaveNet32Call& c, int arith, hipStream_t s);
+// one whole coupling layer of the flow (pre conv, four WaveNet layers, post conv, x1 += ...) as one kernel, 16-bit-operand modes (wavenet32.hip)
+struct FlowCouple16Call {
+    TensorRef x0, x1;  // conditioning half (read), updated half (in place): fp32 [b][F/2][t]
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0, hidden = 0, half = 0;
+};
+bool flow_couple16_supported(int hidden, int half, int kt, int rate, int layers, const PackedConv& pre, const PackedConv* in, const PackedConv* rs, const PackedConv& post);
+hipError_t launch_flow_couple16(const PackedConv& pre, const PackedConv* in, const PackedConv* rs, const PackedConv& post, const FlowCouple16Call& c, int arith,
+                                hipStream_t s);
 hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbPair32Call& c, hipStream_t s);
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);

@@ -481,6 +481,250 @@ __global__ __launch_bounds__(4 * H / NCW, 1) void wavenet16_kernel(const WaveNet
     WN_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One whole coupling layer of the flow as ONE kernel, 16-bit-operand modes (vits.cpp:500-517, reverse direction, mean only):
+//     h = pre(x0);  4 x { in = Conv_k5(h); acts = tanh . sigmoid; rs = Conv_1x1(acts); h += rs[0:H]; out += rs[H:2H] (last: out += rs) };
+//     x1 += post(out)            (the post conv's weights are negated at load: x1 - m, vits.cpp:506,513)
+// As launches a coupling layer is nine of them in these modes (converter + pre conv, fill, four WaveNet layers, converter + post conv)
+// with 6 us of MFMA work per 37-44 us WaveNet layer at batch 64 x 225 frames: each layer fills its h tile from HBM, adds into h / out in
+// HBM and pays a launch gap. Here a block owns 48 frames and computes on 64 columns (the 2-frame halo of each of the four k = 5 convs
+// on both sides): the fp32 stream h lives in the registers of the waves that compute the res rows (channel groups 0-2), the skip sum in
+// those of the waves that compute the skip rows (groups 3-5), both in the MFMA C layout; the 16-bit conv inputs (round(h), acts, round(x0),
+// round(out)) take turns in two LDS tiles; HBM sees x0 once and x1 twice. Every element goes through the same roundings and the same
+// MFMA chains (chunk, tap, k-half) and fp32 adds in the same order as the launch-by-launch path: bit-identical (GPU test).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FlowCouple16Params {
+    const float* x0;  // conditioning half, fp32 [b][F/2][t]
+    int64_t x0_bs;
+    int x0_cs;
+    float* x1;  // updated half, in place
+    int64_t x1_bs;
+    int x1_cs;
+    const uint16_t* w_pre;
+    const float* b_pre;
+    const uint16_t* w_in[4];
+    const float* b_in[4];
+    const uint16_t* w_rs[4];
+    const float* b_rs[4];
+    const uint16_t* w_post;
+    const float* b_post;
+    const int* lens;
+    int tmax;
+};
+
+template <bool BF>
+__global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple16Params p) {
+    constexpr int H = 192, HF = 96, KT = 5, NL = 4, NG = H / 32, BM = 64, BO = 48, HALO = 8, P = (KT - 1) / 2, XS = BM + KT - 1;
+    constexpr int NGRP = H / 8;  // 16-byte channel groups of an H-channel tile
+    static_assert(HALO == NL * P, "one k = 5 halo per WaveNet layer");
+    extern __shared__ __attribute__((aligned(16))) wn_int4v l16[];
+    wn_int4v* xs = l16;               // [NGRP][XS]  round(h), slot P + column (two zero slots on either side)
+    wn_int4v* ts = l16 + NGRP * XS;   // [NGRP][BM]  acts | round(x0) (12 groups) | round(out)
+    float* ex = reinterpret_cast<float*>(l16);  // [3][2][16][2][64] fp32: the last layer's rs rows on their way to the skip waves (over xs + ts)
+    float* lb = reinterpret_cast<float*>(l16 + NGRP * XS + NGRP * BM);  // biases: pre[H] | in[NL][2H] | rs[NL][2H] | post[HF]
+    constexpr int LB_IN = H, LB_RS = H + NL * 2 * H, LB_POST = H + 2 * NL * 2 * H, LB_N = LB_POST + HF;
+    static_assert(3 * 2 * 16 * 2 * 64 * 4 <= (NGRP * XS + NGRP * BM) * 16, "exchange buffer fits over the two tiles");
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    if ((int)blockIdx.x * BO >= len) return;
+    const int tb = (int)blockIdx.x * BO - HALO;  // global frame of column 0
+    const int krow = lane >> 5;
+    const int gw = wid % NG, ct = wid / NG;
+    const int col = ct * 32 + (lane & 31);
+    const int t = tb + col;
+    const bool inside = t >= 0 && t < len;
+    typedef const __attribute__((address_space(3))) wn_int4v* LdsV;
+
+    // ---- x0 tile (rounded, zero outside the sequence) -> ts[0:12][BM]; zero halo slots of xs; biases -> LDS ----
+    {
+        const float* x0b = p.x0 + (int64_t)b * p.x0_bs;
+        const int g = tid / BM, i = tid - g * BM;  // 12 groups x 64 frames = 768 slots = one per thread
+        const int tt = tb + i;
+        const bool ok = tt >= 0 && tt < len;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ok ? x0b[(int64_t)(g * 8 + e) * p.x0_cs + tt] : 0.f;
+        wn_int4v q;
+        q.x = (int)((unsigned)wn_round16<BF>(v[0]) | ((unsigned)wn_round16<BF>(v[1]) << 16));
+        q.y = (int)((unsigned)wn_round16<BF>(v[2]) | ((unsigned)wn_round16<BF>(v[3]) << 16));
+        q.z = (int)((unsigned)wn_round16<BF>(v[4]) | ((unsigned)wn_round16<BF>(v[5]) << 16));
+        q.w = (int)((unsigned)wn_round16<BF>(v[6]) | ((unsigned)wn_round16<BF>(v[7]) << 16));
+        ts[tid] = q;
+        if (tid < NGRP * 2 * P) {
+            const int gg = tid / (2 * P), j = tid - gg * (2 * P);
+            xs[gg * XS + (j < P ? j : BM + j)] = wn_int4v{0, 0, 0, 0};
+        }
+        for (int i2 = tid; i2 < LB_N; i2 += 768) {
+            float bv;
+            if (i2 < LB_IN) bv = p.b_pre[i2];
+            else if (i2 < LB_RS) bv = p.b_in[(i2 - LB_IN) / (2 * H)][(i2 - LB_IN) % (2 * H)];
+            else if (i2 < LB_POST) {
+                const int l = (i2 - LB_RS) / (2 * H), r = (i2 - LB_RS) % (2 * H);
+                bv = (l + 1 < NL || r < H) ? p.b_rs[l][r] : 0.f;  // (the last layer's 1x1 conv has H rows)
+            } else bv = p.b_post[i2 - LB_POST];
+            lb[i2] = bv;
+        }
+    }
+    __syncthreads();
+
+    wn_floatx16 acc[2];
+    auto mfma = [&](wn_int4v a, wn_int4v bq, wn_floatx16 c) __attribute__((always_inline)) -> wn_floatx16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, bq), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_half8, a), __builtin_bit_cast(wn_half8, bq), c, 0, 0, 0);
+    };
+    // one conv for NM row tiles mt0.. of this wave's column tile: order per output = chunk, tap, k-half (conv16.hip's, wavenet16_kernel's)
+    auto conv = [&](const uint16_t* wp, int mt0, auto total_c, auto taps_c, auto nm_c, LdsV base, const int pitch) __attribute__((always_inline)) {
+        constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value, NM = decltype(nm_c)::value;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+        int wvoff[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wvoff[m] = (int)(((size_t)(mt0 + m) * TOTAL * 64 + lane) * 16);
+        auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_int4v {
+            const int vo = wvoff[m];
+            return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, step * 1024, 0));
+        };
+        constexpr int RS = 8, RD = 6;
+        wn_int4v ring[RS][NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int i = 0; i < RD; ++i) ring[i][m] = load_a(m, i < TOTAL ? i : TOTAL - 1);
+        auto bslot = [&](int s) __attribute__((always_inline)) -> int {
+            const int kk = s & 1, cj = s >> 1, j = cj % TAPS, c = cj / TAPS;
+            return (c * 4 + 2 * kk) * pitch + j;
+        };
+        wn_int4v b_nxt = base[bslot(0)];
+#pragma unroll
+        for (int s = 0; s < TOTAL; ++s) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const wn_int4v bq = b_nxt;
+            b_nxt = base[bslot(s + 1 < TOTAL ? s + 1 : TOTAL - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc[m] = mfma(ring[s % RS][m], bq, acc[m]);
+        }
+    };
+    // 16 values of one row tile (MFMA C layout: register 4 g + e = channel 8 g + 4 krow + e of the tile) -> rounded, whole 16-byte slots of the
+    // tile's four channel groups at this lane's column (v_permlane32_swap trades halves between two groups, see wavenet16_kernel)
+    auto put_tile = [&](wn_int4v* dst, int grp0, int pitch, int slot, const float* v, bool ok) __attribute__((always_inline)) {
+        unsigned w[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned short q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = ok ? wn_round16<BF>(v[4 * g + e]) : (unsigned short)0;
+            w[g][0] = (unsigned)q[0] | ((unsigned)q[1] << 16);
+            w[g][1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const auto x = __builtin_amdgcn_permlane32_swap(w[2 * k][0], w[2 * k + 1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(w[2 * k][1], w[2 * k + 1][1], false, false);
+            dst[(grp0 + 2 * k + krow) * pitch + slot] = wn_int4v{(int)x[0], (int)y[0], (int)x[1], (int)y[1]};
+        }
+    };
+    auto rowof = [&](int tile, int r) __attribute__((always_inline)) -> int { return tile * 32 + (r >> 2) * 8 + krow * 4 + (r & 3); };
+
+    // ---- pre conv (F/2 -> H, 1x1): the waves of channel groups 0-2 compute the rows they will carry as h ----
+    // st[m][r]: groups 0-2: the fp32 stream h, rows 64 gw + 32 m + ...; groups 3-5: the skip sum `outputs`, rows 64 (gw - 3) + 32 m + ...
+    float st[2][16];
+    if (gw < 3) {
+        conv(p.w_pre, 2 * gw, std::integral_constant<int, (HF / 32) * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col), BM);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] = acc[m][r] + lb[rowof(2 * gw + m, r)];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] = 0.f;  // (launch_fill_rows of the launch-by-launch path)
+    }
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        __syncthreads();  // the previous layer's 1x1 conv (l = 0: the pre conv) has read ts; its gated conv has read xs
+        if (gw < 3) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) put_tile(xs, (2 * gw + m) * 4, XS, P + col, st[m], inside);
+        }
+        __syncthreads();
+        // gated conv: tanh tile 2 gw, sigmoid tile 2 gw + 1 of this wave's channel group
+        conv(p.w_in[l], 2 * gw, std::integral_constant<int, NG * KT * 2>{}, std::integral_constant<int, KT>{}, std::integral_constant<int, 2>{}, (LdsV)(xs + krow * XS + col), XS);
+        {
+            float a16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
+                float v = wavenet_gate(acc[0][r] + lb[LB_IN + l * 2 * H + ch], acc[1][r] + lb[LB_IN + l * 2 * H + H + ch]);
+                asm volatile("" : "+v"(v));  // (two roundings, as the launch-by-launch path: fp32 acts, 16-bit at the converter)
+                a16[r] = v;
+            }
+            put_tile(ts, gw * 4, BM, col, a16, inside);
+        }
+        __syncthreads();
+        // 1x1 res/skip conv: tiles 2 gw, 2 gw + 1 of 2H rows (the last layer: H rows, channel groups 0-2 only)
+        if (l + 1 < NL || gw < 3) {
+            conv(p.w_rs[l], 2 * gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col), BM);
+            if (l + 1 < NL) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[m][r] + lb[LB_RS + l * 2 * H + rowof(2 * gw + m, r)];
+                        st[m][r] = st[m][r] + v;  // h' = h + rs[0:H] (groups 0-2), outputs += rs[H:2H] (groups 3-5)
+                    }
+            }
+        }
+    }
+    // ---- the last layer's rs rows (channel groups 0-2) join the skip sum held by groups 3-5: lane for lane through LDS ----
+    __syncthreads();  // every wave has left the last 1x1 conv: xs and ts are free
+    if (gw < 3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ex[(((gw * 2 + m) * 16 + r) * 2 + ct) * 64 + lane] = acc[m][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
+    }
+    __syncthreads();
+    if (gw >= 3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] = st[m][r] + ex[((((gw - 3) * 2 + m) * 16 + r) * 2 + ct) * 64 + lane];
+    }
+    __syncthreads();  // ex read: ts may be written
+    if (gw >= 3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) put_tile(ts, (2 * (gw - 3) + m) * 4, BM, col, st[m], inside);
+    }
+    __syncthreads();
+    // ---- post conv (H -> F/2, 1x1) and the coupling: x1 += post(out) on the block's own 48 frames ----
+    if (gw < 3) {
+        conv(p.w_post, gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col), BM);
+        if (col >= HALO && col < HALO + BO && t < len) {
+            float* x1b = p.x1 + (int64_t)b * p.x1_bs + t;
+            float addv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) addv[r] = x1b[(int64_t)rowof(gw, r) * p.x1_cs];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][r] + lb[LB_POST + rowof(gw, r)];
+                v = addv[r] + v;
+                x1b[(int64_t)rowof(gw, r) * p.x1_cs] = v;
+            }
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 bool wavenet32_supported(int hidden, int kt, int dil, const PackedConv& in, const PackedConv& rs) {
     if (hidden != 192 || kt != 5 || dil != 1) return false;
@@ -558,6 +802,54 @@ hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const Wa
         if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((wavenet16_kernel<H, KT, true, 2>), grid, dim3(2 * H), ldsz, s, p);
         else VITS_KLAUNCH((wavenet16_kernel<H, KT, false, 2>), grid, dim3(2 * H), ldsz, s, p);
     }
+    return hipGetLastError();
+}
+
+bool flow_couple16_supported(int hidden, int half, int kt, int rate, int layers, const PackedConv& pre, const PackedConv* in, const PackedConv* rs, const PackedConv& post) {
+    if (hidden != 192 || half != 96 || kt != 5 || rate != 1 || layers != 4) return false;
+    if (!pre.wp16 || !pre.bias || pre.cin != half || pre.cout != hidden || pre.kt != 1 || pre.epi != EPI_STD) return false;
+    if (!post.wp16 || !post.bias || post.cin != hidden || post.cout != half || post.kt != 1 || post.epi != EPI_STD) return false;
+    for (int l = 0; l < layers; ++l) {
+        if (!wavenet16_supported(hidden, kt, 1, in[l], rs[l])) return false;
+        if (rs[l].cout != (l + 1 < layers ? 2 * hidden : hidden)) return false;
+    }
+    return true;
+}
+
+hipError_t launch_flow_couple16(const PackedConv& pre, const PackedConv* in, const PackedConv* rs, const PackedConv& post, const FlowCouple16Call& c, int arith,
+                                hipStream_t s) {
+    if (arith == VITS_ARITH_F32 || !flow_couple16_supported(c.hidden, c.half, 5, 1, 4, pre, in, rs, post) || !c.x0.p || !c.x1.p) return hipErrorInvalidValue;
+    FlowCouple16Params p;
+    p.x0 = c.x0.p;
+    p.x0_bs = c.x0.bs;
+    p.x0_cs = c.x0.cs;
+    p.x1 = c.x1.p;
+    p.x1_bs = c.x1.bs;
+    p.x1_cs = c.x1.cs;
+    p.w_pre = pre.wp16;
+    p.b_pre = pre.bias;
+    for (int l = 0; l < 4; ++l) {
+        p.w_in[l] = in[l].wp16;
+        p.b_in[l] = in[l].bias;
+        p.w_rs[l] = rs[l].wp16;
+        p.b_rs[l] = rs[l].bias;
+    }
+    p.w_post = post.wp16;
+    p.b_post = post.bias;
+    p.lens = c.lens;
+    p.tmax = c.tmax;
+    constexpr int H = 192, XS = 64 + 4, NGRP = H / 8, LB_N = H + 2 * 4 * 2 * H + 96;
+    const size_t ldsz = (size_t)(NGRP * XS + NGRP * 64) * 16 + (size_t)LB_N * 4;
+    static std::atomic<bool> big_lds_set{false};
+    if (ldsz > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_couple16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_couple16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+        if (e1 != hipSuccess || e2 != hipSuccess) return e1 != hipSuccess ? e1 : e2;
+        big_lds_set.store(true, std::memory_order_release);
+    }
+    dim3 grid((c.tmax + 47) / 48, c.batch);
+    if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true>), grid, dim3(768), ldsz, s, p);
+    else VITS_KLAUNCH((flow_couple16_kernel<false>), grid, dim3(768), ldsz, s, p);
     return hipGetLastError();
 }
 
