@@ -512,10 +512,14 @@ struct FlowCouple16Params {
     int tmax;
 };
 
-template <bool BF>
-__global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple16Params p) {
+// NCW: 32-frame column tiles per wave. 1 = twelve waves (channel group, column tile); 2 = six waves that own both column tiles of their channel
+// group: every weight fragment then feeds two MFMAs per row tile, which halves the fragment traffic through the CU's vector memory path
+// (the bound of the gated conv, see wavenet16_kernel) — without the per-layer fill and epilogue that made it lose there.
+template <bool BF, int NCW>
+__global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowCouple16Params p) {
     constexpr int H = 192, HF = 96, KT = 5, NL = 4, NG = H / 32, BM = 64, BO = 48, HALO = 8, P = (KT - 1) / 2, XS = BM + KT - 1;
     constexpr int NGRP = H / 8;  // 16-byte channel groups of an H-channel tile
+    constexpr int NTH = 768 / NCW;
     static_assert(HALO == NL * P, "one k = 5 halo per WaveNet layer");
     extern __shared__ __attribute__((aligned(16))) wn_int4v l16[];
     wn_int4v* xs = l16;               // [NGRP][XS]  round(h), slot P + column (two zero slots on either side)
@@ -531,32 +535,41 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
     if ((int)blockIdx.x * BO >= len) return;
     const int tb = (int)blockIdx.x * BO - HALO;  // global frame of column 0
     const int krow = lane >> 5;
-    const int gw = wid % NG, ct = wid / NG;
-    const int col = ct * 32 + (lane & 31);
-    const int t = tb + col;
-    const bool inside = t >= 0 && t < len;
+    const int gw = wid % NG, ct0 = (wid / NG) * NCW;
+    const int col0 = ct0 * 32 + (lane & 31);  // this lane's column of its column tile n: col0 + 32 n
+    bool inside[NCW];
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) inside[n] = tb + col0 + 32 * n >= 0 && tb + col0 + 32 * n < len;
     typedef const __attribute__((address_space(3))) wn_int4v* LdsV;
 
     // ---- x0 tile (rounded, zero outside the sequence) -> ts[0:12][BM]; zero halo slots of xs; biases -> LDS ----
     {
         const float* x0b = p.x0 + (int64_t)b * p.x0_bs;
-        const int g = tid / BM, i = tid - g * BM;  // 12 groups x 64 frames = 768 slots = one per thread
-        const int tt = tb + i;
-        const bool ok = tt >= 0 && tt < len;
-        float v[8];
+        constexpr int NSLOT = (HF / 8) * BM, PER = NSLOT / NTH;  // 768 slots
+        float v[PER][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ok ? x0b[(int64_t)(g * 8 + e) * p.x0_cs + tt] : 0.f;
-        wn_int4v q;
-        q.x = (int)((unsigned)wn_round16<BF>(v[0]) | ((unsigned)wn_round16<BF>(v[1]) << 16));
-        q.y = (int)((unsigned)wn_round16<BF>(v[2]) | ((unsigned)wn_round16<BF>(v[3]) << 16));
-        q.z = (int)((unsigned)wn_round16<BF>(v[4]) | ((unsigned)wn_round16<BF>(v[5]) << 16));
-        q.w = (int)((unsigned)wn_round16<BF>(v[6]) | ((unsigned)wn_round16<BF>(v[7]) << 16));
-        ts[tid] = q;
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NTH;
+            const int g = idx / BM, i = idx - g * BM;
+            const int tt = tb + i;
+            const bool ok = tt >= 0 && tt < len;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u][e] = ok ? x0b[(int64_t)(g * 8 + e) * p.x0_cs + tt] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            wn_int4v q;
+            q.x = (int)((unsigned)wn_round16<BF>(v[u][0]) | ((unsigned)wn_round16<BF>(v[u][1]) << 16));
+            q.y = (int)((unsigned)wn_round16<BF>(v[u][2]) | ((unsigned)wn_round16<BF>(v[u][3]) << 16));
+            q.z = (int)((unsigned)wn_round16<BF>(v[u][4]) | ((unsigned)wn_round16<BF>(v[u][5]) << 16));
+            q.w = (int)((unsigned)wn_round16<BF>(v[u][6]) | ((unsigned)wn_round16<BF>(v[u][7]) << 16));
+            ts[tid + u * NTH] = q;
+        }
         if (tid < NGRP * 2 * P) {
             const int gg = tid / (2 * P), j = tid - gg * (2 * P);
             xs[gg * XS + (j < P ? j : BM + j)] = wn_int4v{0, 0, 0, 0};
         }
-        for (int i2 = tid; i2 < LB_N; i2 += 768) {
+        for (int i2 = tid; i2 < LB_N; i2 += NTH) {
             float bv;
             if (i2 < LB_IN) bv = p.b_pre[i2];
             else if (i2 < LB_RS) bv = p.b_in[(i2 - LB_IN) / (2 * H)][(i2 - LB_IN) % (2 * H)];
@@ -569,18 +582,20 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
     }
     __syncthreads();
 
-    wn_floatx16 acc[2];
+    wn_floatx16 acc[2][NCW];
     auto mfma = [&](wn_int4v a, wn_int4v bq, wn_floatx16 c) __attribute__((always_inline)) -> wn_floatx16 {
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, bq), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_half8, a), __builtin_bit_cast(wn_half8, bq), c, 0, 0, 0);
     };
-    // one conv for NM row tiles mt0.. of this wave's column tile: order per output = chunk, tap, k-half (conv16.hip's, wavenet16_kernel's)
+    // one conv for NM row tiles mt0.. of this wave's NCW column tiles: order per output = chunk, tap, k-half (conv16.hip's, wavenet16_kernel's)
     auto conv = [&](const uint16_t* wp, int mt0, auto total_c, auto taps_c, auto nm_c, LdsV base, const int pitch) __attribute__((always_inline)) {
         constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value, NM = decltype(nm_c)::value;
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
         int wvoff[NM];
 #pragma unroll
@@ -599,17 +614,25 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
             const int kk = s & 1, cj = s >> 1, j = cj % TAPS, c = cj / TAPS;
             return (c * 4 + 2 * kk) * pitch + j;
         };
-        wn_int4v b_nxt = base[bslot(0)];
+        wn_int4v b_nxt[NCW];
+#pragma unroll
+        for (int n = 0; n < NCW; ++n) b_nxt[n] = base[bslot(0) + 32 * n];
 #pragma unroll
         for (int s = 0; s < TOTAL; ++s) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const wn_int4v bq = b_nxt;
-            b_nxt = base[bslot(s + 1 < TOTAL ? s + 1 : TOTAL - 1)];
+            wn_int4v bq[NCW];
+#pragma unroll
+            for (int n = 0; n < NCW; ++n) {
+                bq[n] = b_nxt[n];
+                b_nxt[n] = base[bslot(s + 1 < TOTAL ? s + 1 : TOTAL - 1) + 32 * n];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < NM; ++m) acc[m] = mfma(ring[s % RS][m], bq, acc[m]);
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int n = 0; n < NCW; ++n) acc[m][n] = mfma(ring[s % RS][m], bq[n], acc[m][n]);
         }
     };
     // 16 values of one row tile (MFMA C layout: register 4 g + e = channel 8 g + 4 krow + e of the tile) -> rounded, whole 16-byte slots of the
@@ -634,19 +657,23 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
     auto rowof = [&](int tile, int r) __attribute__((always_inline)) -> int { return tile * 32 + (r >> 2) * 8 + krow * 4 + (r & 3); };
 
     // ---- pre conv (F/2 -> H, 1x1): the waves of channel groups 0-2 compute the rows they will carry as h ----
-    // st[m][r]: groups 0-2: the fp32 stream h, rows 64 gw + 32 m + ...; groups 3-5: the skip sum `outputs`, rows 64 (gw - 3) + 32 m + ...
-    float st[2][16];
+    // st[m][n][r]: groups 0-2: the fp32 stream h, rows 64 gw + 32 m + ...; groups 3-5: the skip sum `outputs`, rows 64 (gw - 3) + 32 m + ...
+    float st[2][NCW][16];
     if (gw < 3) {
-        conv(p.w_pre, 2 * gw, std::integral_constant<int, (HF / 32) * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col), BM);
+        conv(p.w_pre, 2 * gw, std::integral_constant<int, (HF / 32) * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col0), BM);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[m][r] = acc[m][r] + lb[rowof(2 * gw + m, r)];
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[m][n][r] = acc[m][n][r] + lb[rowof(2 * gw + m, r)];
     } else {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[m][r] = 0.f;  // (launch_fill_rows of the launch-by-launch path)
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[m][n][r] = 0.f;  // (launch_fill_rows of the launch-by-launch path)
     }
 
 #pragma unroll
@@ -654,34 +681,39 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
         __syncthreads();  // the previous layer's 1x1 conv (l = 0: the pre conv) has read ts; its gated conv has read xs
         if (gw < 3) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) put_tile(xs, (2 * gw + m) * 4, XS, P + col, st[m], inside);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NCW; ++n) put_tile(xs, (2 * gw + m) * 4, XS, P + col0 + 32 * n, st[m][n], inside[n]);
         }
         __syncthreads();
         // gated conv: tanh tile 2 gw, sigmoid tile 2 gw + 1 of this wave's channel group
-        conv(p.w_in[l], 2 * gw, std::integral_constant<int, NG * KT * 2>{}, std::integral_constant<int, KT>{}, std::integral_constant<int, 2>{}, (LdsV)(xs + krow * XS + col), XS);
-        {
+        conv(p.w_in[l], 2 * gw, std::integral_constant<int, NG * KT * 2>{}, std::integral_constant<int, KT>{}, std::integral_constant<int, 2>{}, (LdsV)(xs + krow * XS + col0), XS);
+#pragma unroll
+        for (int n = 0; n < NCW; ++n) {
             float a16[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = gw * 32 + (r >> 2) * 8 + krow * 4 + (r & 3);
-                float v = wavenet_gate(acc[0][r] + lb[LB_IN + l * 2 * H + ch], acc[1][r] + lb[LB_IN + l * 2 * H + H + ch]);
+                float v = wavenet_gate(acc[0][n][r] + lb[LB_IN + l * 2 * H + ch], acc[1][n][r] + lb[LB_IN + l * 2 * H + H + ch]);
                 asm volatile("" : "+v"(v));  // (two roundings, as the launch-by-launch path: fp32 acts, 16-bit at the converter)
                 a16[r] = v;
             }
-            put_tile(ts, gw * 4, BM, col, a16, inside);
+            put_tile(ts, gw * 4, BM, col0 + 32 * n, a16, inside[n]);
         }
         __syncthreads();
         // 1x1 res/skip conv: tiles 2 gw, 2 gw + 1 of 2H rows (the last layer: H rows, channel groups 0-2 only)
         if (l + 1 < NL || gw < 3) {
-            conv(p.w_rs[l], 2 * gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col), BM);
+            conv(p.w_rs[l], 2 * gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col0), BM);
             if (l + 1 < NL) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[m][r] + lb[LB_RS + l * 2 * H + rowof(2 * gw + m, r)];
-                        st[m][r] = st[m][r] + v;  // h' = h + rs[0:H] (groups 0-2), outputs += rs[H:2H] (groups 3-5)
-                    }
+                    for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[m][n][r] + lb[LB_RS + l * 2 * H + rowof(2 * gw + m, r)];
+                            st[m][n][r] = st[m][n][r] + v;  // h' = h + rs[0:H] (groups 0-2), outputs += rs[H:2H] (groups 3-5)
+                        }
             }
         }
     }
@@ -691,35 +723,49 @@ __global__ __launch_bounds__(768, 1) void flow_couple16_kernel(const FlowCouple1
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ex[(((gw * 2 + m) * 16 + r) * 2 + ct) * 64 + lane] = acc[m][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ex[(((gw * 2 + m) * 16 + r) * 2 + ct0 + n) * 64 + lane] = acc[m][n][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
     }
     __syncthreads();
     if (gw >= 3) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[m][r] = st[m][r] + ex[((((gw - 3) * 2 + m) * 16 + r) * 2 + ct) * 64 + lane];
+            for (int n = 0; n < NCW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[m][n][r] = st[m][n][r] + ex[((((gw - 3) * 2 + m) * 16 + r) * 2 + ct0 + n) * 64 + lane];
     }
     __syncthreads();  // ex read: ts may be written
     if (gw >= 3) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) put_tile(ts, (2 * (gw - 3) + m) * 4, BM, col, st[m], inside);
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NCW; ++n) put_tile(ts, (2 * (gw - 3) + m) * 4, BM, col0 + 32 * n, st[m][n], inside[n]);
     }
     __syncthreads();
     // ---- post conv (H -> F/2, 1x1) and the coupling: x1 += post(out) on the block's own 48 frames ----
     if (gw < 3) {
-        conv(p.w_post, gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col), BM);
-        if (col >= HALO && col < HALO + BO && t < len) {
-            float* x1b = p.x1 + (int64_t)b * p.x1_bs + t;
-            float addv[16];
+        conv(p.w_post, gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col0), BM);
+        float addv[NCW][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) addv[r] = x1b[(int64_t)rowof(gw, r) * p.x1_cs];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int n = 0; n < NCW; ++n) {
+            const int col = col0 + 32 * n, t = tb + col;
+            const bool mine = col >= HALO && col < HALO + BO && t < len;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) addv[n][r] = mine ? p.x1[(int64_t)b * p.x1_bs + (int64_t)rowof(gw, r) * p.x1_cs + t] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NCW; ++n) {
+            const int col = col0 + 32 * n, t = tb + col;
+            if (!(col >= HALO && col < HALO + BO && t < len)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[0][r] + lb[LB_POST + rowof(gw, r)];
-                v = addv[r] + v;
-                x1b[(int64_t)rowof(gw, r) * p.x1_cs] = v;
+                float v = acc[0][n][r] + lb[LB_POST + rowof(gw, r)];
+                v = addv[n][r] + v;
+                p.x1[(int64_t)b * p.x1_bs + (int64_t)rowof(gw, r) * p.x1_cs + t] = v;
             }
         }
     }
@@ -840,16 +886,16 @@ hipError_t launch_flow_couple16(const PackedConv& pre, const PackedConv* in, con
     p.tmax = c.tmax;
     constexpr int H = 192, XS = 64 + 4, NGRP = H / 8, LB_N = H + 2 * 4 * 2 * H + 96;
     const size_t ldsz = (size_t)(NGRP * XS + NGRP * 64) * 16 + (size_t)LB_N * 4;
-    static std::atomic<bool> big_lds_set{false};
-    if (ldsz > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_couple16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_couple16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        if (e1 != hipSuccess || e2 != hipSuccess) return e1 != hipSuccess ? e1 : e2;
-        big_lds_set.store(true, std::memory_order_release);
-    }
+    // six waves owning both column tiles of their channel group (VITS_FLOW_NCW=1: twelve waves, one column tile each)
+    static const int ncw = getenv("VITS_FLOW_NCW") ? atoi(getenv("VITS_FLOW_NCW")) : 2;
     dim3 grid((c.tmax + 47) / 48, c.batch);
-    if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true>), grid, dim3(768), ldsz, s, p);
-    else VITS_KLAUNCH((flow_couple16_kernel<false>), grid, dim3(768), ldsz, s, p);
+    if (ncw == 1) {
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 1>), grid, dim3(768), ldsz, s, p);
+        else VITS_KLAUNCH((flow_couple16_kernel<false, 1>), grid, dim3(768), ldsz, s, p);
+    } else {
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 2>), grid, dim3(384), ldsz, s, p);
+        else VITS_KLAUNCH((flow_couple16_kernel<false, 2>), grid, dim3(384), ldsz, s, p);
+    }
     return hipGetLastError();
 }
 
