@@ -133,18 +133,20 @@ def test_rel_attention_does_not_depend_on_the_longest_member_of_the_batch(pkg):
     runs alone or beside a 2049-token one (same MFMA sequence in both paths)."""
     rng = np.random.default_rng(11)
     heads, hd, w = 2, 96, 4
-    T, TL = 300, 2049
-    q, k, v = rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T)
-    rk, rv = rnd(rng, 2 * w + 1, hd, scale=0.1), rnd(rng, 2 * w + 1, hd, scale=0.1)
-    alone = pkg.op_rel_attention(q, k, v, rk, rv, heads, w, lens=np.array([T], np.int32))
+    # (100 tokens alone: the short-sequence variant — one key tile of look-ahead, four blocks per CU —; 300 alone: four waves, two tiles of
+    # look-ahead; beside 2049 tokens: eight waves. 100 and 300 are 16-byte aligned strides, 2049 is not: vector and scalar loads of V.)
+    for T, TL in ((300, 2049), (100, 2049), (100, 300)):
+        q, k, v = rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T, scale=0.3), rnd(rng, 1, heads * hd, T)
+        rk, rv = rnd(rng, 2 * w + 1, hd, scale=0.1), rnd(rng, 2 * w + 1, hd, scale=0.1)
+        alone = pkg.op_rel_attention(q, k, v, rk, rv, heads, w, lens=np.array([T], np.int32))
 
-    def pad(a):
-        out = rnd(rng, 2, heads * hd, TL, scale=0.3)
-        out[0, :, :T] = a[0]
-        return out
+        def pad(a):
+            out = rnd(rng, 2, heads * hd, TL, scale=0.3)
+            out[0, :, :T] = a[0]
+            return out
 
-    both = pkg.op_rel_attention(pad(q), pad(k), pad(v), rk, rv, heads, w, lens=np.array([T, TL], np.int32))
-    assert np.array_equal(alone[0, :, :T], both[0, :, :T])
+        both = pkg.op_rel_attention(pad(q), pad(k), pad(v), rk, rv, heads, w, lens=np.array([T, TL], np.int32))
+        assert np.array_equal(alone[0, :, :T], both[0, :, :T]), (T, TL)
 
 
 def test_add_layer_norm_matches_oracle(pkg, oracle):

@@ -278,8 +278,11 @@ __device__ unsigned long long vits_att_phase[8 * 65536];
 #define ATT_STAMP(k)
 #endif
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 3) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+// MAXS: k-steps of head_dim the register arrays are sized for (24: head_dim <= 96, the MMS-TTS architecture; 32: <= 128). SHORT: sequences of
+// at most a few key tiles per wave (the 128-token utterances of a batch): ONE key tile of look-ahead instead of two and at most 128 VGPRs, so
+// that four blocks of four waves share a CU instead of three — 1024 blocks are then one round of the chip instead of 1.33.
+template <int NW, int MAXS, bool SHORT>
+__global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                                      int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
                                                                      int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int v16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -321,7 +324,6 @@ __global__ __launch_bounds__(64 * NW, 3) void rel_attention_mfma_kernel(const fl
     const int nsteps = hd >> 2;
     const int ntiles = (len + 15) >> 4;
     // this lane's Q operands for every k-step (A[m = ln][k = 4s + lk]): the same for every key tile and for the relative-key product
-    constexpr int MAXS = 32;  // head_dim <= 128
     float qa[MAXS];
 #pragma unroll
     for (int s2 = 0; s2 < MAXS; ++s2) qa[s2] = s2 < nsteps ? qt[(4 * s2 + lk) * ATT_Q + ln] : 0.f;
@@ -375,6 +377,20 @@ __global__ __launch_bounds__(64 * NW, 3) void rel_attention_mfma_kernel(const fl
             }
         };
         int n = wid;
+        if constexpr (SHORT) {
+            if (n < ntiles) load_tile(n, k0);
+            while (n < ntiles) {
+                load_tile(n + NW, k1);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(n, k0);
+                n += NW;
+                if (n >= ntiles) break;
+                load_tile(n + NW, k0);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(n, k1);
+                n += NW;
+            }
+        } else {
         if (n < ntiles) {
             load_tile(n, k0);
             load_tile(n + NW, k1);
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, 3) void rel_attention_mfma_kernel(const fl
             __builtin_amdgcn_sched_barrier(0);
             tile(n, k2);
             n += NW;
+        }
         }
     }
     __syncthreads();
@@ -515,17 +532,20 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             static const int nw_env = getenv("VITS_ATT_NW") ? atoi(getenv("VITS_ATT_NW")) : 0;
             int nw = 2 * ldsm > 160 * 1024 ? 8 : 4;
             if (nw_env == 4 || nw_env == 8) nw = nw_env;
-#define VITS_ATTM_LAUNCH(NW)                                                                                                                     \
+#define VITS_ATTM_LAUNCH(NW, MS, SH)                                                                                                                   \
     do {                                                                                                                                         \
         if (ldsm > 64 * 1024) {                                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel<NW, MS, SH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
             if (e != hipSuccess) return e;                                                                                                       \
         }                                                                                                                                        \
-        VITS_KLAUNCH(rel_attention_mfma_kernel<NW>, gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
+        VITS_KLAUNCH((rel_attention_mfma_kernel<NW, MS, SH>), gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
                            out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0);                                            \
     } while (0)
-            if (nw == 4) VITS_ATTM_LAUNCH(4);
-            else VITS_ATTM_LAUNCH(8);
+            static const int short_max = getenv("VITS_ATT_SHORT") ? atoi(getenv("VITS_ATT_SHORT")) : 512;  // tokens; 0 disables the short variant
+            // (the long variants keep their arrays at 32 k-steps: sized for 24 the four-wave kernel measured 0.22 against 0.18 ms at 1024 tokens)
+            if (nw == 4 && head_dim <= 96 && tmax <= short_max) VITS_ATTM_LAUNCH(4, 24, true);
+            else if (nw == 4) VITS_ATTM_LAUNCH(4, 32, false);
+            else VITS_ATTM_LAUNCH(8, 32, false);
 #undef VITS_ATTM_LAUNCH
             return hipGetLastError();
         }
