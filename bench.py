@@ -226,6 +226,53 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
 
 
 
+def serving_two_engines(pkg, torch, base_model, base_bytes, mode, steps=8):
+    """NOT a BASELINE configuration — a serving data point: two resident engine instances of the same model on one GPU (the C API allows
+    distinct handles to run concurrently), each fed whole batches of 64 x 128 ids by its own host thread. The device then overlaps the
+    latency-bound stage one (text encoder + duration predictor, exact fp32) of one instance with the matrix-core-bound vocoder of the
+    other; per-batch latency doubles. Reported beside, never instead of, the single-instance figures."""
+    import threading
+    out = {"note": "two engine instances (two model handles, two host threads), each processing whole 64 x 128-id batches; samples/s over both; "
+                   "single-instance figures are `value` / sub_results"}
+    other = pkg.Model(base_bytes)
+    other.set_mode(mode)
+    ids64 = pkg.synth_ids(64, 128)
+    cap = 256 * 8 * 128 + 294
+    bufs = [torch.empty((64, cap), dtype=torch.float32, device="cuda") for _ in range(2)]
+    engines = [base_model, other]
+    try:
+        for name, arith in (("f32", pkg.ARITH_F32), ("f16", pkg.ARITH_F16), ("bf16", pkg.ARITH_BF16)):
+            for m in engines:
+                m.set_arith(arith)
+            n = steps if name != "f32" else max(3, steps // 2)
+            counts = [0, 0]
+
+            def worker(i, reps):
+                tot = 0
+                for _ in range(reps):
+                    _, lengths, _ = engines[i].process_batch(ids64, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=4321, out_device=bufs[i].data_ptr(),
+                                                             out_device_stride=cap, skip_host_copy=True, keep_pcm=False)
+                    tot += int(lengths.sum())
+                counts[i] = tot
+
+            for i in range(2):
+                worker(i, 1)  # warm-up (arena growth, first launches)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(i, n)) for i in range(2)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            torch.cuda.synchronize()
+            e = time.perf_counter() - t
+            out["c3_" + name] = {"value": sum(counts) / e, "unit": "samples/s", "ms_per_batch": 1000.0 * e / (2 * n), "batches": 2 * n}
+    finally:
+        base_model.set_arith(pkg.ARITH_F32)
+        other.close()
+    return out
+
+
 def find_profile_artifact(pkg, suffix, key, tag):
     """Newest profiles/*<suffix> that (a) records the source hash of the library sources of THIS run and (b) has an entry for the
     kernel `key` and (c) was collected on this workload (`tag` = workload|batch|arith: a kernel instantiation's bytes per launch and busy
@@ -305,6 +352,7 @@ def main():
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the pinned-duration and host-PCM passes reported beside the headline")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the compact sub-results (c2_f32, c3_f16, c3_bf16, c5_f32, c5_bf16) and the "
                     "duration-boundary report that the default single-GPU run prints beside the headline")
+    ap.add_argument("--no-serving", action="store_true", help="skip the two-engine serving data point (`serving_two_engines`) of the default run")
     ap.add_argument("--pcm16", action="store_true", help="multi-GPU: convert to int16 on the device and gather that (half the bytes)")
     ap.add_argument("--balance", choices=["none", "frames"], default="none",
                     help="multi-GPU: 'frames' = every step first predicts frames (frames_only pre-pass on the own block), all-gathers "
@@ -622,6 +670,8 @@ def main():
         if default_run and not args.no_sub_results:
             t0 = time.perf_counter()
             res["sub_results"] = sub_results(pkg, torch, models[0], jobs[0]["bytes"], mode)
+            if not args.no_serving:
+                res["serving_two_engines"] = serving_two_engines(pkg, torch, models[0], jobs[0]["bytes"], mode)
             res["sub_results"]["wall_s"] = time.perf_counter() - t0
             res["sub_results"]["note"] = ("library default configuration (no per-kernel events), ids -> fp32 PCM in HBM, reference mode, predicted durations; 16-bit modes: "
                                           "VITS_ARITH_SCOPE_FLOW_VOCODER (stage one exact fp32, durations identical to the fp32 run)")
