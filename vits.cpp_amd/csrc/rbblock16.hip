@@ -101,6 +101,9 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     constexpr int STEPS = 2 * KT, TOTAL = NCH * STEPS;
     static_assert(BO > 0, "tile too narrow for this kernel size");
     extern __shared__ __attribute__((aligned(16))) int4v tile[];  // [G][PITCH] slots of 8 x 16 bit: x_p, then t_p, then x_{p+1}, ...
+    // behind the tile: the biases of the six convs, [pair][b1 | b2][C] fp32 — read from LDS where they are added (fetched from memory
+    // behind each conv they cost an exposed L2 round trip per conv: six per block, which the short k = 3 blocks notice)
+    float* lbias = reinterpret_cast<float*>(tile + (C / 8) * PITCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int strip = wid % NSTRIP, rt0 = (wid / NSTRIP) * MRW;
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     const int t0 = blockIdx.x * BO;
     if (t0 >= len) return;
     RBB_STAMP(0);
+    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
+        const int pi = i / (2 * C), r = i - pi * 2 * C;
+        lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
+    }
     const int h = lane >> 5, col = lane & 31;
     const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
     const int tg0 = t0 - H;                   // global time of tile column 0
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
         // conv 1 over x_p: t column u reads x columns u - P2 dil + j dil
         conv(p.w1[pi], -P2 * dil, dil);
         __syncthreads();  // every wave is done with x_p: t_p takes its place
-        write_tile(acc, p.b1[pi]);  // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
+        write_tile(acc, lbias + pi * 2 * C);  // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
         __syncthreads();
         // conv 2 over t_p: y column u reads t columns u - P2 + j
         conv(p.w2[pi], -P2, 1);
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch0 = (rt0 + m) * 32 + 8 * g + 4 * h;
-                const float4v bias = *reinterpret_cast<const float4v*>(p.b2[pi] + ch0);
+                const float4v bias = *reinterpret_cast<const float4v*>(lbias + pi * 2 * C + C + ch0);
 #pragma unroll
                 for (int nr = 0; nr < NRW; ++nr)
 #pragma unroll
@@ -336,7 +343,7 @@ template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
 static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
     constexpr int D0 = 1, D1 = 3, D2 = 5;
     constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
-    const size_t lds = (size_t)(C / 8) * PITCH * 16;
+    const size_t lds = (size_t)(C / 8) * PITCH * 16 + (size_t)6 * C * sizeof(float);
     static std::atomic<bool> big_lds_set{false};
     if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
