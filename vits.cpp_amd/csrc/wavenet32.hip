@@ -587,8 +587,28 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, bq), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_half8, a), __builtin_bit_cast(wn_half8, bq), c, 0, 0, 0);
     };
-    // one conv for NM row tiles mt0.. of this wave's NCW column tiles: order per output = chunk, tap, k-half (conv16.hip's, wavenet16_kernel's)
-    auto conv = [&](const uint16_t* wp, int mt0, auto total_c, auto taps_c, auto nm_c, LdsV base, const int pitch) __attribute__((always_inline)) {
+    // one conv for NM row tiles mt0.. of this wave's NCW column tiles: order per output = chunk, tap, k-half (conv16.hip's, wavenet16_kernel's).
+    // In two parts: conv_begin issues the loads of the first RD weight fragments, conv_run multiplies. A block is alone on its CU and runs ten
+    // convs separated by barriers and tile writes: begun right behind the previous conv, a conv's first fragments travel while the gate, the
+    // tile write and the barrier in front of it run — inside conv_run that L2 round trip was exposed ten times per block.
+    constexpr int RS = 8, RD = 6;
+    wn_int4v ring[RS][2];
+    int wvoff[2];
+    auto load_a = [&](const uint16_t* wp, int m, int step) __attribute__((always_inline)) -> wn_int4v {
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+        const int vo = wvoff[m];
+        return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, step * 1024, 0));
+    };
+    auto conv_begin = [&](const uint16_t* wp, int mt0, auto total_c, auto nm_c) __attribute__((always_inline)) {
+        constexpr int TOTAL = decltype(total_c)::value, NM = decltype(nm_c)::value;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wvoff[m] = (int)(((size_t)(mt0 + m) * TOTAL * 64 + lane) * 16);
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int i = 0; i < RD; ++i) ring[i][m] = load_a(wp, m, i < TOTAL ? i : TOTAL - 1);
+    };
+    auto conv_run = [&](const uint16_t* wp, auto total_c, auto taps_c, auto nm_c, LdsV base, const int pitch) __attribute__((always_inline)) {
         constexpr int TOTAL = decltype(total_c)::value, TAPS = decltype(taps_c)::value, NM = decltype(nm_c)::value;
 #pragma unroll
         for (int m = 0; m < NM; ++m)
@@ -596,20 +616,6 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
             for (int n = 0; n < NCW; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
-        int wvoff[NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) wvoff[m] = (int)(((size_t)(mt0 + m) * TOTAL * 64 + lane) * 16);
-        auto load_a = [&](int m, int step) __attribute__((always_inline)) -> wn_int4v {
-            const int vo = wvoff[m];
-            return __builtin_bit_cast(wn_int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, step * 1024, 0));
-        };
-        constexpr int RS = 8, RD = 6;
-        wn_int4v ring[RS][NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int i = 0; i < RD; ++i) ring[i][m] = load_a(m, i < TOTAL ? i : TOTAL - 1);
         auto bslot = [&](int s) __attribute__((always_inline)) -> int {
             const int kk = s & 1, cj = s >> 1, j = cj % TAPS, c = cj / TAPS;
             return (c * 4 + 2 * kk) * pitch + j;
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
 #pragma unroll
         for (int s = 0; s < TOTAL; ++s) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) ring[(s + RD) % RS][m] = load_a(m, s + RD < TOTAL ? s + RD : TOTAL - 1);
+            for (int m = 0; m < NM; ++m) ring[(s + RD) % RS][m] = load_a(wp, m, s + RD < TOTAL ? s + RD : TOTAL - 1);
             __builtin_amdgcn_sched_barrier(0);
             wn_int4v bq[NCW];
 #pragma unroll
@@ -635,6 +641,12 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
                 for (int n = 0; n < NCW; ++n) acc[m][n] = mfma(ring[s % RS][m], bq[n], acc[m][n]);
         }
     };
+    using C_PRE = std::integral_constant<int, (HF / 32) * 2>;
+    using C_IN = std::integral_constant<int, NG * KT * 2>;
+    using C_RS = std::integral_constant<int, NG * 2>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using IK = std::integral_constant<int, KT>;
     // 16 values of one row tile (MFMA C layout: register 4 g + e = channel 8 g + 4 krow + e of the tile) -> rounded, whole 16-byte slots of the
     // tile's four channel groups at this lane's column (v_permlane32_swap trades halves between two groups, see wavenet16_kernel)
     auto put_tile = [&](wn_int4v* dst, int grp0, int pitch, int slot, const float* v, bool ok) __attribute__((always_inline)) {
@@ -660,7 +672,8 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
     // st[m][n][r]: groups 0-2: the fp32 stream h, rows 64 gw + 32 m + ...; groups 3-5: the skip sum `outputs`, rows 64 (gw - 3) + 32 m + ...
     float st[2][NCW][16];
     if (gw < 3) {
-        conv(p.w_pre, 2 * gw, std::integral_constant<int, (HF / 32) * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col0), BM);
+        conv_begin(p.w_pre, 2 * gw, C_PRE{}, I2{});
+        conv_run(p.w_pre, C_PRE{}, I1{}, I2{}, (LdsV)(ts + krow * BM + col0), BM);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -676,6 +689,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
                 for (int r = 0; r < 16; ++r) st[m][n][r] = 0.f;  // (launch_fill_rows of the launch-by-launch path)
     }
 
+    conv_begin(p.w_in[0], 2 * gw, C_IN{}, I2{});
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         __syncthreads();  // the previous layer's 1x1 conv (l = 0: the pre conv) has read ts; its gated conv has read xs
@@ -687,7 +701,9 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
         }
         __syncthreads();
         // gated conv: tanh tile 2 gw, sigmoid tile 2 gw + 1 of this wave's channel group
-        conv(p.w_in[l], 2 * gw, std::integral_constant<int, NG * KT * 2>{}, std::integral_constant<int, KT>{}, std::integral_constant<int, 2>{}, (LdsV)(xs + krow * XS + col0), XS);
+        conv_run(p.w_in[l], C_IN{}, IK{}, I2{}, (LdsV)(xs + krow * XS + col0), XS);
+        const bool do_rs = l + 1 < NL || gw < 3;
+        if (do_rs) conv_begin(p.w_rs[l], 2 * gw, C_RS{}, I2{});
 #pragma unroll
         for (int n = 0; n < NCW; ++n) {
             float a16[16];
@@ -702,8 +718,9 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
         }
         __syncthreads();
         // 1x1 res/skip conv: tiles 2 gw, 2 gw + 1 of 2H rows (the last layer: H rows, channel groups 0-2 only)
-        if (l + 1 < NL || gw < 3) {
-            conv(p.w_rs[l], 2 * gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, (LdsV)(ts + krow * BM + col0), BM);
+        if (do_rs) {
+            conv_run(p.w_rs[l], C_RS{}, I1{}, I2{}, (LdsV)(ts + krow * BM + col0), BM);
+            if (l + 1 < NL) conv_begin(p.w_in[l + 1 < NL ? l + 1 : l], 2 * gw, C_IN{}, I2{});
             if (l + 1 < NL) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -728,6 +745,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
                 for (int r = 0; r < 16; ++r)
                     ex[(((gw * 2 + m) * 16 + r) * 2 + ct0 + n) * 64 + lane] = acc[m][n][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
     }
+    if (gw < 3) conv_begin(p.w_post, gw, C_RS{}, I1{});
     __syncthreads();
     if (gw >= 3) {
 #pragma unroll
@@ -747,7 +765,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
     __syncthreads();
     // ---- post conv (H -> F/2, 1x1) and the coupling: x1 += post(out) on the block's own 48 frames ----
     if (gw < 3) {
-        conv(p.w_post, gw, std::integral_constant<int, NG * 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (LdsV)(ts + krow * BM + col0), BM);
+        conv_run(p.w_post, C_RS{}, I1{}, I1{}, (LdsV)(ts + krow * BM + col0), BM);
         float addv[NCW][16];
 #pragma unroll
         for (int n = 0; n < NCW; ++n) {
