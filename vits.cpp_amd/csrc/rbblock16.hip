@@ -112,10 +112,6 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     const int t0 = blockIdx.x * BO;
     if (t0 >= len) return;
     RBB_STAMP(0);
-    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
-        const int pi = i / (2 * C), r = i - pi * 2 * C;
-        lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
-    }
     const int h = lane >> 5, col = lane & 31;
     const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
     const int tg0 = t0 - H;                   // global time of tile column 0
@@ -139,6 +135,11 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                     for (int e = 0; e < 4; ++e) yv[m][nr][4 * g + e] = v[e];
                 }
             }
+    }
+    // (the biases: requested behind the stream loads, so that the two round trips overlap)
+    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
+        const int pi = i / (2 * C), r = i - pi * 2 * C;
+        lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
     }
     // round(leaky_relu(src + bias)) of this wave's rows x columns into the LDS tile as whole 16-byte slots, zero outside the sequence (what a
     // conv sees as padding): x_p from the stream (bias = nullptr), t_p from the first conv's accumulators
