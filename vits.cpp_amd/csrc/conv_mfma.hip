@@ -1205,9 +1205,10 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
         const TileShape t2 = tile_shape(tile);
         const int64_t nb = (int64_t)((ncols_max + t2.wn * t2.nr * 32 - 1) / (t2.wn * t2.nr * 32)) * ((w.mtiles_used + t2.wm * t2.mr - 1) / (t2.wm * t2.mr)) * c.batch;
-        // 1x1 convs on short sequences (QKV / output / projection convs of the encoder, the flow's pre / post convs): the narrow tile on
-        // large grids too — 192 -> 576 at batch 64 x 128 tokens 34 -> 26 us, 192 -> 192 21 -> 13 us (VITS_NARROW_K1=0: small grids only)
-        static const int narrow_k1 = getenv("VITS_NARROW_K1") ? atoi(getenv("VITS_NARROW_K1")) : 256;
+        // 1x1 convs (QKV / output / projection convs of the encoder, the flow's pre / post convs): the narrow tile on large grids too —
+        // 192 -> 576 at batch 64 x 128 tokens 34 -> 26 us, 192 -> 192 21 -> 13 us; at 1024 tokens (config 5) the 1x1 convs of a step 0.83 ->
+        // 0.65 ms (bf16 run), 1.34 -> 1.05 ms (fp32 run). VITS_NARROW_K1 = longest sequence that takes it (0: small grids only)
+        static const int narrow_k1 = getenv("VITS_NARROW_K1") ? atoi(getenv("VITS_NARROW_K1")) : (1 << 30);
         const bool k1_short = narrow_k1 > 0 && w.epi == EPI_STD && w.kt == 1 && ncols_max <= narrow_k1;
         if (!no_narrow && shape_ok && (nb <= 128 || k1_short)) tile = TILE_NARROW;
     }
