@@ -73,6 +73,39 @@ def test_two_models_resident_and_interleaved(pkg, oracle, full_bytes):
         assert rel_err(pb1, ref_b["waveform"]) < 1e-4
 
 
+def test_two_handles_on_two_threads_match_sequential_runs(pkg, full_bytes):
+    """The C API lets distinct model handles run concurrently (bench.py's `serving_two_engines`): two engine instances fed from
+    two host threads — their kernels interleave on the device, the per-thread launch timers and the per-handle arenas / streams must not mix —
+    return exactly the PCM of the same calls made one after the other, in the exact and in a 16-bit arithmetic, with the profiler on one of them."""
+    import threading
+    ids_a = np.stack([ids_for(40, 21), ids_for(40, 22), ids_for(40, 23)])
+    ids_b = np.stack([ids_for(24, 31), ids_for(24, 32)])
+    with pkg.Model(full_bytes) as a, pkg.Model(full_bytes) as b:
+        for arith in (pkg.ARITH_F32, pkg.ARITH_BF16):
+            a.set_arith(arith)
+            b.set_arith(arith)
+            ref_a = a.process_batch(ids_a, noise_kind=pkg.NOISE_COUNTER, noise_seed=5)
+            ref_b = b.process_batch(ids_b, noise_kind=pkg.NOISE_COUNTER, noise_seed=6)
+            a.prof_enable(True)
+            out = {}
+
+            def run(name, m, ids, seed):
+                res = []
+                for _ in range(6):
+                    res.append(m.process_batch(ids, noise_kind=pkg.NOISE_COUNTER, noise_seed=seed))
+                out[name] = res
+
+            ta = threading.Thread(target=run, args=("a", a, ids_a, 5))
+            tb = threading.Thread(target=run, args=("b", b, ids_b, 6))
+            ta.start(); tb.start(); ta.join(); tb.join()
+            a.prof_enable(False)
+            for name, ref in (("a", ref_a), ("b", ref_b)):
+                for pcm, lengths, frames in out[name]:
+                    assert np.array_equal(lengths, ref[1]) and np.array_equal(frames, ref[2])
+                    for u in range(len(lengths)):
+                        assert np.array_equal(pcm[u][:lengths[u]], ref[0][u][:lengths[u]]), (arith, name, u)
+
+
 def test_full_benchmark_size_properties(pkg, full_model):
     """BASELINE.json config 3 shape (batch 64 x 128 ids): size-independent properties over the whole batch — exact determinism,
     exact sample counts, bounded output, batch invariance (utterance b of the batch == the same utterance alone). Utterances of
