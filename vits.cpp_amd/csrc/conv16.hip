@@ -513,32 +513,59 @@ hipError_t launch_to_group16(TensorRef x, const int* lens, int batch, int channe
 }
 
 // conv_post on the 16-bit copy of the last vocoder stage (already activated with the final slope): Conv(C -> 1, k) -> tanh
-// (vits.cpp:638-642). Weights are rounded to the arithmetic type on load into LDS; products are exact in fp32.
+// (vits.cpp:638-642). Weights are rounded to the arithmetic type on load into LDS, eight channels of a tap per 16-byte entry — the shape of an
+// activation slot —, and a slot x entry product is four v_dot2c_f32_{f16,bf16} (two exact 16-bit products added into the fp32 sum each): 56
+// ds_read_b128 and 112 dot instructions per sample where one LDS read, one conversion and one FMA per product were 700.
 template <bool BF>
-__global__ void conv_post16_kernel(const uint16_t* __restrict__ x, int64_t x_bs, int x_ts, const float* __restrict__ w, int cin, int k, float* pre, int64_t pre_bs,
-                                   float* wave, int64_t wave_bs, const int* lens, int tmax, int emit_lo, const int* emit_hi) {
-    extern __shared__ float wsm[];  // [cin][k] rounded weights
+__global__ __launch_bounds__(256) void conv_post16_kernel(const uint16_t* __restrict__ x, int64_t x_bs, int x_ts, const float* __restrict__ w, int cin, int k, float* pre,
+                                                          int64_t pre_bs, float* wave, int64_t wave_bs, const int* lens, int tmax, int emit_lo, const int* emit_hi) {
+    extern __shared__ __attribute__((aligned(16))) int4v wq[];  // [cin / 8][k]: channels 8 g .. 8 g + 7 at tap j, rounded
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < cin * k; i += blockDim.x) wsm[i] = unpack16<BF>((unsigned short)(pack16<BF>(w[i], 0.f) & 0xffffu));
-    __syncthreads();
+    const int G = cin >> 3;
+    for (int i = threadIdx.x; i < G * k; i += blockDim.x) {
+        const int g = i / k, j = i - g * k;
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = pack16<BF>(w[(g * 8 + 2 * e) * k + j], w[(g * 8 + 2 * e + 1) * k + j]);
+        wq[i] = int4v{(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+    }
+    // the block's activation slots, [G][256 + k - 1], zero outside the sequence: every slot comes from memory once (coalesced 16-byte loads)
+    // instead of once per tap through the L1
     const int len = lens ? lens[b] : tmax;
+    const int pad = k / 2;
+    const int XS = (int)blockDim.x + k - 1;
+    int4v* xs = wq + G * k;
+    const uint16_t* xb = x + (int64_t)b * x_bs;
+    const int tb = blockIdx.x * blockDim.x - pad;
+    if ((int)(blockIdx.x * blockDim.x) < len) {
+        for (int i = threadIdx.x; i < G * XS; i += blockDim.x) {
+            const int g = i / XS, c = i - g * XS, tt = tb + c;
+            int4v q = {0, 0, 0, 0};
+            if (tt >= 0 && tt < len) q = *reinterpret_cast<const int4v*>(xb + ((int64_t)g * x_ts + tt) * 8);
+            xs[i] = q;
+        }
+    }
+    __syncthreads();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int hi = emit_hi ? emit_hi[b] : len;
     if (t >= len || t < emit_lo || t >= hi) return;
-    const int pad = k / 2;
-    const uint16_t* xb = x + (int64_t)b * x_bs;
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+    auto dot2 = [](int xa, int wa, float acc) __attribute__((always_inline)) -> float {
+        if constexpr (BF) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, xa), __builtin_bit_cast(bf2v, wa), acc, false);
+        else return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, xa), __builtin_bit_cast(half2v, wa), acc, false);
+    };
     float a = 0.f;
-    for (int g = 0; g < cin / 8; ++g)
+    for (int g = 0; g < G; ++g)
         for (int j = 0; j < k; ++j) {
             const int tt = t + j - pad;
-            if (tt < 0 || tt >= len) continue;
-            const int4v q = *reinterpret_cast<const int4v*>(xb + ((int64_t)g * x_ts + tt) * 8);
-            const unsigned u[4] = {(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a += wsm[(g * 8 + 2 * e) * k + j] * unpack16<BF>((unsigned short)(u[e] & 0xffffu));
-                a += wsm[(g * 8 + 2 * e + 1) * k + j] * unpack16<BF>((unsigned short)(u[e] >> 16));
-            }
+            if (tt < 0 || tt >= len) continue;  // (the slot is zero there; skipped so that the sum has the terms, and the order, of a whole run)
+            const int4v q = xs[g * XS + (int)threadIdx.x + j];
+            const int4v wv = wq[g * k + j];
+            a = dot2(q.x, wv.x, a);
+            a = dot2(q.y, wv.y, a);
+            a = dot2(q.z, wv.z, a);
+            a = dot2(q.w, wv.w, a);
         }
     if (pre) pre[(int64_t)b * pre_bs + t] = a;
     wave[(int64_t)b * wave_bs + t] = tanhf(a);
@@ -548,7 +575,8 @@ hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef
                               int emit_lo, const int* emit_hi) {
     if (tmax <= 0) return hipSuccess;
     dim3 grid((tmax + 255) / 256, batch);
-    const size_t lds = (size_t)cin * k * sizeof(float);
+    if (cin & 7) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(cin / 8) * (k + 256 + k - 1) * 16;
     if (arith == VITS_ARITH_BF16)
         VITS_KLAUNCH(conv_post16_kernel<true>, grid, dim3(256), lds, s, x.p, x.bs, x.ts, w, cin, k, pre.p, pre.bs, wave.p, wave.bs, lens, tmax, emit_lo, emit_hi);
     else
