@@ -169,6 +169,15 @@ __global__ __launch_bounds__(256, 2) void convt16_kernel(const ConvT16Params p) 
         for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // this row tile's biases, requested in front of the K loop (inside the epilogue every group's load sat behind the previous group's stores:
+        // a memory round trip per group, see convt16_lines_kernel)
+        float4v bias4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rho0 = rt * 32 + 8 * g + 4 * h;
+            bias4[g] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias4[g] = *reinterpret_cast<const float4v*>(p.bias + (rho0 - (rho0 / p.cout) * p.cout));
+        }
         LdsV xb = (LdsV)(xs + h * XW + cbase + 1);  // + 1: tap j reads position q - j = LDS column (q - t0) + 1 - j
         for (int s0 = 0; s0 < total; s0 += RS) {     // (total is a multiple of RS: the ring phase is the same at every row tile)
 #pragma unroll
@@ -190,8 +199,7 @@ __global__ __launch_bounds__(256, 2) void convt16_kernel(const ConvT16Params p) 
         for (int g = 0; g < 4; ++g) {
             const int rho0 = rt * 32 + 8 * g + 4 * h;
             const int ph = rho0 / p.cout, co0 = rho0 - ph * p.cout;
-            float4v bias = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bias = *reinterpret_cast<const float4v*>(p.bias + co0);
+            const float4v bias = bias4[g];
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int q = t0 + cbase + nr * 32;
@@ -308,6 +316,14 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < PH; ++k) ring[i][k] = load_a(k, i < total ? i : total - 1);
+        // the unit's biases, requested in front of the K loop: fetched inside the epilogue, every group's load sat behind the previous group's
+        // stores, and a load can only be waited for together with the stores issued before it (one in-order vmcnt): a memory round trip per group
+        float4v bias4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias4[g] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias4[g] = *reinterpret_cast<const float4v*>(p.bias + cb * 32 + 8 * g + 4 * h);
+        }
         LdsV xb = (LdsV)(xs + h * XW + cp * 64 + col + 1);
         for (int s0 = 0; s0 < total; s0 += 4) {  // one chunk per iteration: {tap 0, tap 1} x {k-half 0, 1}
 #pragma unroll
@@ -331,8 +347,7 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cb * 32 + 8 * g + 4 * h;
-            float4v bias = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bias = *reinterpret_cast<const float4v*>(p.bias + co0);
+            const float4v bias = bias4[g];
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int q = t0 + cp * 64 + nr * 32 + col;
