@@ -150,23 +150,48 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     out = {}
     noise_base = 4321
 
-    def run(models_ids, steps, warmup=2):
-        def one():
+    def run(models_ids, steps, warmup=2, pipelined=False):
+        """models_ids: [(model, ids, seed, [out buffers], cap)]. pipelined: every model handle keeps two batches in flight
+        (vits_model_submit_batch / vits_model_wait: stage one of batch i + 1 under the vocoder of batch i, bit-identical PCM); the timed
+        region takes K batches in and K results out, pipeline fill and drain included."""
+        def one(k):
             tot, frs = 0, []
-            for m, ids, seed, buf, cap in models_ids:
-                _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=seed, out_device=buf.data_ptr(), out_device_stride=cap,
-                                                     skip_host_copy=True, keep_pcm=False)
+            for m, ids, seed, bufs, cap in models_ids:
+                _, lengths, frames = m.process_batch(ids, mode=mode, noise_kind=pkg.NOISE_COUNTER, noise_seed=seed, out_device=bufs[k % len(bufs)].data_ptr(),
+                                                     out_device_stride=cap, skip_host_copy=True, keep_pcm=False)
                 tot += int(lengths.sum())
                 frs.append(frames)
             return tot, np.concatenate(frs)
-        for _ in range(warmup):
-            one()
+
+        def submit(k):
+            for m, ids, seed, bufs, cap in models_ids:
+                m.submit_batch(ids, mode=mode, noise_seed=seed, out_device=bufs[k % len(bufs)].data_ptr(), out_device_stride=cap, skip_host_copy=True)
+
+        def wait():
+            tot, frs = 0, []
+            for m, *_ in models_ids:
+                _, lengths, frames = m.wait(keep_pcm=False)
+                tot += int(lengths.sum())
+                frs.append(frames)
+            return tot, np.concatenate(frs)
+
+        for k in range(warmup):
+            one(k)
         torch.cuda.synchronize()
         t = time.perf_counter()
         samples = 0
-        for _ in range(steps):
-            n, frames = one()
+        if pipelined:
+            submit(0)
+            for k in range(1, steps):
+                submit(k)
+                n, frames = wait()
+                samples += n
+            n, frames = wait()
             samples += n
+        else:
+            for k in range(steps):
+                n, frames = one(k)
+                samples += n
         torch.cuda.synchronize()
         return time.perf_counter() - t, samples, frames
 
@@ -183,9 +208,24 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
             d.update({"binding_roof": "hbm" if hbm >= mf else "mfma_16bit", "frac_of_binding_roof": max(hbm, mf), "frac_hbm_algorithmic": hbm, "frac_mfma16": mf})
         return d
 
-    def buf_for(B, T):
+    def buf_for(B, T, n=1):
         cap = 256 * 8 * T + 294
-        return torch.empty((B, cap), dtype=torch.float32, device="cuda"), cap
+        return [torch.empty((B, cap), dtype=torch.float32, device="cuda") for _ in range(n)], cap
+
+    PIPE_NOTE = ("ONE model handle, two batches in flight (vits_model_submit_batch / vits_model_wait): stage one of batch i + 1 on the handle's front-end "
+                 "stream under the vocoder of batch i; PCM bit-identical to vits_model_process_batch (GPU test); K batches in and K results out inside the "
+                 "timed region, fill and drain included")
+
+    def both(name, models_ids, n, T, arith, utterances, warmup=2):
+        """serial calls (vits_model_process_batch, one batch in flight) and the pipelined schedule on the same handle(s); `value` is the
+        pipelined one, the serial figure stays beside it"""
+        e, s_, fr = run(models_ids, n, warmup=warmup)
+        serial = entry(e, s_, fr, n, T, arith, utterances)
+        e, s_, fr = run(models_ids, n, warmup=1, pipelined=True)
+        d = entry(e, s_, fr, n, T, arith, utterances)
+        d["schedule"] = PIPE_NOTE
+        d["serial_calls"] = {k: serial[k] for k in ("value", "ms_per_step", "algorithmic_tflops", "frac_of_binding_roof")}
+        out[name] = d
 
     # c2: batch 1, fp32
     ids1 = pkg.synth_ids(1, 128)
@@ -194,14 +234,17 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     e, s_, fr = run([(base_model, ids1, noise_base, b, cap)], n, warmup=5)
     out["c2_f32"] = entry(e, s_, fr, n, 128, "f32", 1)
     out["c2_f32"]["ms_per_utterance"] = 1000.0 * e / n
-    # c3 in the 16-bit arithmetic modes (default scope: stage one exact, durations identical to the fp32 run's)
+    out["c2_f32"]["schedule"] = "serial calls (latency figure: one utterance in, its PCM out)"
+    # c3 in fp32 (pipelined beside the headline's serial figure) and in the 16-bit arithmetic modes (default scope: stage one exact,
+    # durations identical to the fp32 run's)
     ids64 = pkg.synth_ids(64, 128)
-    b, cap = buf_for(64, 128)
+    b, cap = buf_for(64, 128, 2)
+    n = max(3, int(6 * steps_scale))
+    both("c3_f32", [(base_model, ids64, noise_base, b, cap)], n, 128, "f32", 64)
     for name, arith in (("f16", pkg.ARITH_F16), ("bf16", pkg.ARITH_BF16)):
         base_model.set_arith(arith)
-        n = max(3, int(10 * steps_scale))
-        e, s_, fr = run([(base_model, ids64, noise_base, b, cap)], n)
-        out["c3_" + name] = entry(e, s_, fr, n, 128, name, 64)
+        n = max(3, int(16 * steps_scale))
+        both("c3_" + name, [(base_model, ids64, noise_base, b, cap)], n, 128, name, 64)
     base_model.set_arith(pkg.ARITH_F32)
     del b
     # c5: two resident bf16-stored models, 8 x 1024 ids each, calls interleaved
@@ -210,15 +253,14 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     for seed, ids_seed in specs:
         m = pkg.Model(pkg.synth_model_bytes(seed, pkg.SYNTH_FULL | pkg.SYNTH_BF16))
         m.set_mode(mode)
-        bb, cap = buf_for(8, 1024)
+        bb, cap = buf_for(8, 1024, 2)
         ms.append((m, pkg.synth_ids(8, 1024, ids_seed=ids_seed), noise_base, bb, cap))
     try:
         for name, arith in (("f32", pkg.ARITH_F32), ("bf16", pkg.ARITH_BF16)):
             for m, *_ in ms:
                 m.set_arith(arith)
-            n = max(2, int((3 if name == "f32" else 5) * steps_scale))
-            e, s_, fr = run(ms, n, warmup=1)
-            out["c5_" + name] = entry(e, s_, fr, n, 1024, name, 16)
+            n = max(2, int((3 if name == "f32" else 6) * steps_scale))
+            both("c5_" + name, ms, n, 1024, name, 16, warmup=1)
     finally:
         for m, *_ in ms:
             m.close()

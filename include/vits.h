@@ -167,6 +167,26 @@ VITS_API void vits_free_batch_result(vits_batch_result* r);
 /* Block until everything queued by this model has finished. */
 VITS_API int vits_model_sync(vits_model* model);
 
+/* ---- pipelined batches on ONE handle ------------------------------------------------------------------------------------
+ * vits_model_process_batch is one call in, one result out: its stage one (text encoder + duration predictor, vits.cpp:244-440,
+ * 927-972: ~110 small, latency-bound launches in exact fp32) runs with the matrix cores mostly idle, and the host read of the
+ * frame counts (vits.cpp:1133) drains the device once per call. The pair below keeps up to TWO batches in flight on one model
+ * handle: vits_model_submit_batch(i + 1) queues stage one of batch i + 1 on the handle's front-end stream (its own stage-one
+ * arena), where it runs UNDER the flow / vocoder kernels of batch i, reads its frame counts while the device is busy, queues its
+ * flow + vocoder behind batch i's on the main stream and returns; vits_model_wait() returns the results of the OLDEST submitted
+ * batch (in submission order). Every kernel is batch-invariant and runs on the same operands as in vits_model_process_batch, so
+ * the PCM, lengths and frames are BIT-IDENTICAL to it (GPU test). Typical loop:
+ *     submit(0); for (i = 1; i < n; ++i) { submit(i); wait(&r[i-1]); } wait(&r[n-1]);
+ * Restrictions (checked; -1 + vits_last_error): VITS_NOISE_COUNTER only (no host noise buffers outlive the call), no collect_taps,
+ * on_chunk, frames_only or async; at most two batches in flight; opts.out_device buffers of in-flight batches must be distinct.
+ * While batches are in flight the other entry points that use the device (process*, set_arith, taps) refuse with "batches in flight".
+ * With the per-kernel profiler enabled the two stages run serialised on the main stream (events need non-overlapping kernels).
+ * Both return 0 on success. vits_model_pending = number of submitted batches not yet waited for (0..2). */
+VITS_API int vits_model_submit_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
+                                     const vits_process_opts* opts);
+VITS_API int vits_model_wait(vits_model* model, vits_batch_result* out);
+VITS_API int vits_model_pending(const vits_model* model);
+
 /* Tokenizer only (src/vits_tokenizer.cpp:182-208). Writes up to cap ids, returns the count (or -1). */
 VITS_API int64_t vits_model_tokenize(vits_model* model, const char* text, int32_t* ids, size_t cap);
 

@@ -122,6 +122,53 @@ int main(void) {
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
 
 
+def test_busy_guard_admits_one_caller(tmp_path):
+    """csrc/busy_guard.h (the flag the C ABI takes around every entry point of a model handle: a second caller gets "model busy"
+    instead of racing on the arenas; reference contract: src/include/vits.h:22-30) as a CPU unit test: eight threads contend for one
+    flag — never two inside, refusals do happen, a nested attempt from the owner is refused, the flag is free afterwards."""
+    import subprocess
+    src = tmp_path / "busy.cpp"
+    src.write_text(r'''
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include <vector>
+#include "busy_guard.h"
+int main() {
+    std::atomic<bool> flag{false};
+    std::atomic<int> inside{0}, worst{0}, entered{0}, refused{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; ++t)
+        th.emplace_back([&] {
+            for (int i = 0; i < 20000; ++i) {
+                vits::BusyGuard g(&flag);
+                if (!g.entered()) { ++refused; continue; }
+                const int now = ++inside;
+                int w = worst.load();
+                while (now > w && !worst.compare_exchange_weak(w, now)) {}
+                vits::BusyGuard nested(&flag);  // a callback re-entering its own handle
+                if (nested.entered()) worst = 99;
+                ++entered;
+                --inside;
+            }
+        });
+    for (auto& t : th) t.join();
+    vits::BusyGuard none(nullptr);
+    std::printf("%d %d %d %d %d\n", worst.load(), entered.load(), refused.load(), (int)flag.load(), (int)none.entered());
+    return 0;
+}
+''')
+    exe = tmp_path / "busy"
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Werror", "-I", os.path.join(ROOT, "vits.cpp_amd", "csrc"), str(src), "-o", str(exe)],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    worst, entered, refused, flag, none = map(int, subprocess.run([str(exe)], capture_output=True, text=True).stdout.split())
+    assert worst == 1 and entered > 0 and entered + refused == 8 * 20000 and flag == 0 and none == 0
+    # and the ABI uses it at every entry point that touches an engine
+    abi = open(os.path.join(ROOT, "vits.cpp_amd", "csrc", "abi.cpp")).read()
+    assert abi.count("VITS_ENTER(model") >= 12
+
+
 # ---- model files whose tensor shapes disagree with the hyper-parameters must be rejected at load ------------------------
 def _tensor_headers(data):
     """(name, header offset of `rank`, rank, ne list, nbytes) for every tensor record of a model file (SURVEY.md App. C)."""

@@ -336,7 +336,7 @@ def test_16bit_kernel_choices_do_not_change_a_single_bit(name):
     base = run({})
     for extra in ({"VITS_NO_CONVT16S": "1"}, {"VITS_NO_CONVT16L": "1"}, {"VITS_CONVT16S_ALL": "1"}, {"VITS_NO_RBBLOCK16": "1"}, {"VITS_RBB_C64K11": "1"}, {"VITS_RBB_C128": "0"},
                   {"VITS_NO_FUSE16": "1", "VITS_NO_CONVT16S": "1"}, {"VITS_RB_STREAMS": "1"}, {"VITS_NO_FLOW_FUSE": "1"}, {"VITS_FLOW_NCW": "1"},
-                  {"VITS_NO_FLOW_FUSE": "1", "VITS_NO_WN_FUSE": "1"}):
+                  {"VITS_NO_FLOW_FUSE": "1", "VITS_NO_WN_FUSE": "1"}, {"VITS_NO_FLOW_FUSE": "1", "VITS_WN16_NCW": "2"}, {"VITS_ATT_NW": "8"}, {"VITS_ATT_SHORT": "0"}):
         assert run(extra) == base, extra
 
 
@@ -429,3 +429,32 @@ def test_fused_fp32_resblock_pair_is_bit_identical_to_the_two_kernel_path(pkg, f
                 assert np.array_equal(x, y), (mode, w)
         for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name,arith,_tol", ARITHS)
+def test_converter_path_keeps_its_arithmetic_under_the_profiler_and_the_grouped_schedule(pkg, full_bytes, monkeypatch, name, arith, _tol):
+    """on the fp32-layout (converter) path of a 16-bit mode (VITS_NO_GROUP16=1) the schedule must not change the arithmetic:
+    the grouped launch and the fused fp32 pairs are fp32 kernels and stay out of a 16-bit run. Profiler on (which prefers the grouped
+    schedule), VITS_RB_GROUP=1 and the plain three-stream run give the same PCM bit for bit — and it is NOT the fp32 PCM."""
+    ids = pkg.synth_ids(3, 40, ids_seed=77)
+    monkeypatch.setenv("VITS_NO_GROUP16", "1")
+    outs = {}
+    with pkg.Model(full_bytes) as m:
+        f32 = m.process_batch(ids, noise_seed=12)
+        m.set_arith(arith)
+        outs["plain"] = m.process_batch(ids, noise_seed=12)
+        m.prof_enable(True)
+        outs["prof"] = m.process_batch(ids, noise_seed=12)
+        m.prof_enable(False)
+        names = [k["name"] for k in m.prof_report()["kernels"]]
+        bad = [n for n in names if "resblock_group" in n or (n.startswith("hifigan_resblock_pair") and "|f" in n)]  # conv_group_kernel / rbpair32
+        assert not bad, bad
+    monkeypatch.setenv("VITS_RB_GROUP", "1")
+    with pkg.Model(full_bytes) as m:
+        m.set_arith(arith)
+        outs["grouped"] = m.process_batch(ids, noise_seed=12)
+    for k in ("prof", "grouped"):
+        assert np.array_equal(outs["plain"][1], outs[k][1])
+        for x, y in zip(outs["plain"][0], outs[k][0]):
+            assert np.array_equal(x, y), k
+    assert any(not np.array_equal(x, y) for x, y in zip(outs["plain"][0], f32[0]))

@@ -1,0 +1,184 @@
+"""Pipelined batches on ONE model handle (include/vits.h: vits_model_submit_batch / vits_model_wait) and the busy guard.
+
+The contract of the pipeline is BIT-IDENTITY with vits_model_process_batch (which the other GPU tests pin against the oracle):
+stage one of batch i + 1 runs on the handle's front-end stream under the vocoder of batch i, in its own stage-one arena; every
+kernel is batch-invariant and sees the same operands, so PCM, lengths and frames cannot change — whatever the interleaving."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_model(pkg, full_bytes):
+    m = pkg.Model(full_bytes)
+    yield m
+    m.close()
+
+
+def ragged_ids(pkg, lens, seed=0):
+    stride = max(lens)
+    ids = np.zeros((len(lens), stride), np.int32)
+    for b, n in enumerate(lens):
+        ids[b, :n] = pkg.synth_ids(1, n, ids_seed=1234 + 17 * seed + b)[0]
+    return ids, np.asarray(lens, np.int32)
+
+
+BATCHES = [[40, 5, 64, 17, 1], [128] * 6, [3, 90], [33], [64, 64, 12, 100, 7, 7, 51, 2]]
+
+
+@pytest.mark.parametrize("arith", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pipelined_batches_are_bit_identical_to_process_batch(pkg, full_model, arith, mode):
+    m = full_model
+    m.set_arith({"f32": pkg.ARITH_F32, "f16": pkg.ARITH_F16, "bf16": pkg.ARITH_BF16}[arith])
+    try:
+        jobs = [ragged_ids(pkg, lens, seed=s) for s, lens in enumerate(BATCHES)]
+        want = [m.process_batch(ids, id_lengths=lens, mode=mode, noise_seed=900 + s) for s, (ids, lens) in enumerate(jobs)]
+        got = []
+        m.submit_batch(jobs[0][0], id_lengths=jobs[0][1], mode=mode, noise_seed=900)
+        for s in range(1, len(jobs)):
+            m.submit_batch(jobs[s][0], id_lengths=jobs[s][1], mode=mode, noise_seed=900 + s)
+            assert m.pending == 2
+            got.append(m.wait())
+        got.append(m.wait())
+        assert m.pending == 0
+        for (pw, lw, fw), (pg, lg, fg) in zip(want, got):
+            assert np.array_equal(lw, lg) and np.array_equal(fw, fg)
+            for a, b in zip(pw, pg):
+                assert np.array_equal(a, b)
+        # the serial entry point still gives the same answer afterwards (arena slot 0 again)
+        again = m.process_batch(jobs[1][0], id_lengths=jobs[1][1], mode=mode, noise_seed=901)
+        for a, b in zip(want[1][0], again[0]):
+            assert np.array_equal(a, b)
+    finally:
+        m.set_arith(pkg.ARITH_F32)
+
+
+def test_pipelined_device_output_pinned_durations_and_windows(pkg, full_model):
+    """out_device buffers (the bench's configuration), pinned durations (no host read orders the two streams: an event does),
+    and the windowed vocoder inside a pipelined batch."""
+    import torch
+    m = full_model
+    ids = pkg.synth_ids(4, 48)
+    cap = 256 * 8 * 48 + 294
+    for kw in (dict(), dict(fixed_duration=2), dict(vocoder_chunk_frames=37)):
+        want = [m.process_batch(ids, noise_seed=70 + s, **kw) for s in range(3)]
+        bufs = [torch.zeros((4, cap), dtype=torch.float32, device="cuda") for _ in range(3)]
+        m.submit_batch(ids, noise_seed=70, out_device=bufs[0].data_ptr(), out_device_stride=cap, skip_host_copy=True, **kw)
+        res = []
+        for s in (1, 2):
+            m.submit_batch(ids, noise_seed=70 + s, out_device=bufs[s].data_ptr(), out_device_stride=cap, skip_host_copy=True, **kw)
+            res.append(m.wait())
+        res.append(m.wait())
+        for s in range(3):
+            pw, lw, fw = want[s]
+            pg, lg, fg = res[s]
+            assert pg is None and np.array_equal(lw, lg) and np.array_equal(fw, fg)
+            host = bufs[s].cpu().numpy()
+            for b in range(4):
+                assert np.array_equal(host[b, : lw[b]], pw[b])
+
+
+def test_pipeline_with_the_profiler_on_runs_serialised_and_equal(pkg, full_model):
+    m = full_model
+    ids, lens = ragged_ids(pkg, [30, 77, 4])
+    want = [m.process_batch(ids, id_lengths=lens, noise_seed=5 + s) for s in range(2)]
+    m.prof_reset()
+    m.prof_enable(True)
+    try:
+        m.submit_batch(ids, id_lengths=lens, noise_seed=5)
+        m.submit_batch(ids, id_lengths=lens, noise_seed=6)
+        got = [m.wait(), m.wait()]
+    finally:
+        m.prof_enable(False)
+    assert len(m.prof_report()["kernels"]) > 10
+    for (pw, lw, _), (pg, lg, _) in zip(want, got):
+        assert np.array_equal(lw, lg)
+        for a, b in zip(pw, pg):
+            assert np.array_equal(a, b)
+
+
+def test_pipeline_misuse_is_refused(pkg, full_model):
+    m = full_model
+    L = pkg.lib()
+    ids = pkg.synth_ids(2, 16)
+    with pytest.raises(pkg.VitsError, match="nothing was submitted"):
+        m.wait()
+    m.submit_batch(ids)
+    m.submit_batch(ids)
+    with pytest.raises(pkg.VitsError, match="two batches in flight"):
+        m.submit_batch(ids)
+    with pytest.raises(pkg.VitsError, match="batches in flight"):
+        m.process_batch(ids)
+    with pytest.raises(pkg.VitsError, match="batches in flight"):
+        m.set_arith(pkg.ARITH_F16)
+    with pytest.raises(pkg.VitsError, match="batches in flight"):
+        m.process_ids(ids[0])
+    a = m.wait()
+    b = m.wait()
+    assert m.pending == 0
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y)  # same ids, same seed
+    # host noise buffers do not outlive a call: only the counter stream is accepted
+    import ctypes as C
+    o = pkg.ProcessOpts()
+    o.struct_size = C.sizeof(pkg.ProcessOpts)
+    o.mode, o.noise_kind = pkg.MODE_DEFAULT, pkg.NOISE_REFERENCE
+    lens = np.full(2, 16, np.int32)
+    assert L.vits_model_submit_batch(m._h, pkg._ptr(ids), pkg._ptr(lens), 2, 16, C.byref(o)) == -1
+    assert "VITS_NOISE_COUNTER" in pkg.last_error()
+    o.noise_kind, o.collect_taps = pkg.NOISE_COUNTER, 1
+    assert L.vits_model_submit_batch(m._h, pkg._ptr(ids), pkg._ptr(lens), 2, 16, C.byref(o)) == -1
+    assert m.pending == 0
+    m.process_batch(ids)  # and the handle is still usable
+
+
+def test_a_busy_handle_refuses_a_second_caller(pkg, full_model):
+    """One call at a time per handle (the reference's contract, src/include/vits.h:22-30), enforced: (a) a streaming callback that
+    re-enters its own handle, deterministically; (b) a second thread while a long batch runs."""
+    m = full_model
+    ids, lens = ragged_ids(pkg, [48, 9])
+    seen = []
+
+    def sink(utt, offset, pcm):
+        for call in (m.sync, lambda: m.process_ids(ids[0, :9]), lambda: m.set_mode(pkg.MODE_HF), lambda: m.tap("durations")):
+            try:
+                call()
+                seen.append("entered")
+            except pkg.VitsError as e:
+                seen.append(str(e))
+        return False
+
+    m.process_batch(ids, id_lengths=lens, vocoder_chunk_frames=32, on_chunk=sink)
+    assert seen and all("model busy" in s or "no tap" in s for s in seen), seen[:4]
+    assert any("model busy" in s for s in seen)
+    assert m.mode == pkg.MODE_REFERENCE  # the refused set_mode changed nothing
+    # (b) another thread
+    big = pkg.synth_ids(32, 128)
+    errs, done = [], []
+
+    def worker():
+        while True:  # (the main thread's sync may hold the handle at the instant this call enters: that refusal is the guard working too)
+            try:
+                done.append(m.process_batch(big, keep_pcm=False, skip_host_copy=False)[1].sum())
+                return
+            except pkg.VitsError as e:
+                assert "model busy" in str(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t0 = time.perf_counter()
+    while t.is_alive() and time.perf_counter() - t0 < 30:
+        try:
+            m.sync()
+        except pkg.VitsError as e:
+            errs.append(str(e))
+            break
+    t.join()
+    assert done and done[0] > 0
+    assert errs and "model busy" in errs[0]
+    m.process_batch(ids, id_lengths=lens)  # released again

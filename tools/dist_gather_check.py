@@ -103,6 +103,43 @@ def main():
             for u in range(total):
                 n = int(rl[u])
                 assert torch.equal(g[u, :n], ref[u, :n]), f"rank {rank}: exchange step {i} utterance {u} differs (pcm16={pcm16})"
+    # 4) padded blocks on the exchange stream: row_capacity > rows makes every rank's block carry padding rows, so the
+    # `keep` path runs even with one rank. The exchange's buffers are POISONED first: a reader that is not ordered behind the
+    # all-gather (or an index_select on another stream) would hand out poison, not a lucky copy of the right data -------------------
+    for pcm16 in (False, True):
+        blocks = []
+        ex = mg.PcmExchange(len(mine), cap, dtype=torch.int16 if pcm16 else torch.float32, device="cuda", row_capacity=len(mine) + 2,
+                            on_block=lambda step, g_, gl_: blocks.append((step, g_.clone(), gl_.clone())))
+        assert ex.keep is not None and ex.kept is not None
+        poison = 0x7A7A if pcm16 else float("nan")
+        ex.out.fill_(poison)
+        ex.kept.fill_(poison)
+        ex.send.fill_(poison)
+        torch.cuda.synchronize()
+        bufs = [torch.zeros((len(mine), cap), dtype=torch.float32, device="cuda") for _ in range(3)]
+        bufs16 = [torch.zeros((len(mine), cap), dtype=torch.int16, device="cuda") for _ in range(3)]
+        refs = []
+        for i in range(4):
+            _, lengths, _ = m.process_batch(ids_all[mine], noise_seed=base + 7 * i, noise_seed_offsets=np.asarray(mine, np.int32), out_device=bufs[i % 3].data_ptr(),
+                                            out_device_stride=cap, skip_host_copy=True)
+            lens_d = torch.from_numpy(lengths).cuda()
+            src = bufs[i % 3]
+            if pcm16:
+                pkg.pcm16_device(src.data_ptr(), src.stride(0), bufs16[i % 3].data_ptr(), bufs16[i % 3].stride(0), len(mine), cap, lengths_ptr=lens_d.data_ptr(),
+                                 stream=torch.cuda.current_stream().cuda_stream)
+                src = bufs16[i % 3]
+            refs.append((src.clone(), lengths.copy()))
+            ex.submit(src, lens_d)
+        ex.flush()
+        assert [b[0] for b in blocks] == [0, 1, 2, 3] and ex.bmax == len(mine) + 2
+        lo_row = sum(ex.counts[:rank])
+        for i, (_, g, gl) in enumerate(blocks):
+            assert g.shape[0] == total and gl.shape[0] == total  # padding rows gone
+            want, wl = refs[i]
+            for r in range(len(mine)):
+                n = int(wl[r])
+                assert int(gl[lo_row + r]) == n
+                assert torch.equal(g[lo_row + r, :n], want[r, :n]), f"rank {rank}: padded exchange step {i} row {r} differs (pcm16={pcm16})"
     dist.barrier()
     dist.destroy_process_group()
     m.close()

@@ -10,10 +10,12 @@ TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1,
 _CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
 _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
 _WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)(?:, \d+)?>")
-_COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)>")
+_COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)(?:, \d+)?>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
-_RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
-_CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\w+)>")
+# rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF> (block-shape parameters between C and the dilations: any number of them)
+_RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+)(?:, \d+)*?, (\d+), (\d+), (\d+), (\w+)>")
+_CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\d+), (\w+)>")
+_CONVT16L = re.compile(r"convt16_lines_kernel<(\d+), (\w+)>")
 _GROUP = re.compile(r"conv_group_kernel<(-?\d+)>")
 _RBPAIR32 = re.compile(r"rbpair32_kernel<(-?\d+), (-?\d+), (\d+)>")
 _RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)(?:, \w+)?>")
@@ -49,12 +51,16 @@ def bench_key(kernel_name):
         kt, dil, c = m.groups()
         return f"k{kt}|d{dil}|f{c}|e0"
     m = _RBBLOCK16.search(kernel_name)
-    if m:  # `rbblock16_kernel<11, 64, 1, 3, 5, false>` -> `k11|d135|B64|e0g`
+    if m:  # `rbblock16_kernel<11, 32, 4, 3, 1, 1, 3, 5, false>` -> `k11|d135|B32|e0g`
         kt, c, d0, d1, d2, _ = m.groups()
         return f"k{kt}|d{d0}{d1}{d2}|B{c}|e0g"
     m = _CONVT16.search(kernel_name)
-    if m:  # `convt16_kernel<4, 1, false>` -> `k2|d-1|S|e2g` (the engine prints the stride behind the S; one rocprof name serves several stages)
-        return "k2|d-1|S|e2g"
+    if m:  # `convt16_kernel<4, 1, 16, false>` -> `k2|d-1|S4.1.16|e2g` (the engine prints the same tag: kernels.h convt16_stream_tag)
+        nr, cs, rs, _ = m.groups()
+        return f"k2|d-1|S{nr}.{cs}.{rs}|e2g"
+    m = _CONVT16L.search(kernel_name)
+    if m:  # `convt16_lines_kernel<128, false>` -> `k2|d-1|SL128|e2g`
+        return f"k2|d-1|SL{m.group(1)}|e2g"
     m = _GROUP.search(kernel_name)
     if m:  # `conv_group_kernel<3>` -> `kG|d3|G0|e0` (two or three member convolutions of 11 / 7 / 3 taps per launch, 128 x 128 tile)
         return f"kG|d{m.group(1)}|G0|e0"

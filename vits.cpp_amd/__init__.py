@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "vits_op_rel_attention", "vits_op_add_layer_norm", "vits_device_info", "vits_set_device", "vits_model_file_reserialize",
     "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
     "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
-    "vits_model_set_arith_scope", "vits_model_get_arith_scope",
+    "vits_model_set_arith_scope", "vits_model_get_arith_scope", "vits_model_submit_batch", "vits_model_wait", "vits_model_pending",
 ]
 
 
@@ -138,6 +138,12 @@ def lib():
     L.vits_free_batch_result.argtypes = [C.POINTER(BatchResult)]
     L.vits_model_sync.restype = i32
     L.vits_model_sync.argtypes = [vp]
+    L.vits_model_submit_batch.restype = i32
+    L.vits_model_submit_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(ProcessOpts)]
+    L.vits_model_wait.restype = i32
+    L.vits_model_wait.argtypes = [vp, C.POINTER(BatchResult)]
+    L.vits_model_pending.restype = i32
+    L.vits_model_pending.argtypes = [vp]
     L.vits_model_tokenize.restype = i64
     L.vits_model_tokenize.argtypes = [vp, C.c_char_p, vp, sz]
     L.vits_model_sampling_rate.restype = i32
@@ -401,6 +407,51 @@ class Model:
             return pcm, lengths, frames
         finally:
             lib().vits_free_batch_result(C.byref(res))
+
+    def submit_batch(self, ids, id_lengths=None, mode=MODE_DEFAULT, noise_seed=4321, fixed_duration=0, out_device=None, out_device_stride=0,
+                     skip_host_copy=False, vocoder_chunk_frames=0, noise_seed_offsets=None):
+        """vits_model_submit_batch: queue one batch on this handle's pipeline (at most two in flight); its stage one runs under the
+        previous batch's vocoder. Results come from wait(), in submission order, bit-identical to process_batch."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.ndim == 1:
+            ids = ids[None, :]
+        B, stride = ids.shape
+        lens = np.full(B, stride, np.int32) if id_lengths is None else np.ascontiguousarray(id_lengths, dtype=np.int32)
+        o = ProcessOpts()
+        o.struct_size = C.sizeof(ProcessOpts)
+        o.mode, o.noise_kind, o.noise_seed = mode, NOISE_COUNTER, noise_seed
+        o.fixed_duration = fixed_duration
+        o.out_device = out_device
+        o.out_device_stride = out_device_stride
+        o.skip_host_copy = int(skip_host_copy)
+        o.vocoder_chunk_frames = int(vocoder_chunk_frames)
+        nso = None if noise_seed_offsets is None else np.ascontiguousarray(noise_seed_offsets, dtype=np.int32)
+        if nso is not None and nso.size != B:
+            raise ValueError("noise_seed_offsets needs one entry per utterance")
+        o.noise_seed_offsets = _ptr(nso)
+        if lib().vits_model_submit_batch(self._h, _ptr(ids), _ptr(lens), B, stride, C.byref(o)) != 0:
+            raise VitsError(last_error())
+
+    def wait(self, keep_pcm=True):
+        """vits_model_wait: (pcm list or None, lengths, frames) of the oldest submitted batch."""
+        res = BatchResult()
+        if lib().vits_model_wait(self._h, C.byref(res)) != 0:
+            raise VitsError(last_error())
+        try:
+            B = res.batch
+            lengths = np.ctypeslib.as_array(res.lengths, shape=(B,)).copy()
+            frames = np.ctypeslib.as_array(res.frames, shape=(B,)).copy()
+            pcm = None
+            if res.data and keep_pcm:
+                full = np.ctypeslib.as_array(res.data, shape=(B, res.stride))
+                pcm = [full[b, : lengths[b]].copy() for b in range(B)]
+            return pcm, lengths, frames
+        finally:
+            lib().vits_free_batch_result(C.byref(res))
+
+    @property
+    def pending(self):
+        return lib().vits_model_pending(self._h)
 
     def sync(self):
         if lib().vits_model_sync(self._h) != 0:

@@ -2,6 +2,7 @@
 // std::runtime_error escape and calls exit(1) from ASSERT: /root/reference/src/vits_model_data.cpp:102,144,
 // src/include/debug.h:29-36); failures return NULL / {NULL,0} / -1 and set vits_last_error().
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -10,6 +11,7 @@
 #include <vector>
 
 #include "../../include/vits.h"
+#include "busy_guard.h"
 #include "engine.h"
 
 namespace vits {
@@ -32,6 +34,14 @@ static void set_err(const std::string& e) { g_last_error = e; }
     }
 
 VITS_API const char* vits_last_error(void) { return g_last_error.c_str(); }
+
+// One call at a time per model handle, enforced (busy_guard.h). Distinct handles run concurrently.
+#define VITS_ENTER(model, ret)                                                                                                          \
+    vits::BusyGuard busy_guard_((model) ? &const_cast<vits_model*>(model)->eng.busy : nullptr);                                        \
+    if ((model) && !busy_guard_.entered()) {                                                                                                 \
+        set_err("model busy: another call is in progress on this handle (one call at a time per model; use one handle per thread)"); \
+        return ret;                                                                                                                     \
+    }
 
 // reference: src/vits.cpp:1205-1215
 VITS_API vits_model* vits_model_load_from_bytes(const char* bytes, size_t size) {
@@ -85,6 +95,7 @@ static vits_result process_ids_impl(vits_model* model, const int32_t* ids, size_
         set_err(n == 0 ? "empty input (no known symbols in the text)" : "null argument");
         return r;
     }
+    VITS_ENTER(model, r)
     vits_process_opts o;
     std::memset(&o, 0, sizeof(o));
     o.struct_size = sizeof(o);
@@ -132,6 +143,7 @@ VITS_API int vits_model_set_mode(vits_model* model, int mode) {
         set_err("bad mode");
         return -1;
     }
+    VITS_ENTER(model, -1)
     model->eng.mode = mode;
     return 0;
 }
@@ -143,7 +155,12 @@ VITS_API int vits_model_set_arith(vits_model* model, int arith) {
         set_err("bad arithmetic mode");
         return -1;
     }
+    VITS_ENTER(model, -1)
     std::string err;
+    if (model->eng.pending()) {
+        set_err("batches in flight: call vits_model_wait for every submitted batch first");
+        return -1;
+    }
     if (model->eng.set_arith(arith, err) != 0) {
         set_err(err);
         return -1;
@@ -155,6 +172,11 @@ VITS_API int vits_model_get_arith(const vits_model* model) { return model ? mode
 VITS_API int vits_model_set_arith_scope(vits_model* model, int scope) {
     if (!model || (scope != VITS_ARITH_SCOPE_FLOW_VOCODER && scope != VITS_ARITH_SCOPE_ALL_CONVS)) {
         set_err("bad arithmetic scope");
+        return -1;
+    }
+    VITS_ENTER(model, -1)
+    if (model->eng.pending()) {
+        set_err("batches in flight: call vits_model_wait for every submitted batch first");
         return -1;
     }
     model->eng.arith_scope = scope;
@@ -170,6 +192,7 @@ VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, con
         set_err("null argument");
         return -1;
     }
+    VITS_ENTER(model, -1)
     vits_process_opts o;
     std::memset(&o, 0, sizeof(o));
     o.mode = VITS_MODE_DEFAULT;
@@ -185,6 +208,46 @@ VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, con
     VITS_CATCH(-1)
 }
 
+VITS_API int vits_model_submit_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
+                                     const vits_process_opts* opts) {
+    VITS_TRY
+    if (!model || !ids) {
+        set_err("null argument");
+        return -1;
+    }
+    VITS_ENTER(model, -1)
+    vits_process_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.mode = VITS_MODE_DEFAULT;
+    o.noise_kind = VITS_NOISE_COUNTER;
+    if (opts) std::memcpy(&o, opts, std::min<size_t>(sizeof(o), opts->struct_size ? opts->struct_size : sizeof(o)));
+    std::string err;
+    const int rc = model->eng.submit_batch(ids, id_lengths, batch, id_stride, o, err);
+    if (rc != 0) set_err(err);
+    return rc;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_model_wait(vits_model* model, vits_batch_result* out) {
+    VITS_TRY
+    if (out) std::memset(out, 0, sizeof(*out));
+    if (!model) {
+        set_err("null argument");
+        return -1;
+    }
+    VITS_ENTER(model, -1)
+    std::string err;
+    const int rc = model->eng.wait_batch(out, err);
+    if (rc != 0) {
+        set_err(err);
+        if (out) vits_free_batch_result(out);
+    }
+    return rc;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_model_pending(const vits_model* model) { return model ? model->eng.pending() : -1; }
+
 VITS_API void vits_free_batch_result(vits_batch_result* r) {
     if (!r) return;
     delete[] r->data;
@@ -196,6 +259,7 @@ VITS_API void vits_free_batch_result(vits_batch_result* r) {
 VITS_API int vits_model_sync(vits_model* model) {
     VITS_TRY
     if (!model) return -1;
+    VITS_ENTER(model, -1)
     std::string err;
     const int rc = model->eng.sync(err);
     if (rc) set_err(err);
@@ -219,6 +283,7 @@ VITS_API int64_t vits_model_weight_bytes(const vits_model* model) { return model
 VITS_API int64_t vits_model_get_tap(vits_model* model, const char* name, int32_t utt, float* dst, size_t cap) {
     VITS_TRY
     if (!model || !name) return 0;
+    VITS_ENTER(model, 0)
     return model->eng.get_tap(name, utt, dst, cap);
     VITS_CATCH(0)
 }
@@ -288,11 +353,17 @@ VITS_API int64_t vits_model_file_tokenize(const char* model_bytes, size_t size, 
 
 VITS_API int vits_prof_enable(vits_model* model, int32_t on) {
     if (!model) return -1;
+    VITS_ENTER(model, -1)
+    if (model->eng.pending()) {
+        set_err("batches in flight: call vits_model_wait for every submitted batch first");
+        return -1;
+    }
     model->eng.prof.on = on != 0;
     return 0;
 }
 VITS_API int vits_prof_reset(vits_model* model) {
     if (!model) return -1;
+    VITS_ENTER(model, -1)
     hipStreamSynchronize(model->eng.stream);
     model->eng.prof.reset();
     return 0;
@@ -300,6 +371,7 @@ VITS_API int vits_prof_reset(vits_model* model) {
 VITS_API int64_t vits_prof_report(vits_model* model, char* buf, size_t cap) {
     VITS_TRY
     if (!model || !buf || !cap) return -1;
+    VITS_ENTER(model, -1)
     hipStreamSynchronize(model->eng.stream);
     std::string s = model->eng.prof.report();
     const size_t n = std::min(cap - 1, s.size());

@@ -670,12 +670,12 @@ static hipError_t launch_tile16(int tile, const Conv16Params& p, int mtiles_used
     const size_t lds = (size_t)p.nbuf * 4 * p.xwp * 16;
 #define VITS_LAUNCH16(WM, WN, MR, NR)                                                                                                \
     do {                                                                                                                             \
-        static std::atomic<bool> big_lds_set{false};                                                                                 \
-        if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {                                                       \
+        static BigLdsOnce big_lds_set;                                                                                 \
+        if (lds > 64 * 1024 && big_lds_set.needed()) {                                                       \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<KT, DIL, WM, WN, MR, NR, EPI, kBF>),     \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
             if (ea != hipSuccess) return ea;                                                                                         \
-            big_lds_set.store(true, std::memory_order_release);                                                                      \
+            big_lds_set.done();                                                                      \
         }                                                                                                                            \
         VITS_KLAUNCH((conv16_kernel<KT, DIL, WM, WN, MR, NR, EPI, kBF>), grid, dim3(320), lds, s, p);                          \
     } while (0)

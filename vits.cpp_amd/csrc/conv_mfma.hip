@@ -1046,12 +1046,12 @@ static hipError_t launch_tile(const PackedConv& w, int tile, const ConvParams& p
     const size_t lds = DB ? (size_t)p.nbuf * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * sizeof(float) : (size_t)CK * p.xw * sizeof(float);
 #define VITS_LAUNCH(WM, WN, MR, NR)                                                                                                   \
     do {                                                                                                                              \
-        static std::atomic<bool> big_lds_set{false}; /* (atomic: distinct model handles may launch from distinct threads) */         \
-        if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {                                                                                        \
+        static BigLdsOnce big_lds_set; /* (atomic: distinct model handles may launch from distinct threads) */         \
+        if (lds > 64 * 1024 && big_lds_set.needed()) {                                                                                        \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>),       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
             if (ea != hipSuccess) return ea;                                                                                          \
-            big_lds_set.store(true, std::memory_order_release);                                                                                                 \
+            big_lds_set.done();                                                                                                 \
         }                                                                                                                             \
         VITS_KLAUNCH((conv_mfma_kernel<KT, DIL, DB, WM, WN, MR, NR, EPI>), grid, dim3(DB ? 320 : 256), lds, s, p);                             \
     } while (0)
@@ -1153,11 +1153,11 @@ hipError_t launch_conv_group(const PackedConv* const* w, const ConvCall* c, int 
     dim3 grid((ncols_max + 127) / 128, w[0]->mtiles_used / 4, z);
 #define VITS_GROUP_LAUNCH(D)                                                                                                              \
     do {                                                                                                                                  \
-        static std::atomic<bool> big_lds_set{false};                                                                                      \
-        if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {                                                            \
+        static BigLdsOnce big_lds_set;                                                                                      \
+        if (lds > 64 * 1024 && big_lds_set.needed()) {                                                            \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_group_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (ea != hipSuccess) return ea;                                                                                              \
-            big_lds_set.store(true, std::memory_order_release);                                                                           \
+            big_lds_set.done();                                                                           \
         }                                                                                                                                 \
         VITS_KLAUNCH((conv_group_kernel<D>), grid, dim3(320), lds, s, g);                                                           \
     } while (0)

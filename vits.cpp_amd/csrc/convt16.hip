@@ -389,16 +389,40 @@ template <int NR, int CSPLIT, int RS, bool BF>
 static hipError_t launch_ct(const ConvT16Params& p, int ncols_max, int batch, hipStream_t s) {
     constexpr int BN = NR * CSPLIT * 32, XW = (BN + 1 + 7) / 8 * 8;
     const size_t lds = (size_t)(p.cin / 8) * XW * 16;
-    static std::atomic<bool> big_lds_set{false};
-    if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+    static BigLdsOnce big_lds_set;
+    if (lds > 64 * 1024 && big_lds_set.needed()) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt16_kernel<NR, CSPLIT, RS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
-        big_lds_set.store(true, std::memory_order_release);
+        big_lds_set.done();
     }
     dim3 grid((ncols_max + BN - 1) / BN, batch);
     VITS_KLAUNCH((convt16_kernel<NR, CSPLIT, RS, BF>), grid, dim3(256), lds, s, p);
     return hipGetLastError();
 }
+
+// which instantiation serves a transposed conv (one place: the launch below and the profiler label of the engine both ask here).
+// convt16_lines_kernel<BN>: four phases per wave, for row counts above 128 with a stride that is a multiple of 4; 128 positions per block,
+// 64 when c_in = 512 (LDS for two blocks per CU). convt16_kernel<NR, CSPLIT, RS>: 128 positions per block; 64 when the input tile of 128
+// would not leave room for two blocks per CU (c_in = 512); 256 positions with two waves per row tile when there are only two row tiles (the
+// last upsampler: 64 rows); sixteen ring slots where the step count allows.
+namespace {
+struct CtChoice {
+    int lines_bn = 0, nr = 0, csplit = 0, rs = 0;
+};
+CtChoice ct_choice(const PackedConv& w) {
+    static const bool all_s = getenv("VITS_CONVT16S_ALL") != nullptr;
+    CtChoice c;
+    if (w.rows > 128 && w.ct_stride % 4 == 0 && !all_s) {
+        c.lines_bn = w.cin > 256 ? 64 : 128;
+        return c;
+    }
+    c.rs = w.cin % 128 == 0 ? 16 : 8;
+    if (w.rows / 32 <= 2) c.nr = 4, c.csplit = 2;
+    else if (w.cin > 256) c.nr = 2, c.csplit = 1;
+    else c.nr = 4, c.csplit = 1;
+    return c;
+}
+}  // namespace
 
 hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
     if (!convt16_stream_supported(w) || !c.yg) return hipErrorInvalidValue;
@@ -426,41 +450,44 @@ hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int a
     p.y16_slope = c.y16_slope;
     const bool bf = arith == VITS_ARITH_BF16;
     const int ncols_max = c.t_in + 1;
-    const int nrt = w.rows / 32;
-    // tile: 128 positions per block; 64 when the input tile of 128 would not leave room for two blocks per CU (c_in = 512); 256 positions
-    // with two waves per row tile when there are only two row tiles (the last upsampler: 64 rows)
-    static const bool all_s = getenv("VITS_CONVT16S_ALL") != nullptr;
-    if (w.rows > 128 && w.ct_stride % 4 == 0 && !all_s) {
+    const CtChoice ch = ct_choice(w);
+    if (ch.lines_bn) {
         // four phases per wave: whole output lines per store burst. 128 positions per block, 64 when c_in = 512 (LDS for two blocks per CU)
         auto go = [&](auto bn_c, auto bf_c) -> hipError_t {
             constexpr int BN = decltype(bn_c)::value;
             constexpr bool BFv = decltype(bf_c)::value;
             constexpr int XW = (BN + 1 + 7) / 8 * 8;
             const size_t lds = (size_t)(p.cin / 8) * XW * 16;
-            static std::atomic<bool> big_lds_set{false};
-            if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+            static BigLdsOnce big_lds_set;
+            if (lds > 64 * 1024 && big_lds_set.needed()) {
                 hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt16_lines_kernel<BN, BFv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (ea != hipSuccess) return ea;
-                big_lds_set.store(true, std::memory_order_release);
+                big_lds_set.done();
             }
             dim3 grid((ncols_max + BN - 1) / BN, c.batch);
             VITS_KLAUNCH((convt16_lines_kernel<BN, BFv>), grid, dim3(256), lds, s, p);
             return hipGetLastError();
         };
-        if (w.cin > 256) return bf ? go(std::integral_constant<int, 64>{}, std::true_type{}) : go(std::integral_constant<int, 64>{}, std::false_type{});
+        if (ch.lines_bn == 64) return bf ? go(std::integral_constant<int, 64>{}, std::true_type{}) : go(std::integral_constant<int, 64>{}, std::false_type{});
         return bf ? go(std::integral_constant<int, 128>{}, std::true_type{}) : go(std::integral_constant<int, 128>{}, std::false_type{});
     }
-    const bool r16 = w.cin % 128 == 0;  // sixteen ring slots where the step count allows
-    if (nrt <= 2) {
-        if (r16) return bf ? launch_ct<4, 2, 16, true>(p, ncols_max, c.batch, s) : launch_ct<4, 2, 16, false>(p, ncols_max, c.batch, s);
-        return bf ? launch_ct<4, 2, 8, true>(p, ncols_max, c.batch, s) : launch_ct<4, 2, 8, false>(p, ncols_max, c.batch, s);
-    }
-    if (w.cin > 256) {
-        if (r16) return bf ? launch_ct<2, 1, 16, true>(p, ncols_max, c.batch, s) : launch_ct<2, 1, 16, false>(p, ncols_max, c.batch, s);
-        return bf ? launch_ct<2, 1, 8, true>(p, ncols_max, c.batch, s) : launch_ct<2, 1, 8, false>(p, ncols_max, c.batch, s);
-    }
-    if (r16) return bf ? launch_ct<4, 1, 16, true>(p, ncols_max, c.batch, s) : launch_ct<4, 1, 16, false>(p, ncols_max, c.batch, s);
-    return bf ? launch_ct<4, 1, 8, true>(p, ncols_max, c.batch, s) : launch_ct<4, 1, 8, false>(p, ncols_max, c.batch, s);
+#define VITS_CT(NR, CS, RS)                                                                                            \
+    if (ch.nr == NR && ch.csplit == CS && ch.rs == RS)                                                                 \
+        return bf ? launch_ct<NR, CS, RS, true>(p, ncols_max, c.batch, s) : launch_ct<NR, CS, RS, false>(p, ncols_max, c.batch, s)
+    VITS_CT(4, 2, 16);
+    VITS_CT(4, 2, 8);
+    VITS_CT(2, 1, 16);
+    VITS_CT(2, 1, 8);
+    VITS_CT(4, 1, 16);
+    VITS_CT(4, 1, 8);
+#undef VITS_CT
+    return hipErrorInvalidValue;
+}
+
+void convt16_stream_tag(const PackedConv& w, char* buf, size_t cap) {
+    const CtChoice ch = ct_choice(w);
+    if (ch.lines_bn) std::snprintf(buf, cap, "SL%d", ch.lines_bn);
+    else std::snprintf(buf, cap, "S%d.%d.%d", ch.nr, ch.csplit, ch.rs);
 }
 
 }  // namespace vits

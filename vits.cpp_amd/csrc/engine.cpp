@@ -94,12 +94,98 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
 }
 
 int Engine::sync(std::string& err) {
+    if (front_) HIP_OK(hipStreamSynchronize(front_));
     HIP_OK(hipStreamSynchronize(stream));
     return 0;
 }
 
 int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int id_stride, const vits_process_opts& o, vits_batch_result* out,
                           std::string& err) {
+    if (pending()) {
+        err = "batches in flight: call vits_model_wait for every submitted batch first";
+        return -1;
+    }
+    a1_slot_ = 0;
+    return process_impl(ids, id_lens, B, id_stride, o, out, err, nullptr);
+}
+
+// ---- pipelined batches (vits.h: vits_model_submit_batch / vits_model_wait) --------------------------------------------------
+// submit(n): stage one of batch n on the front-end stream into stage-one arena n & 1 — beside the flow / vocoder of batch n - 1,
+// which is running on the main stream —, the frame counts through pinned memory behind an event (the host waits for THAT event,
+// not for the device), stage two behind batch n - 1 on the main stream. Batch n - 2, the previous user of the arena, was waited
+// for before this submit was accepted, so nothing on the device still reads it.
+int Engine::submit_batch(const int32_t* ids, const int32_t* id_lens, int B, int id_stride, const vits_process_opts& o, std::string& err) {
+    if (pending() >= 2) {
+        err = "two batches in flight already: call vits_model_wait first";
+        return -1;
+    }
+    if (o.noise_kind != VITS_NOISE_COUNTER || o.collect_taps || o.on_chunk || o.frames_only || o.async) {
+        err = "vits_model_submit_batch: VITS_NOISE_COUNTER only, and no collect_taps / on_chunk / frames_only / async";
+        return -1;
+    }
+    Pending& p = pend_[submit_seq_ & 1];
+    if (!p.done) {
+        HIP_OK(hipEventCreateWithFlags(&p.s1_done, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    }
+    if (!front_ && !knobs.no_pipeline) {
+        int least = 0, greatest = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        // high priority: the small stage-one launches take the next free wave slots ahead of the vocoder's queued blocks
+        HIP_OK(hipStreamCreateWithPriority(&front_, hipStreamNonBlocking, knobs.front_prio ? greatest : least));
+    }
+    a1_slot_ = (int)(submit_seq_ & 1);
+    const int rc = process_impl(ids, id_lens, B, id_stride, o, nullptr, err, &p);
+    a1_slot_ = 0;
+    if (rc) {
+        // (whatever was queued is harmless: it only touches this slot's arenas; leave the device idle before the slot is reused)
+        if (front_) hipStreamSynchronize(front_);
+        hipStreamSynchronize(stream);
+        return rc;
+    }
+    p.active = true;
+    ++submit_seq_;
+    return 0;
+}
+
+int Engine::wait_batch(vits_batch_result* out, std::string& err) {
+    if (!pending()) {
+        err = "vits_model_wait: nothing was submitted";
+        return -1;
+    }
+    Pending& p = pend_[wait_seq_ & 1];
+    HIP_OK(hipEventSynchronize(p.done));
+    p.active = false;
+    ++wait_seq_;
+    if (out) {
+        out->batch = (size_t)p.B;
+        out->stride = p.stride;
+        out->lengths = new int64_t[p.B];
+        out->frames = new int64_t[p.B];
+        std::copy(p.lengths.begin(), p.lengths.end(), out->lengths);
+        std::copy(p.frames.begin(), p.frames.end(), out->frames);
+        out->data = nullptr;
+        if (p.host_copy) {
+            out->data = new float[(size_t)p.B * p.stride];
+            std::memcpy(out->data, p.host, sizeof(float) * (size_t)p.B * p.stride);
+        }
+    }
+    return 0;
+}
+
+namespace {
+// the stream member of the engine is "the stream being queued on": stage one of a pipelined batch swaps the front-end stream in
+struct StreamSwap {
+    hipStream_t& slot;
+    hipStream_t saved;
+    StreamSwap(hipStream_t& s, hipStream_t to) : slot(s), saved(s) { slot = to; }
+    void restore() { slot = saved; }
+    ~StreamSwap() { slot = saved; }
+};
+}  // namespace
+
+int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int id_stride, const vits_process_opts& o, vits_batch_result* out,
+                         std::string& err, Pending* pend) {
     if (B <= 0 || id_stride <= 0) {
         err = "empty batch";
         return -1;
@@ -142,6 +228,11 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     // Under VITS_ARITH_SCOPE_FLOW_VOCODER (default) stage one is exact fp32 in every arithmetic mode: the durations — the path's
     // only integer output, ceil() of a float (vits.cpp:996-1001) — are then bit-identical to the fp32 path's.
     arith_now_ = arith_scope == VITS_ARITH_SCOPE_ALL_CONVS ? arith : VITS_ARITH_F32;
+    // pipelined batch: stage one goes to the front-end stream (the per-kernel profiler needs kernels that do not overlap: then,
+    // and under VITS_NO_PIPELINE, everything stays on the main stream and a pipelined batch is merely a deferred result)
+    const bool overlap = pend && front_ && !prof.on;
+    StreamSwap s1_stream(stream, overlap ? front_ : stream);
+    hipStream_t const main_stream = s1_stream.saved;
     if (layout_stage_one(c)) return -1;
     if (run_text_encoder(c)) return -1;
     if (run_duration_predictor(c)) return -1;
@@ -153,12 +244,33 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
     frames.resize(B);
     if (o.fixed_duration > 0) {
         for (int b = 0; b < B; ++b) frames[b] = std::max(1, o.fixed_duration * c.tlen[b]);
+    } else if (pend) {
+        // through pinned memory behind an event on the stage-one stream: the host waits for this batch's stage one only, while the
+        // previous batch's vocoder keeps the device busy
+        if (pend->frames_cap < (size_t)B) {
+            if (pend->frames_pinned) hipHostFree(pend->frames_pinned);
+            pend->frames_pinned = nullptr;
+            pend->frames_cap = 0;
+            HIP_OK(hipHostMalloc((void**)&pend->frames_pinned, sizeof(int) * (size_t)(B + 64), hipHostMallocDefault));
+            pend->frames_cap = (size_t)B + 64;
+        }
+        HIP_OK(hipMemcpyAsync(pend->frames_pinned, c.s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipEventRecord(pend->s1_done, stream));
+        prof.fence();
+        HIP_OK(hipEventSynchronize(pend->s1_done));
+        std::copy(pend->frames_pinned, pend->frames_pinned + B, frames.begin());
     } else {
         HIP_OK(hipMemcpyAsync(frames.data(), c.s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
         prof.fence();
         HIP_OK(hipStreamSynchronize(stream));
         prof.fence();
     }
+    if (overlap) {
+        // stage two runs on the main stream, behind this batch's stage one (pinned durations: no host read ordered them yet)
+        if (o.fixed_duration > 0) HIP_OK(hipEventRecord(pend->s1_done, stream));
+        HIP_OK(hipStreamWaitEvent(main_stream, pend->s1_done, 0));
+    }
+    s1_stream.restore();
     for (int b = 0; b < B; ++b) {
         c.Lmax = std::max(c.Lmax, frames[b]);
         c.sum_frames += frames[b];
@@ -349,6 +461,33 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
 
     // ---- results ------------------------------------------------------------------------------------------------
     c.rx.phase("vits.results");
+    if (pend) {
+        // a pipelined batch: everything the host will hand out is known now; the PCM (if a host copy was asked for) goes to the
+        // slot's pinned staging behind the kernels, and `done` marks the end of the batch on the device
+        pend->B = B;
+        pend->stride = (size_t)smax[n_up];
+        pend->lengths.resize(B);
+        pend->frames.resize(B);
+        for (int b = 0; b < B; ++b) {
+            pend->lengths[b] = c.slen[n_up][b];
+            pend->frames[b] = frames[b];
+        }
+        pend->host_copy = !o.skip_host_copy;
+        if (pend->host_copy) {
+            const size_t need = sizeof(float) * (size_t)B * pend->stride;
+            if (need > pend->host_cap) {
+                if (pend->host) hipHostFree(pend->host);
+                pend->host = nullptr;
+                pend->host_cap = 0;
+                HIP_OK(hipHostMalloc((void**)&pend->host, need + need / 8, hipHostMallocDefault));
+                pend->host_cap = need + need / 8;
+            }
+            HIP_OK(hipMemcpy2DAsync(pend->host, pend->stride * 4, wave_dst, (size_t)wave_stride * 4, pend->stride * 4, (size_t)B, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_OK(hipEventRecord(pend->done, stream));
+        prof.fence();
+        return 0;
+    }
     if (out) {
         out->batch = (size_t)B;
         out->stride = (size_t)smax[n_up];

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -123,6 +124,8 @@ struct Knobs {
     bool rb_group_always = false;  // VITS_RB_GROUP=1: grouped launches also when the three streams are available
     bool no_flow_fuse = false;   // VITS_NO_FLOW_FUSE: 16-bit modes: a coupling layer of the flow as nine launches instead of one kernel
     bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
+    int front_prio = 1;          // VITS_FRONT_PRIO=0: the front-end stream of pipelined batches at normal instead of high priority
+    bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
     void read();
 };
 
@@ -137,7 +140,14 @@ class Engine {
     bool validate(const uint8_t* bytes, size_t size, std::string& err);
     int process_batch(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out,
                       std::string& err);
+    // pipelined batches (include/vits.h vits_model_submit_batch / vits_model_wait): up to two in flight
+    int submit_batch(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, std::string& err);
+    int wait_batch(vits_batch_result* out, std::string& err);
+    int pending() const { return (int)(submit_seq_ - wait_seq_); }
     int sync(std::string& err);
+    // One call at a time per handle (the reference's contract too: process writes member tensors, src/include/vits.h:22-30). The ABI
+    // takes this flag around every entry point that touches the engine; a second thread gets "model busy" instead of a race.
+    std::atomic<bool> busy{false};
     int set_arith(int arith, std::string& err);  // VITS_ARITH_*: packs the 16-bit weight fragments on first use
     int arith = VITS_ARITH_F32;
     // which convolutions a 16-bit arithmetic mode applies to (include/vits.h VITS_ARITH_SCOPE_*)
@@ -190,7 +200,28 @@ class Engine {
     std::vector<void*> owned_;  // every device allocation made at load
     bool dry_run_ = false;
 
-    Arena a1_, a2_;
+    // stage-one arenas: one per pipeline slot (a batch's stage two reads its stage-one results while the next batch's stage one runs)
+    Arena a1_[2], a2_;
+    int a1_slot_ = 0;
+    Arena& a1() { return a1_[a1_slot_]; }
+    // A batch submitted with submit_batch and not yet waited for. Its results are known on the host when submit returns (the frame
+    // counts were read there); `done` marks the end of its device work, `host` is pinned staging for the PCM when a host copy was asked for.
+    struct Pending {
+        bool active = false;
+        int B = 0;
+        size_t stride = 0;
+        std::vector<int64_t> lengths, frames;
+        bool host_copy = false;
+        float* host = nullptr;
+        size_t host_cap = 0;  // bytes
+        int* frames_pinned = nullptr;
+        size_t frames_cap = 0;  // ints
+        hipEvent_t s1_done = nullptr, done = nullptr;
+    } pend_[2];
+    uint64_t submit_seq_ = 0, wait_seq_ = 0;  // batch n lives in pend_[n & 1]
+    hipStream_t front_ = nullptr;             // stage one of pipelined batches (created on first use)
+    int process_impl(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out, std::string& err,
+                     Pending* pend);
     // The three resblocks of a vocoder stage (kernel sizes 3/7/11) are independent chains of six convolutions; they run on
     // three streams so that the tail of one kernel's grid overlaps the head of another's. side_[j-1] carries resblock j.
     hipStream_t side_[2] = {nullptr, nullptr};

@@ -6,9 +6,17 @@ namespace vits {
 // ---- load -------------------------------------------------------------------------------------------------
 Engine::~Engine() {
     if (stream) hipStreamSynchronize(stream);
+    if (front_) hipStreamSynchronize(front_);
     for (hipStream_t s : side_)
         if (s) hipStreamSynchronize(s);
     clear_taps();
+    for (Pending& p : pend_) {
+        if (p.host) hipHostFree(p.host);
+        if (p.frames_pinned) hipHostFree(p.frames_pinned);
+        if (p.s1_done) hipEventDestroy(p.s1_done);
+        if (p.done) hipEventDestroy(p.done);
+    }
+    if (front_) hipStreamDestroy(front_);
     if (!dry_run_) {
         for (void* p : owned_) hipFree(p);
         for (PackSrc& ps : packs_)

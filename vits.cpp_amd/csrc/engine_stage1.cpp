@@ -87,9 +87,9 @@ int Engine::layout_stage_one(Call& c) {
         layout1(measure);
         const size_t need = measure.off + 4096;
         measure.cap = 0;
-        if (need > a1_.cap) HIP_OK(hipStreamSynchronize(stream));
-        HIP_OK(a1_.reserve(need));
-        layout1(a1_);
+        if (need > a1().cap) HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(a1().reserve(need));
+        layout1(a1());
         for (int i = 0; i < 3; ++i) {
             x16_[i] = Ref16();
             x16_cap_[i] = 0;

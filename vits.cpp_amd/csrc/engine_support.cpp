@@ -37,6 +37,8 @@ void Knobs::read() {
     rb_group_always = flag("VITS_RB_GROUP");
     no_flow_fuse = flag("VITS_NO_FLOW_FUSE");
     if (const char* e = std::getenv("VITS_PROF_ATTACH")) prof_attach = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VITS_FRONT_PRIO")) front_prio = std::atoi(e);
+    no_pipeline = flag("VITS_NO_PIPELINE");
 }
 
 // ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----

@@ -95,8 +95,9 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
             if (convt16_stream_supported(U.up)) {
                 // the upsampler as a streaming kernel (convt16.hip: every phase of a tile of input positions in one block; bit-identical)
                 if (prof.on) {
-                    char full[160];
-                    std::snprintf(full, sizeof(full), "hifigan_upsample_convT|k2|d-1|S%d|e2g|c%dx%d", U.stride, U.up.cin, U.up.cout);
+                    char full[160], tag[24];
+                    convt16_stream_tag(U.up, tag, sizeof(tag));
+                    std::snprintf(full, sizeof(full), "hifigan_upsample_convT|k2|d-1|%s|e2g|c%dx%d", tag, U.up.cin, U.up.cout);
                     prof.begin(full, 2.0 * (double)U.up.rows * (double)U.up.cin * 2.0 * (double)ssum[st_in], ct_bytes, stream, true);
                 }
                 HIP_OK(launch_convt16_stream(U.up, c, arith_now_, stream));
@@ -331,11 +332,14 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
         const bool lcopy = C >= knobs.lrelu_copy_minc;
         TensorRef bul = TR(s2.bul, C, sts[st_out]);
         auto al16 = [](const TensorRef& t) { return (reinterpret_cast<uintptr_t>(t.p) & 15) == 0 && (t.cs & 3) == 0 && (t.bs & 3) == 0; };
-        // which resblocks run as fused pairs (narrow stages; all pairs of a resblock or none)
+        // which resblocks run as fused pairs (narrow stages; all pairs of a resblock or none). rbpair32 and the grouped launch are fp32
+        // kernels that do not go through conv(): in a 16-bit arithmetic mode on this (converter) path they would silently compute the
+        // wide-stage resblocks in fp32 — not the arithmetic that was asked for, and other bits with the profiler on than off.
+        const bool exact32 = arith_now_ == VITS_ARITH_F32;
         bool fusedrb[3] = {false, false, false};
         for (size_t j = 0; j < nk && j < 3; ++j) {
             const ResBlockW& R = U.rbs[j];
-            bool f = !knobs.no_fuse32 && al16(bu) && (reinterpret_cast<uintptr_t>(s2.by[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(s2.bt[0]) & 15) == 0 && (sts[st_out] & 3) == 0;
+            bool f = exact32 && !knobs.no_fuse32 && al16(bu) && (reinterpret_cast<uintptr_t>(s2.by[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(s2.bt[0]) & 15) == 0 && (sts[st_out] & 3) == 0;
             for (size_t d = 0; d < R.dil.size() && f; ++d) f = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
             fusedrb[j] = f;
         }
@@ -343,7 +347,7 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
         // (measured, batch 64 x 128 ids: serialised launches 79.7 ms per step, grouped 79.1, three streams 76.8 — kernels of DIFFERENT
         // launches share a CU, which blocks of one launch do not, so the streams win where they can be used: the
         // grouped schedule is for the single-stream case, i.e. under the per-kernel profiler; VITS_RB_GROUP=1 forces it)
-        bool grouped = !knobs.no_rb_group && nk >= 2 && nk <= 3 && knobs.rb_streams > 1 && (prof.on || knobs.rb_group_always);
+        bool grouped = exact32 && !knobs.no_rb_group && nk >= 2 && nk <= 3 && knobs.rb_streams > 1 && (prof.on || knobs.rb_group_always);
         {
             int members = 0, seen = 0;
             for (size_t j = 0; j < nk && grouped; ++j) {

@@ -9,10 +9,25 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
 namespace vits {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a function ON A DEVICE. A kernel instantiation that needs more than
+// 64 KB of LDS raises its limit once per device: the once-flag is one bit per device, so a process that loads models on several
+// devices (vits_set_device) raises it on each of them (a process-wide flag left the second device at 64 KB: launch failures there).
+struct BigLdsOnce {
+    std::atomic<uint64_t> mask{0};
+    static uint64_t bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool needed() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 // Per-launch timing without extra queue packets. The engine's per-kernel profiler (bench.py's instrumented region) used to bracket
 // every launch with hipEventRecord: a barrier packet each, ~300 of them per step, and durations that include the gap to the next packet.
@@ -214,6 +229,9 @@ hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hi
 // positions per block; bit-identical to launch_conv16 on the same call
 bool convt16_stream_supported(const PackedConv& w);
 hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
+// tile tag of the instantiation launch_convt16_stream picks for `w` ("SL128" = convt16_lines_kernel<128>, "S4.1.16" = convt16_kernel<4, 1, 16>):
+// the profiler label carries it, so that a profiler entry lines up with exactly one rocprofv3 kernel name (tools/pmc_common.py)
+void convt16_stream_tag(const PackedConv& w, char* buf, size_t cap);
 hipError_t launch_to_group16(TensorRef x, const int* lens, int batch, int channels, int tmax, float slope, Ref16 y, int arith, hipStream_t s);
 hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef pre, TensorRef wave, const int* lens, int batch, int tmax, int arith, hipStream_t s,
                               int emit_lo = 0, const int* emit_hi = nullptr);

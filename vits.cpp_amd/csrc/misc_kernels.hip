@@ -1149,11 +1149,11 @@ hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const f
     dim3 grid((tmax + 31) / 32, batch);
 #define VITS_DDS_LAUNCH1(A, M)                                                                                                         \
     do {                                                                                                                               \
-        static std::atomic<bool> big{false};                                                                                          \
-        if (lds > 64 * 1024 && !big.load(std::memory_order_acquire)) {                                                                 \
+        static BigLdsOnce big;                                                                                          \
+        if (lds > 64 * 1024 && big.needed()) {                                                                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dds_layer_kernel<A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return e;                                                                                             \
-            big.store(true, std::memory_order_release);                                                                                \
+            big.done();                                                                                \
         }                                                                                                                              \
         VITS_KLAUNCH((dds_layer_kernel<A, M>), grid, dim3(32 * LN_GROUPS), lds, s, p);                                           \
     } while (0)

@@ -345,11 +345,11 @@ static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
     constexpr int D0 = 1, D1 = 3, D2 = 5;
     constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
     const size_t lds = (size_t)(C / 8) * PITCH * 16 + (size_t)6 * C * sizeof(float);
-    static std::atomic<bool> big_lds_set{false};
-    if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+    static BigLdsOnce big_lds_set;
+    if (lds > 64 * 1024 && big_lds_set.needed()) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
-        big_lds_set.store(true, std::memory_order_release);
+        big_lds_set.done();
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
     VITS_KLAUNCH((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);

@@ -388,11 +388,11 @@ static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
     constexpr int BO = BM - (KT - 1);
     constexpr int XWP = (BM + (KT - 1) * DIL + 7) / 8 * 8, TW = (BM + KT - 1 + 7) / 8 * 8;
     const size_t lds = C >= 64 ? (size_t)(C / 8) * (XWP > TW ? XWP : TW) * 16 : (size_t)(C / 8) * (XWP + TW) * 16;
-    static std::atomic<bool> big_lds_set{false};
-    if (lds > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+    static BigLdsOnce big_lds_set;
+    if (lds > 64 * 1024 && big_lds_set.needed()) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
-        big_lds_set.store(true, std::memory_order_release);
+        big_lds_set.done();
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
     VITS_KLAUNCH((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(ROWS ? 2 * C : 256), lds, s, p);

@@ -229,11 +229,11 @@ static hipError_t launch_rb32(const RbPair32Params& p, int batch, hipStream_t s)
     constexpr int WN = 4 / (C / 32), BM = WN * (C >= 128 ? 4 : 2) * 32, BO = BM - (KT - 1);
     constexpr int XWP = (BM + (KT - 1) * DIL + 3 + 3) / 4 * 4;
     const size_t ldsz = ((size_t)C * XWP * sizeof(float) + 1023) / 1024 * 1024;  // (the last 1 KB DMA instruction may overhang the tile)
-    static std::atomic<bool> big_lds_set{false};
-    if (ldsz > 64 * 1024 && !big_lds_set.load(std::memory_order_acquire)) {
+    static BigLdsOnce big_lds_set;
+    if (ldsz > 64 * 1024 && big_lds_set.needed()) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpair32_kernel<KT, DIL, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
-        big_lds_set.store(true, std::memory_order_release);
+        big_lds_set.done();
     }
     dim3 grid((p.tmax + BO - 1) / BO, batch);
     VITS_KLAUNCH((rbpair32_kernel<KT, DIL, C>), grid, dim3(256), ldsz, s, p);

@@ -148,12 +148,15 @@ class PcmExchange:
       flush()                    drains the pipeline (end of a run, or when the caller needs the last block).
 
     The PCM of step i is therefore read by the collective while step i + 1 runs: the caller must not overwrite it before step
-    i + 2 begins (rotate THREE output buffers: `slot(i) = i % 3`; submit(i + 2) first waits for gather i-... see `submit`).
+    i + 2 begins (rotate THREE output buffers: `slot(i) = i % 3`; submit(i + 2) returns only after the copy of PCM i out of its buffer
+    has completed, so the rotation is safe however far the exchange stream lags). All device work of the exchange — the copies into the
+    send buffer, the collectives, the removal of padding rows — runs on the exchange stream, ordered behind the caller's stream at every
+    submit.
     Results arrive through `on_block(step, gathered [rows, smax], lengths [rows])` (views into the exchange's own buffers, valid
     until the next block is produced) or `last`. Works on CPU tensors with gloo (synchronous there) and on the GPU with
     nccl == RCCL; int16 PCM travels as bytes."""
 
-    def __init__(self, rows, cap, dtype=torch.float32, device="cpu", on_block=None):
+    def __init__(self, rows, cap, dtype=torch.float32, device="cpu", on_block=None, row_capacity=0):
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.dist_on else 1
         self.rank = dist.get_rank() if self.dist_on else 0
@@ -169,11 +172,14 @@ class PcmExchange:
         else:
             self.counts = [int(rows)]
         self.rows = int(rows)
-        self.bmax = max(max(self.counts), 1)
+        # every rank's block is padded to bmax rows (row_capacity: a caller whose shard sizes change from run to run fixes it up front)
+        self.bmax = max(max(self.counts), 1, int(row_capacity))
         n = self.world * self.bmax
-        self.keep = None
+        self.keep = self.keep_cpu = self.kept = None
         if any(c != self.bmax for c in self.counts):
-            self.keep = torch.cat([torch.arange(r * self.bmax, r * self.bmax + self.counts[r], device=self.device) for r in range(self.world)])
+            self.keep_cpu = torch.cat([torch.arange(r * self.bmax, r * self.bmax + self.counts[r]) for r in range(self.world)])
+            self.keep = self.keep_cpu.to(self.device)
+            self.kept = torch.zeros(int(self.keep_cpu.numel()) * self.cap, dtype=dtype, device=self.device)  # the gathered block without the padding rows
         pin = dict(pin_memory=True) if self.cuda else {}
         self.len_send = [torch.zeros(self.bmax, dtype=torch.int64, device=self.device) for _ in range(2)]
         self.len_all = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(2)]
@@ -183,6 +189,8 @@ class PcmExchange:
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.len_ev = [torch.cuda.Event() if self.cuda else None for _ in range(2)]
         self.out_ev = torch.cuda.Event() if self.cuda else None
+        self.copy_ev = torch.cuda.Event() if self.cuda else None  # behind the copy of a step's PCM into `send`: the caller's buffer is free again
+        self.copy_pending = False
         self.pending = None  # (step, pcm, slot): lengths queued, PCM not yet
         self.step = 0
         self.last = None
@@ -193,13 +201,20 @@ class PcmExchange:
 
     def submit(self, pcm, lengths):
         """pcm [rows, >= cap used] on self.device (fp32 or int16), rows valid up to lengths[b]; lengths int64 [rows] on the same
-        device. The data must be complete (the producing stream synchronised, which vits_model_process_batch does before it
-        returns). Returns immediately; pcm must stay untouched until the SECOND next submit / the next flush."""
+        device, both produced on (or synchronised with) the CALLER's current stream: the exchange stream is ordered behind it here.
+        Returns without waiting for any collective; pcm must stay untouched until the SECOND next submit has returned / the next flush
+        (rotate three buffers): submit(i) returns only when the copy of PCM i - 2 out of its buffer has completed."""
         assert pcm.shape[0] == self.rows and pcm.dtype == self.dtype and pcm.shape[1] <= self.cap
         slot = self.step & 1
+        # (the caller's stream must be looked up OUTSIDE the side-stream context: inside it, the current stream IS the side stream)
+        producer = torch.cuda.current_stream(self.device) if self.cuda else None
+        if self.cuda and self.copy_pending:
+            # the previous submit queued the copy of PCM step-2 into `send`; the caller is about to reuse that buffer for step + 1
+            self.copy_ev.synchronize()
+            self.copy_pending = False
         with self._on_side():
             if self.cuda:
-                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                self.side.wait_stream(producer)
             self.len_send[slot][: self.rows].copy_(lengths)
             if self.dist_on:
                 dist.all_gather_into_tensor(self.len_all[slot], self.len_send[slot])
@@ -211,9 +226,9 @@ class PcmExchange:
         prev, self.pending = self.pending, (self.step, pcm, slot)
         self.step += 1
         if prev is not None:
-            self._gather(*prev)
+            self._gather(*prev, producer=producer)
 
-    def _gather(self, step, pcm, slot):
+    def _gather(self, step, pcm, slot, producer=None):
         if self.cuda:
             self.len_ev[slot].synchronize()  # (recorded a whole step ago: no wait in the steady state)
         lens_host = self.len_host[slot]
@@ -221,9 +236,16 @@ class PcmExchange:
         if smax > pcm.shape[1]:
             raise ValueError("PCM buffer narrower than the longest utterance of another rank: all ranks must use the same capacity")
         n = self.world * self.bmax
+        if self.cuda and producer is None:
+            producer = torch.cuda.current_stream(self.device)
         with self._on_side():
+            if self.cuda:
+                self.side.wait_stream(producer)  # pcm was written on the caller's stream (e.g. the int16 conversion bench.py launches there)
             send = self.send[: self.bmax * smax].view(self.bmax, smax)
             send[: self.rows].copy_(pcm[:, :smax])
+            if self.cuda:
+                self.copy_ev.record(self.side)
+                self.copy_pending = True
             out = self.out[: n * smax].view(n, smax)
             if self.dist_on:
                 if self.dtype == torch.float32:
@@ -232,12 +254,18 @@ class PcmExchange:
                     dist.all_gather_into_tensor(out.view(torch.uint8), send.view(torch.uint8))
             else:
                 out.copy_(send)
+            if self.keep is not None:
+                # drop the padding rows ON THE EXCHANGE STREAM, behind the all-gather that fills `out`, into a buffer of the exchange
+                # (no allocation, and nothing on another stream reads `out` before it is complete)
+                kept = self.kept[: self.keep_cpu.numel() * smax].view(-1, smax)
+                torch.index_select(out, 0, self.keep, out=kept)
+                out = kept
             if self.cuda:
                 self.out_ev.record(self.side)
         self.bytes_moved += n * smax * out.element_size()
         lens = lens_host.clone()
         if self.keep is not None:
-            out, lens = out.index_select(0, self.keep), lens.index_select(0, self.keep.cpu())
+            lens = lens.index_select(0, self.keep_cpu)
         self.last = (step, out, lens)
         if self.on_block is not None:
             if self.cuda:
@@ -251,6 +279,7 @@ class PcmExchange:
             self._gather(*prev)
         if self.cuda:
             self.side.synchronize()
+            self.copy_pending = False
         return self.last
 
 
