@@ -559,6 +559,16 @@ def main():
         ts = torch.tensor([total_samples], dtype=torch.int64, device="cuda")
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         total_samples = int(ts.item())
+    # self-check of an N-GPU run: the number of ranks that actually took part, counted THROUGH the communicator (a sum of ones over
+    # RCCL), and the devices they ran on — so that a line that claims n_gpus = 8 cannot come from fewer processes
+    ranks_seen, devices_seen = 1, [torch.cuda.current_device()]
+    if dist_on:
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
+        dv = torch.full((dist.get_world_size(),), -1, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(dv, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cuda"))
+        devices_seen = [int(x) for x in dv.tolist()]
 
     res = None
     if rank == 0:
@@ -577,7 +587,8 @@ def main():
                       "audio samples/sec end-to-end (ids -> fp32 PCM in HBM), two resident bf16-stored models, 1024-id utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.arith, "data": "synthetic",
+            "dtype": args.arith, "data": "synthetic", "ranks_seen": ranks_seen, "rccl_world_size": dist.get_world_size() if dist_on else 1,
+            "devices_seen": devices_seen,
             "config": {"workload": workload, "batch_per_gpu": B * len(jobs), "ids_per_utterance": T, "frames_per_utterance_mean": float(np.mean(frames)),
                        "samples_per_step": total_samples // args.steps, "sampling_rate": sr, "parallelism": f"utterance-sharded x{world}",
                        "shard_balance": args.balance, "pcm_destination": "device (HBM)", "vocoder_chunk_frames": args.chunk_frames,

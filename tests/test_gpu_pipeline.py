@@ -58,29 +58,14 @@ def test_pipelined_batches_are_bit_identical_to_process_batch(pkg, full_model, a
         m.set_arith(pkg.ARITH_F32)
 
 
-def test_pipelined_device_output_pinned_durations_and_windows(pkg, full_model):
+def test_pipelined_device_output_pinned_durations_and_windows():
     """out_device buffers (the bench's configuration), pinned durations (no host read orders the two streams: an event does),
-    and the windowed vocoder inside a pipelined batch."""
-    import torch
-    m = full_model
-    ids = pkg.synth_ids(4, 48)
-    cap = 256 * 8 * 48 + 294
-    for kw in (dict(), dict(fixed_duration=2), dict(vocoder_chunk_frames=37)):
-        want = [m.process_batch(ids, noise_seed=70 + s, **kw) for s in range(3)]
-        bufs = [torch.zeros((4, cap), dtype=torch.float32, device="cuda") for _ in range(3)]
-        m.submit_batch(ids, noise_seed=70, out_device=bufs[0].data_ptr(), out_device_stride=cap, skip_host_copy=True, **kw)
-        res = []
-        for s in (1, 2):
-            m.submit_batch(ids, noise_seed=70 + s, out_device=bufs[s].data_ptr(), out_device_stride=cap, skip_host_copy=True, **kw)
-            res.append(m.wait())
-        res.append(m.wait())
-        for s in range(3):
-            pw, lw, fw = want[s]
-            pg, lg, fg = res[s]
-            assert pg is None and np.array_equal(lw, lg) and np.array_equal(fw, fg)
-            host = bufs[s].cpu().numpy()
-            for b in range(4):
-                assert np.array_equal(host[b, : lw[b]], pw[b])
+    and the windowed vocoder inside a pipelined batch — tools/pipe_check.py in its own process (it needs torch for the device
+    buffers, and torch's HIP runtime has to come up before the library's)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pipe_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pipe_check ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
 def test_pipeline_with_the_profiler_on_runs_serialised_and_equal(pkg, full_model):

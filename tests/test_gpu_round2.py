@@ -64,6 +64,7 @@ def test_bench_forced_dist_line(tmp_path):
     assert r.stdout.count("\n") == 1, r.stdout[:400]  # ONE line, nothing else on stdout
     line = json.loads(r.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
+    assert line["ranks_seen"] == 1 and line["rccl_world_size"] == 1 and line["devices_seen"] == [0]  # counted through the communicator
 
 
 # ---- dispatcher options ----------------------------------------------------------------------------------------------------
