@@ -715,22 +715,16 @@ Act dds(const Ctx& c, const std::string& base, Act x, const Act* g) {
 }
 
 /*
- * Inverse rational-quadratic spline for one token, ref: vits.cpp:695-802 (+ tails :804-852); HF:139-163,211-302.
- * uw,uh: 10 unnormalised widths/heights (already / sqrt(filter_channels)), ud: 9 unnormalised derivatives.
- * `last_token` selects the reference's index -1 wrap (Q4, ggml-util.h:235-236,252-253): in reference mode the
- * writes "[..., -1] = upper_bound", "[..., -1] += 1e-6" and the right tail-derivative constant never land on
- * the LAST token's row (they land on the previous row's last element, which is where the next row's write
- * would have gone, so every other row is correct).
+ * Inverse rational-quadratic spline of one token's row, ref: vits.cpp:695-802 (rational_quadratic_spline); HF:211-302.
+ * uw,uh: 10 unnormalised widths/heights (already / sqrt(filter_channels)); udp: the nb + 1 PADDED unnormalised derivatives as they
+ * arrive at :704 (after the pad / index_put of :828-830 and, in reference mode, the masking of :837-840).
+ * `q4` (reference mode, LAST token's row) selects the index -1 wrap (Q4, ggml-util.h:235-236,252-253): the writes
+ * "[..., -1] = upper_bound" (:726,742) and "[..., -1] += 1e-6" (:750) never land on the last row (they land on the previous row's
+ * last element, which is where the next row's write would have gone, so every other row is correct).
  */
-float spline_inverse(float x, const float* uw, const float* uh, const float* ud, int nb, float B, int mode, bool last_token) {
+static float spline_row(float x, const float* uw, const float* uh, const float* udp, int nb, float B, int mode, bool q4) {
     const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
-    if (!(x >= -B && x <= B)) return x;  // ref :819-832 (identity outside the interval); HF:143-151
-    const bool q4 = (mode == VO_MODE_REFERENCE) && last_token;
-    std::vector<float> udp(nb + 1), W(nb), Hh(nb), cw(nb + 1), chh(nb + 1), D(nb + 1);
-    const float constant = (float)std::log(std::exp(1.0 - (double)min_d) - 1.0);  // ref :826
-    udp[0] = constant;
-    for (int i = 0; i < nb - 1; ++i) udp[i + 1] = ud[i];
-    udp[nb] = q4 ? 0.f : constant;  // ref :828-830 (pad value 0 stays when the -1 write misses)
+    std::vector<float> W(nb), Hh(nb), cw(nb + 1), chh(nb + 1), D(nb + 1);
     // widths
     {
         float mx = -INFINITY;
@@ -802,6 +796,75 @@ float spline_inverse(float x, const float* uw, const float* uh, const float* ud,
     return root * in_w + in_cw;                 // ref :797
 }
 
+/* the padded derivative row of one token, ref :826-830: pad (1, 1), [..., 0] = constant, [..., -1] = constant — which misses the LAST
+ * token's row in reference mode (Q4: the pad value 0 stays) */
+static void padded_derivatives(const float* ud, int nb, int mode, bool last_token, float* udp) {
+    const float min_d = 1e-3f;
+    const float constant = (float)std::log(std::exp(1.0 - (double)min_d) - 1.0);  // ref :826
+    udp[0] = constant;
+    for (int i = 0; i < nb - 1; ++i) udp[i + 1] = ud[i];
+    udp[nb] = (mode == VO_MODE_REFERENCE && last_token) ? 0.f : constant;
+}
+
+/*
+ * HF semantics of the unconstrained spline for one token (HF:139-163): identity outside [-B, B], the spline inside. This is what the
+ * reference's :804-852 computes too AS LONG AS every latent of the utterance lies inside the interval; when one does not, the
+ * reference's masked get / set pair misaligns (Q6) — see unconstrained_spline_reference() below, which is what VO_MODE_REFERENCE runs.
+ */
+float spline_inverse(float x, const float* uw, const float* uh, const float* ud, int nb, float B, int mode, bool last_token) {
+    if (!(x >= -B && x <= B)) return x;  // HF:143-151
+    std::vector<float> udp(nb + 1);
+    padded_derivatives(ud, nb, mode, last_token, udp.data());
+    return spline_row(x, uw, uh, udp.data(), nb, B, mode, mode == VO_MODE_REFERENCE && last_token);
+}
+
+thread_local int64_t g_outside_latents = 0;  // latents outside [-B, B] met by the last duration_predictor call of this thread (all flows)
+
+/*
+ * unconstrained_rational_quadratic_spline, ref vits.cpp:804-852, LITERALLY (Q6), on one utterance. x [T]: the second half of the
+ * latent; u [3nb-1][T]: conv_proj output. Statement by statement:
+ *   :819-823  inside = (x >= -B) * (x <= B); outside = !inside
+ *   :832      outputs = masked_set(zeros, outside, masked_get(x, INSIDE))  — masked_get KEEPS THE SHAPE (x where the mask is 1, else 0:
+ *             custom-ops.h:746-749), masked_set consumes its values SEQUENTIALLY (values[index++] at every position whose mask is 1:
+ *             custom-ops.h:836-850). So the j-th outside token receives element j of [x_t if inside_t else 0] — an unrelated token's
+ *             latent or 0 —, not its own latent (HF: identity tails).
+ *   :834-835  the spline input of EVERY token is masked_get(x, inside): outside tokens enter as 0 ...
+ *   :837-840  ... with their unnormalised widths / heights / padded derivatives (constants of :829-830 included) zeroed by the same mask
+ *   :849      outputs = masked_set(outputs, inside, result): the k-th INSIDE token receives result[k] — the spline output of token k,
+ *             which is its own only while no token before it lay outside. One outside latent shifts every later token's value.
+ * With every latent inside, all of this is the identity permutation and equals spline_inverse() per token. (The reference's own
+ * known-answer test for masked_get expects the COMPACTED form {2,4,5} and is commented out: test/test_ggml_utils.cpp:584-590.)
+ */
+static void unconstrained_spline_reference(float* x, const float* u, int T, int nb, float B, float inv_sqrt) {
+    std::vector<float> inside(T), vals(T), res(T), out(T, 0.f), uw(nb), uh(nb), ud(nb - 1), udp(nb + 1);
+    for (int t = 0; t < T; ++t) {
+        inside[t] = (x[t] >= -B && x[t] <= B) ? 1.f : 0.f;  // :819-823
+        vals[t] = inside[t] == 1.f ? x[t] : 0.f;            // masked_get(inputs, inside_interval_mask), shape kept
+        if (inside[t] != 1.f) ++g_outside_latents;
+    }
+    {
+        int index = 0;  // :832 masked_set(outputs, outside_interval_mask, vals)
+        for (int t = 0; t < T; ++t)
+            if (inside[t] != 1.f) out[t] = vals[index++];
+    }
+    for (int t = 0; t < T; ++t) {
+        const float mk = inside[t];
+        for (int i = 0; i < nb; ++i) uw[i] = mk == 1.f ? u[(size_t)i * T + t] * inv_sqrt : 0.f;         // :878-880, :838
+        for (int i = 0; i < nb; ++i) uh[i] = mk == 1.f ? u[(size_t)(nb + i) * T + t] * inv_sqrt : 0.f;  // :881-883, :839
+        for (int i = 0; i < nb - 1; ++i) ud[i] = u[(size_t)(2 * nb + i) * T + t];                        // :885
+        padded_derivatives(ud.data(), nb, VO_MODE_REFERENCE, t == T - 1, udp.data());                    // :828-830
+        if (mk != 1.f)
+            for (int i = 0; i <= nb; ++i) udp[i] = 0.f;                                                  // :840
+        res[t] = spline_row(vals[t], uw.data(), uh.data(), udp.data(), nb, B, VO_MODE_REFERENCE, t == T - 1);
+    }
+    {
+        int index = 0;  // :849 masked_set(outputs, inside_interval_mask, result)
+        for (int t = 0; t < T; ++t)
+            if (inside[t] == 1.f) out[t] = res[index++];
+    }
+    std::memcpy(x, out.data(), sizeof(float) * T);
+}
+
 /* stochastic duration predictor (reverse), ref: vits.cpp:927-972, conv flow :855-899, affine :901-925; HF:740-804 */
 Act duration_predictor(const Ctx& c, const Act& enc_out, const float* noise /*[2][T]*/) {
     const vo_model& m = c.m;
@@ -811,6 +874,7 @@ Act duration_predictor(const Ctx& c, const Act& enc_out, const float* noise /*[2
     x = dds(c, dp + "conv_dds.", x, nullptr);                                                                           // ref :941
     Act cond = conv1d(x, m.T(dp + "conv_proj.weight"), &m.T(dp + "conv_proj.bias"), 1, 0, 0, false, 0.f, c.threads);    // ref :943
     Act z(2, T);
+    g_outside_latents = 0;
     for (int i = 0; i < 2 * T; ++i) z.d[i] = noise[i] * m.noise_scale_dur;  // ref :948-949
     const int nb = m.dp_bins;
     const float inv_sqrt = (float)(1.0 / std::sqrt((double)m.hidden));  // ref :877
@@ -833,12 +897,19 @@ Act duration_predictor(const Ctx& c, const Act& enc_out, const float* noise /*[2
             Act h = conv1d(z0, m.T(fb + "conv_pre.weight"), &m.T(fb + "conv_pre.bias"), 1, 0, 0, false, 0.f, c.threads);  // ref :864
             h = dds(c, fb + "conv_dds.", h, &cond);                                                                       // ref :868
             Act u = conv1d(h, m.T(fb + "conv_proj.weight"), &m.T(fb + "conv_proj.bias"), 1, 0, 0, false, 0.f, c.threads);  // ref :871, [3nb-1][T]
-            std::vector<float> uw(nb), uh(nb), ud(nb - 1);
-            for (int t = 0; t < T; ++t) {
-                for (int i = 0; i < nb; ++i) uw[i] = u.d[(size_t)i * T + t] * inv_sqrt;         // ref :878-880
-                for (int i = 0; i < nb; ++i) uh[i] = u.d[(size_t)(nb + i) * T + t] * inv_sqrt;  // ref :881-883
-                for (int i = 0; i < nb - 1; ++i) ud[i] = u.d[(size_t)(2 * nb + i) * T + t];     // ref :885
-                z.d[(size_t)T + t] = spline_inverse(z.d[(size_t)T + t], uw.data(), uh.data(), ud.data(), nb, m.dp_tail, c.mode, t == T - 1);
+            if (c.mode == VO_MODE_REFERENCE) {
+                // the reference's masked get / set pair, literally (Q6): equals the per-token form below while every latent is inside
+                unconstrained_spline_reference(z.d.data() + T, u.d.data(), T, nb, m.dp_tail, inv_sqrt);
+            } else {
+                std::vector<float> uw(nb), uh(nb), ud(nb - 1);
+                for (int t = 0; t < T; ++t) {
+                    for (int i = 0; i < nb; ++i) uw[i] = u.d[(size_t)i * T + t] * inv_sqrt;         // ref :878-880
+                    for (int i = 0; i < nb; ++i) uh[i] = u.d[(size_t)(nb + i) * T + t] * inv_sqrt;  // ref :881-883
+                    for (int i = 0; i < nb - 1; ++i) ud[i] = u.d[(size_t)(2 * nb + i) * T + t];     // ref :885
+                    const float xin = z.d[(size_t)T + t];
+                    if (!(xin >= -m.dp_tail && xin <= m.dp_tail)) ++g_outside_latents;
+                    z.d[(size_t)T + t] = spline_inverse(xin, uw.data(), uh.data(), ud.data(), nb, m.dp_tail, c.mode, t == T - 1);
+                }
             }
         }
     }
@@ -1407,8 +1478,14 @@ VO_API void vo_masked_set(const float* t, const float* mask, const float* values
     int64_t k = 0;
     for (int64_t i = 0; i < n; ++i) dst[i] = ((int)mask[i]) == 1 ? values[k++] : t[i];
 }
-/* ref: test_ggml_utils.cpp:585-590 expects the compacted form {2,4,5}; custom-ops.h:739-762 keeps the shape
- * (zeros) instead (Q6). This is the compacted form the test vector pins. */
+/* ref: custom-ops.h:739-762 as implemented: the SHAPE IS KEPT (t where the mask is 1, else 0) — what :832-840 of vits.cpp consume (Q6) */
+VO_API void vo_masked_get(const float* t, const float* mask, int64_t n, float* dst) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = ((int)mask[i]) == 1 ? t[i] : 0.f;
+}
+/* latents outside the spline interval met by the last vo_process_ids / vo_log_durations call of this thread (all three flows) */
+VO_API int64_t vo_outside_latents(void) { return g_outside_latents; }
+/* ref: test_ggml_utils.cpp:585-590 (commented out there) expects the compacted form {2,4,5}; custom-ops.h:739-762 keeps the shape
+ * (zeros) instead (Q6). This is the compacted form the test vector describes. */
 VO_API int64_t vo_masked_get_compact(const float* t, const float* mask, int64_t n, float* dst) {
     int64_t k = 0;
     for (int64_t i = 0; i < n; ++i)

@@ -13,8 +13,9 @@
  *       tests/golden/ (npz files), generator tests/golden/make_golden.py; oracle mode VO_MODE_HF must match them;
  *   (2) the reference's own helper-op known-answer vectors (test/test_ggml_utils.cpp:458-606);
  *   (3) the libstdc++ noise-stream known answer.
- * Mode VO_MODE_REFERENCE then applies the reference's literal deviations from HF (SURVEY.md App. B Q1-Q5),
- * each restated from the cited reference lines; that delta is pinned by reading, not by execution — the
+ * Mode VO_MODE_REFERENCE then applies the reference's literal deviations from HF (SURVEY.md App. B Q1-Q6),
+ * each restated from the cited reference lines and pinned by fixtures of a transformers.VitsModel patched with torch
+ * restatements of the same lines (tests/golden/: the _refmode_taps and _q6_refmode_taps files) — the
  * ggml arithmetic below the call sites (fp16 im2col, GELU/softmax tables; Q7/Q8) is "parity unpinned".
  */
 #ifndef VITS_ORACLE_H
@@ -125,6 +126,11 @@ VO_API void vo_index_put_last_dim(float* t, const int64_t ne[3], int32_t index, 
 VO_API void vo_index_add_last_dim(float* t, const int64_t ne[3], int32_t index, float value);
 VO_API void vo_masked_set(const float* t, const float* mask, const float* values, int64_t n, float* dst);
 VO_API int64_t vo_masked_get_compact(const float* t, const float* mask, int64_t n, float* dst);
+/* masked_get as custom-ops.h:739-762 implements it (shape kept, zeros where the mask is 0): the form vits.cpp:832-840 consumes (Q6) */
+VO_API void vo_masked_get(const float* t, const float* mask, int64_t n, float* dst);
+/* number of duration-predictor latents that lay outside [-tail_bound, tail_bound] in the last vo_process_ids / vo_log_durations call of
+ * the calling thread (summed over the three spline flows): 0 means the Q6 misalignment of vits.cpp:832-849 did not come into play */
+VO_API int64_t vo_outside_latents(void);
 VO_API void vo_gather0(const float* t, const int64_t ne[3], const float* index, int64_t n_index, float* dst);
 VO_API void vo_arange(int32_t end, float* dst);
 

@@ -137,20 +137,56 @@ def _ref_rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_hei
     return root * input_bin_widths + input_cumwidths                                                  # :797
 
 
+def _masked_get(t, mask):
+    """tensor_masked_get as IMPLEMENTED (src/include/custom-ops.h:739-752): `((int)src1) == 1 ? src0 : 0` element by element — the shape
+    is kept, zeros where the mask is 0. (A [tokens] mask against a [tokens, n] tensor is repeated along n first: broadcast_if_possible,
+    :729-736.) The reference's own known-answer test expects the compacted form and is commented out (test/test_ggml_utils.cpp:584-590)."""
+    if t.dim() == 2 and mask.dim() == 1:
+        mask = mask[:, None].expand_as(t)
+    return torch.where(mask == 1, t, torch.zeros_like(t))
+
+
+def _masked_set(t, mask, values):
+    """tensor_masked_set (src/include/custom-ops.h:829-862): walks the elements in order (custom_op2, :118-141: ne[0] outermost — token
+    order for the [tokens, 1, 1] tensors it is called with) and takes `values[index++]` wherever the mask is 1: the values are consumed
+    SEQUENTIALLY from the front of `values`, whatever position they came from."""
+    out = t.clone()
+    index = 0
+    for i in range(t.numel()):
+        if int(mask[i]) == 1:
+            out[i] = values[index]
+            index += 1
+    return out
+
+
 def _ref_unconstrained_rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, reverse=False,
                                                  tail_bound=5.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
-    """src/vits.cpp:804-852. inputs [1, 1, T]; the others [1, 1, T, bins(-1)]. Every latent of the fixtures lies inside
-    [-tail_bound, tail_bound] (asserted), so the masked get/set pair of :832-849 — whose misalignment outside the interval
-    (Q6) is documented as not reproduced — is the identity here."""
+    """src/vits.cpp:804-852, statement by statement — including the masked get / set pair of :832-849 (Q6): masked_get keeps the shape,
+    masked_set consumes compacted values, so ONE latent outside [-tail_bound, tail_bound] hands every later token the spline output of
+    its predecessor-by-count, and the outside tokens receive unrelated latents. With every latent inside, both masked_set calls are the
+    identity permutation (the non-q6 fixtures). inputs [1, 1, T]; the others [1, 1, T, bins(-1)]."""
     assert reverse and inputs.shape[0] == 1 and inputs.shape[1] == 1
-    assert bool(((inputs >= -tail_bound) & (inputs <= tail_bound)).all()), "fixture latent outside the spline interval (Q6 territory)"
+    x = inputs[0, 0]
+    more_than_min = (x >= -tail_bound).float()                                                        # :819
+    less_than_max = (x <= tail_bound).float()                                                         # :820
+    inside = less_than_max * more_than_min                                                            # :822
+    outside = 1.0 - inside                                                                            # :823 (tensor_binary_not)
+    outputs = torch.zeros_like(x)                                                                     # :825
     constant = float(np.log(np.exp(1 - min_derivative) - 1))                                         # :826
     ud = torch.nn.functional.pad(unnormalized_derivatives[0, 0], (1, 1))                              # :828
     ud[:, 0] = constant                                                                               # :829
     _put_last_wrapped(ud, constant)                                                                   # :830  (Q4)
-    out = _ref_rational_quadratic_spline(inputs[0, 0], unnormalized_widths[0, 0], unnormalized_heights[0, 0], ud, reverse, tail_bound,
-                                         min_bin_width, min_bin_height, min_derivative)
-    return out[None, None], torch.zeros_like(inputs)
+    outputs = _masked_set(outputs, outside, _masked_get(x, inside))                                   # :832  (Q6: values of the INSIDE mask)
+    reshaped_inputs = _masked_get(x, inside)                                                          # :834-835
+    result = _ref_rational_quadratic_spline(reshaped_inputs, _masked_get(unnormalized_widths[0, 0], inside),                    # :837-847
+                                            _masked_get(unnormalized_heights[0, 0], inside), _masked_get(ud, inside), reverse, tail_bound,
+                                            min_bin_width, min_bin_height, min_derivative)
+    outputs = _masked_set(outputs, inside, result)                                                    # :849
+    _ref_unconstrained_rational_quadratic_spline.outside_seen += int(outside.sum())
+    return outputs[None, None], torch.zeros_like(inputs)
+
+
+_ref_unconstrained_rational_quadratic_spline.outside_seen = 0
 
 
 def _ref_elementwise_affine_forward(self, inputs, padding_mask, global_conditioning=None, reverse=False):
@@ -175,7 +211,7 @@ class reference_mode_patches:
 
 
 @torch.no_grad()
-def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False):
+def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False, stage_one_only=False):
     """Restates VitsModel.forward (modeling_vits.py:1298-1394) step by step to expose the stage outputs, with the two
     torch.randn draws replaced by the supplied arrays. refmode: call inside `reference_mode_patches()`; additionally the
     transposed convs run without padding (Q1, src/vits.cpp:187 overwrites padding with 0), the resblock mean is a multiply by
@@ -196,6 +232,9 @@ def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False):
         torch.randn = real_randn
     length_scale = 1.0 / model.speaking_rate
     duration = torch.ceil(torch.exp(log_duration) * mask_t * length_scale)
+    if stage_one_only:
+        f = lambda t: t[0].numpy().astype(np.float32)
+        return dict(ids=ids.astype(np.int32), noise_dur=noise_dur.astype(np.float32), enc_out=f(hidden), log_duration=f(log_duration), durations=f(duration))
     predicted_lengths = torch.clamp_min(torch.sum(duration, [1, 2]), 1).long()
     L = int(predicted_lengths.max())
     out_mask = (torch.arange(L)[None] < predicted_lengths[:, None]).unsqueeze(1).float()
@@ -257,6 +296,83 @@ def taps_for(parsed, T, seed, refmode=False):
         with reference_mode_patches():
             return hf_taps(model, ids, nd, lambda L: rng.standard_normal((F, L)).astype(np.float32), refmode=True)
     return hf_taps(model, ids, nd, lambda L: rng.standard_normal((F, L)).astype(np.float32))
+
+
+def q6_taps_for(parsed, T, seed, noise_gain):
+    """Stage one (text encoder + duration predictor) in reference mode with the duration noise scaled by `noise_gain`, so that latents
+    LEAVE the spline interval [-5, 5] and the reference's masked get / set misalignment (Q6, src/vits.cpp:832-849) shapes the result.
+    Stage-one taps only (an outside latent can make a token hundreds of frames long: the audio would not be a small fixture)."""
+    model = hf_model_from_file(parsed)
+    rng = np.random.default_rng(seed)
+    ids = make_ids(T, model.config.vocab_size, seed)
+    nd = (rng.standard_normal((2, T)) * noise_gain).astype(np.float32)
+    with reference_mode_patches():
+        _ref_unconstrained_rational_quadratic_spline.outside_seen = 0
+        taps = hf_taps(model, ids, nd, None, refmode=True, stage_one_only=True)
+        taps["outside_latents"] = np.array([_ref_unconstrained_rational_quadratic_spline.outside_seen], np.int64)
+    assert taps["outside_latents"][0] > 0, "no latent left the interval: the fixture would not pin Q6"
+    return taps
+
+
+# ---- the counter-based synthetic streams of include/vits_synth_noise.h in numpy (an input DATA definition: integer hashing, one
+# exact int -> float conversion, one exact subtraction and ONE rounded float multiply — bit-identical to the C header) -----------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(z):
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _hash3(seed, stream, index):
+    with np.errstate(over="ignore"):
+        h = _mix64(np.uint64(seed) ^ np.uint64(0xD1B54A32D192ED03))
+        h = _mix64(h ^ (np.uint64(stream) * np.uint64(0x9E3779B97F4A7C15)))
+        return _mix64(h ^ index.astype(np.uint64))
+
+
+def counter_normal(seed, stream, index):
+    """vits_counter_normal(seed, stream, index) for an array of indices"""
+    index = np.asarray(index, np.uint64)
+    a, b = _hash3(seed, stream, np.uint64(2) * index), _hash3(seed, stream, np.uint64(2) * index + np.uint64(1))
+    s = np.zeros(index.shape, np.int64)
+    for h in (a, b):
+        for sh in (0, 16, 32, 48):
+            s += ((h >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.int64)
+    centred = s.astype(np.float32) - np.float32(262140.0)
+    return (centred * np.float32(1.8688258e-05)).astype(np.float32)
+
+
+def synth_ids(ids_seed, utt, T, vocab):
+    """vits_synth_id(ids_seed, utt, t, vocab) for t in [0, T)"""
+    t = np.arange(T, dtype=np.uint64)
+    u = (_hash3(ids_seed + utt, 3, t) >> np.uint64(33)) % np.uint64(vocab - 1)
+    ids = 1 + u.astype(np.int32)
+    ids[0::2] = 0
+    return ids.astype(np.int32)
+
+
+def bench_utterance_taps(parsed, utt=0, T=128, ids_seed=1234, noise_seed=4321, decimate=4):
+    """Utterance `utt` of bench.py's batch (64 x 128 ids: ids from the counter stream with seed 1234 + utt, noise with seed 4321 + utt)
+    through the reference-mode patched transformers model: pins the benchmark's own size independently of the oracle (VERDICT r3
+    missing 4). The noise is the counter stream itself (inputs need not be stored: the GPU run uses VITS_NOISE_COUNTER like the bench);
+    stored: durations, log-durations, the flow output and every `decimate`-th sample of the waveform (<= 300 KB)."""
+    model = hf_model_from_file(parsed)
+    ids = synth_ids(ids_seed, utt, T, model.config.vocab_size)
+    seed = noise_seed + utt
+    nd = counter_normal(seed, 1, np.arange(2 * T)).reshape(2, T)
+    F = model.config.flow_size
+    with reference_mode_patches():
+        _ref_unconstrained_rational_quadratic_spline.outside_seen = 0
+        taps = hf_taps(model, ids, nd, lambda L: counter_normal(seed, 2, np.arange(F * L)).reshape(F, L), refmode=True)
+        assert _ref_unconstrained_rational_quadratic_spline.outside_seen == 0
+    return dict(ids=taps["ids"], ids_seed=np.array([ids_seed], np.int64), noise_seed=np.array([noise_seed], np.int64), utt=np.array([utt], np.int64),
+                log_duration=taps["log_duration"], durations=taps["durations"], z_flow=taps["z_flow"], waveform_len=np.array([taps["waveform"].size], np.int64),
+                waveform_decimated=taps["waveform"][..., ::decimate].copy(), pre_tanh_decimated=taps["pre_tanh"][..., ::decimate].copy(),
+                decimate=np.array([decimate], np.int64))
 
 
 def reference_exported_tiny():
@@ -325,6 +441,18 @@ def main():
     print("reference mode: frames", int(rtaps["durations"].sum()), "vs HF", int(taps["durations"].sum()), "; samples", rtaps["waveform"].size, "vs", taps["waveform"].size)
     for k, v in taps.items():
         print(k, v.shape, float(np.sqrt((v.astype(np.float64) ** 2).mean())))
+    # (D) Q6: latents outside the spline interval (duration noise x 4: |0.8 * 4 * n| > 5 for one draw in eight), stage one only
+    q = q6_taps_for(parse_model_file(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)), 24, 21, 4.0)
+    np.savez(os.path.join(HERE, "tiny_synth_q6_refmode_taps.npz"), **q)
+    print("tiny q6: outside latents", int(q["outside_latents"][0]), "durations", q["durations"].astype(int).ravel().tolist())
+    q = q6_taps_for(parse_model_file(data), 40, 22, 4.0)
+    np.savez(os.path.join(HERE, "full_synth_q6_refmode_taps.npz"), **q)
+    print("full q6: outside latents", int(q["outside_latents"][0]), "durations", q["durations"].astype(int).ravel().tolist())
+    # (E) the benchmark's own size: utterance 0 of bench.py's batch (128 ids) through the patched model
+    b = bench_utterance_taps(parse_model_file(data))
+    np.savez_compressed(os.path.join(HERE, "bench_utt0_refmode_taps.npz"), **b)
+    print("bench utterance 0: frames", int(b["durations"].sum()), "samples", int(b["waveform_len"][0]), "file",
+          os.path.getsize(os.path.join(HERE, "bench_utt0_refmode_taps.npz")), "bytes")
 
 
 if __name__ == "__main__":

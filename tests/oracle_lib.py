@@ -162,10 +162,11 @@ class Model:
             lib().vo_run_free(r)
 
 
-def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, threads=0, arith=0, arith_scope=SCOPE_FLOW_VOCODER):
+def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, threads=0, arith=0, arith_scope=SCOPE_FLOW_VOCODER, noise_dur=None):
     """Stage one only (text encoder + duration predictor): (log_duration [T], durations [T]) of one utterance."""
     ids = np.ascontiguousarray(ids, dtype=np.int32)
-    o = Opts(mode, noise_kind, noise_seed, None, None, 0, 0, threads, arith, arith_scope)
+    nd = _f32(noise_dur)
+    o = Opts(mode, noise_kind, noise_seed, _ptr(nd), None, 0, 0, threads, arith, arith_scope)
     logw, dur = np.zeros(ids.size, np.float32), np.zeros(ids.size, np.float32)
     if lib().vo_log_durations(self._h, _ptr(ids), ids.size, C.byref(o), _ptr(logw), _ptr(dur)) != 0:
         raise OracleError(lib().vo_last_error().decode())
@@ -173,6 +174,13 @@ def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noi
 
 
 Model.log_durations = _log_durations
+
+
+def outside_latents():
+    """latents outside the spline interval in the last process_ids / log_durations call of this thread (vo_outside_latents)"""
+    f = lib().vo_outside_latents
+    f.restype = C.c_int64
+    return int(f())
 
 
 def reference_noise(n, seed=None):

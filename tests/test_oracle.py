@@ -49,6 +49,61 @@ def test_oracle_reference_mode_reproduces_the_patched_transformers_taps(pkg, ora
     assert g["waveform"].size > ups * int(g["durations"].sum())
 
 
+@pytest.mark.parametrize("fixture", ["tiny_synth_q6_refmode_taps.npz", "full_synth_q6_refmode_taps.npz"])
+def test_oracle_reference_mode_reproduces_the_masked_get_set_misalignment(pkg, oracle, tiny_hf_bytes, fixture):
+    """Q6 (VERDICT r3 missing 1): with latents OUTSIDE [-5, 5] the reference's tensor_masked_get keeps the shape while tensor_masked_set
+    consumes compacted values (vits.cpp:832-849, custom-ops.h:739-752,829-862): one outside latent hands every later token its
+    predecessor-by-count's spline output. The fixture is a transformers.VitsModel patched with a statement-by-statement torch restatement
+    of those lines (make_golden.py, duration noise x 4); oracle(VO_MODE_REFERENCE) must reproduce its log-durations and durations — and
+    HF's identity tails (VO_MODE_HF, and the oracle's reading before round 4) must NOT."""
+    g = golden(fixture)
+    m = oracle.Model(_bytes_for(fixture, pkg, tiny_hf_bytes))
+    logw, dur = m.log_durations(g["ids"], mode=oracle.MODE_REFERENCE, noise_kind=oracle.NOISE_EXPLICIT, noise_dur=g["noise_dur"])
+    assert oracle.outside_latents() == int(g["outside_latents"][0]) > 0
+    np.testing.assert_array_equal(dur, g["durations"].ravel())
+    assert rel_err(logw, g["log_duration"]) < 1e-4
+    logw_hf, _ = m.log_durations(g["ids"], mode=oracle.MODE_HF, noise_kind=oracle.NOISE_EXPLICIT, noise_dur=g["noise_dur"])
+    assert rel_err(logw_hf, g["log_duration"]) > 1e-2
+
+
+def test_counter_noise_numpy_port_is_the_header(pkg, oracle):
+    """make_golden.py's numpy port of include/vits_synth_noise.h (used to feed the patched transformers model the benchmark's counter
+    noise) is bit-identical to the C header: the oracle run on the counter stream equals the oracle run on the port's values."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    m = oracle.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY))
+    for utt in (0, 5):
+        ids = mg.synth_ids(1234, utt, 31, 38)
+        np.testing.assert_array_equal(ids, pkg.synth_ids(utt + 1, 31)[utt])
+        nd = mg.counter_normal(4321 + utt, 1, np.arange(2 * 31)).reshape(2, 31)
+        a = m.log_durations(ids, noise_kind=oracle.NOISE_COUNTER, noise_seed=4321 + utt)
+        b = m.log_durations(ids, noise_kind=oracle.NOISE_EXPLICIT, noise_dur=nd)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    assert abs(float(mg.counter_normal(7, 2, np.arange(200000)).std()) - 1.0) < 0.01
+
+
+def test_oracle_reproduces_the_benchmark_size_utterance(pkg, oracle):
+    """VERDICT r3 missing 4: utterance 0 of bench.py's batch (128 ids, ids seed 1234, counter noise seed 4321) through the patched
+    transformers model (tests/golden/bench_utt0_refmode_taps.npz) — the benchmark's own size pinned independently of the oracle."""
+    g = golden("bench_utt0_refmode_taps.npz")
+    ids = pkg.synth_ids(1, 128, ids_seed=int(g["ids_seed"][0]))[0]
+    np.testing.assert_array_equal(ids, g["ids"])
+    m = oracle.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL))
+    r = m.process_ids(ids, mode=oracle.MODE_REFERENCE, noise_kind=oracle.NOISE_COUNTER, noise_seed=int(g["noise_seed"][0]) + int(g["utt"][0]),
+                      taps=["log_duration", "durations", "z_flow", "pre_tanh", "waveform"])
+    np.testing.assert_array_equal(r["durations"], g["durations"].ravel())
+    assert oracle.outside_latents() == 0
+    assert r["waveform"].size == int(g["waveform_len"][0])
+    d = int(g["decimate"][0])
+    assert rel_err(r["log_duration"], g["log_duration"]) < 1e-4
+    assert rel_err(r["z_flow"], g["z_flow"]) < 1e-4
+    assert rel_err(r["pre_tanh"][::d], g["pre_tanh_decimated"]) < 2e-4
+    assert rel_err(r["waveform"][::d], g["waveform_decimated"]) < 2e-4
+
+
 def test_readers_agree_with_reference_exporter_file(pkg, oracle, tiny_hf_bytes):
     """Three readers (product C++, oracle C++, numpy) on the file the reference's exporter wrote."""
     py = parse_model_file(tiny_hf_bytes)
@@ -219,7 +274,11 @@ def test_kat_index_put_add_masked_set_arange(oracle):
     L.vo_masked_set(_p(INPUT), _p(mask), _p(vals), 6, _p(out))  # :577-583
     assert out.tolist() == [1, 10, 3, 10, 10, 6]
     o3 = np.zeros(6, np.float32)
-    assert L.vo_masked_get_compact(_p(INPUT), _p(mask), 6, _p(o3)) == 3 and o3[:3].tolist() == [2, 4, 5]  # :585-590
+    assert L.vo_masked_get_compact(_p(INPUT), _p(mask), 6, _p(o3)) == 3 and o3[:3].tolist() == [2, 4, 5]  # :585-590 (COMMENTED OUT in the reference:
+    # its masked_get keeps the shape — custom-ops.h:746-749 `((int)src1) == 1 ? src0 : 0` — which is what vits.cpp:832-840 consume, Q6)
+    o4 = np.full(6, -1, np.float32)
+    L.vo_masked_get(_p(INPUT), _p(mask), 6, _p(o4))
+    assert o4.tolist() == [0, 2, 0, 4, 5, 0]
     ar = np.zeros(6, np.float32)
     L.vo_arange(6, _p(ar))  # :600-605
     assert ar.tolist() == [0, 1, 2, 3, 4, 5]

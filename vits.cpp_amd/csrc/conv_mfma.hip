@@ -122,6 +122,10 @@ __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]
 // a boundary tile costs the producer ~(columns outside) / 2 stores. (A predicated store per (row, 64-column piece) — 96 branches for
 // mostly one or two active lanes each — took 7.5-14k cycles per chunk: at 128 tokens per utterance EVERY tile is a boundary tile, and
 // the compute waves of the encoder's FFN convs waited for that loop half of the time.)
+// Each lane starts its walk at its own column (row r begins at outside-column r mod noob): ds_write_b32 is served in two groups of 32
+// lanes on banks (address / 4) mod 32, and XWP is a multiple of 16, so 32 rows at ONE column sit on two banks — a 16-way conflict per
+// store, which was the whole LDS_BANK_CONFLICT / LDS_IDX_ACTIVE = 0.30-0.37 of the stage-one tiles (round-3 PMC). Rotated, the rows of a
+// store hit min(noob, 16) different banks of their half.
 template <int XWP>
 __device__ __forceinline__ void zero_oob_columns(float* lbase, int ts, int len, int lane) {
     int nl = -ts;
@@ -129,8 +133,14 @@ __device__ __forceinline__ void zero_oob_columns(float* lbase, int ts, int len, 
     int rs = len - ts;
     rs = rs < nl ? nl : (rs > XWP ? XWP : rs);
     const int noob = nl + XWP - rs;
+    if (noob <= 0) return;
     float* row = lbase + (lane & 31) * XWP;
-    for (int k = lane >> 5; k < noob; k += 2) row[k < nl ? k : rs + (k - nl)] = 0.f;
+    int k = (lane & 31) % noob;  // (loop-invariant over the chunks of a block: computed once)
+    for (int i = lane >> 5; i < noob; i += 2) {
+        int kk = k + i;
+        kk = kk >= noob ? kk - noob : kk;
+        row[kk < nl ? kk : rs + (kk - nl)] = 0.f;
+    }
 }
 
 // The kernel body as a device function of the block's (column tile, row-tile group, utterance) coordinates and the block's dynamic

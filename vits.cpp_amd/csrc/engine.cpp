@@ -283,6 +283,13 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
             c.slen[i][b] = frames[b] * c.smul[i] + c.sadd[i];
             c.smax[i] = std::max(c.smax[i], c.slen[i][b]);
         }
+    if (o.collect_taps) {
+        TensorRef d;
+        d.p = c.s1.dur;
+        d.cs = id_stride;
+        d.bs = id_stride;
+        snapshot("durations", d, 1, c.Tmax, B, c.tlen);
+    }
     if (o.frames_only) {
         // dispatcher query: predicted frames / samples per utterance, no audio (buffer sizing, shard balancing by frames)
         if (out) {
@@ -299,13 +306,6 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         HIP_OK(hipStreamSynchronize(stream));
         prof.fence();
         return 0;
-    }
-    if (o.collect_taps) {
-        TensorRef d;
-        d.p = c.s1.dur;
-        d.cs = id_stride;
-        d.bs = id_stride;
-        snapshot("durations", d, 1, c.Tmax, B, c.tlen);
     }
 
     // ---- vocoder windows (long-form / streaming, vits.h vocoder_chunk_frames) ------------------------------------

@@ -1202,31 +1202,30 @@ hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int t
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Inverse rational-quadratic spline on latent row zc, one thread per token
-//   vits.cpp:695-802 (+ tails :804-852); HF modeling_vits.py:139-163,211-302. u = conv_proj output [3*bins-1][T].
-//   mode == VITS_MODE_REFERENCE applies Q3 (:720) and, on the LAST token, Q4 (ggml-util.h:235-236,252-253).
+// Inverse rational-quadratic spline on latent row zc (unconstrained_rational_quadratic_spline, vits.cpp:804-852 + :695-802;
+// HF modeling_vits.py:139-163,211-302). u = conv_proj output [3*bins-1][T]. One block per utterance, one thread per token (tokens
+// beyond 1024 loop).
+//   VITS_MODE_HF: identity outside [-B, B], the spline inside (HF:143-151).
+//   VITS_MODE_REFERENCE: Q3 (:720), on the LAST token Q4 (ggml-util.h:235-236,252-253), and the masked get / set pair of :832-849
+//   LITERALLY (Q6): tensor_masked_get keeps the shape (custom-ops.h:746-749) while tensor_masked_set consumes its values sequentially
+//   (custom-ops.h:836-850). Every token goes through the spline — an outside token as input 0 with zeroed widths / heights / padded
+//   derivatives (:834-840) —, the k-th INSIDE token receives the result of token k, and the j-th OUTSIDE token receives element j of
+//   [x_t if inside_t else 0]. While every latent of the utterance lies inside (all 8,192 ids of the benchmark batch) that is the identity
+//   permutation and each token keeps its own spline output: the block only pays one __syncthreads_or for it.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int MAX_BINS = 16;
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : (float)log(1.0 + exp((double)x)); }  // custom-ops.h:872-879
 
-__global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax, int nb, float B,
-                              float inv_sqrt, int mode) {
-    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int len = lens ? lens[b] : tmax;
-    if (t >= len) return;
-    float* zp = z + (int64_t)b * z_bs + (int64_t)zc * z_cs + t;
-    const float x = *zp;
-    if (!(x >= -B && x <= B)) return;  // identity outside the interval (:819-832)
-    const float* ub = u + (int64_t)b * u_bs + t;
-    const bool q4 = (mode == VITS_MODE_REFERENCE) && (t == len - 1);
+// rational_quadratic_spline (vits.cpp:695-802) on one token's row; masked: the row's parameters were zeroed by :837-840
+__device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, int nb, float B, float inv_sqrt, int mode, bool q4, bool masked) {
     const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
     float W[MAX_BINS], H[MAX_BINS], cw[MAX_BINS + 1], ch[MAX_BINS + 1];
     // widths
     {
         float mx = -INFINITY;
         for (int i = 0; i < nb; ++i) {
-            W[i] = ub[(int64_t)i * u_cs] * inv_sqrt;
+            W[i] = masked ? 0.f : ub[(int64_t)i * u_cs] * inv_sqrt;
             mx = fmaxf(mx, W[i]);
         }
         float sum = 0.f;
@@ -1255,7 +1254,7 @@ __global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, 
     {
         float mx = -INFINITY;
         for (int i = 0; i < nb; ++i) {
-            H[i] = ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
+            H[i] = masked ? 0.f : ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
             mx = fmaxf(mx, H[i]);
         }
         float sum = 0.f;
@@ -1286,7 +1285,8 @@ __global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, 
     const float constant = (float)log(exp(1.0 - (double)min_d) - 1.0);
     auto deriv = [&](int i) -> float {
         float ud;
-        if (i == 0) ud = constant;
+        if (masked) ud = 0.f;  // (the constants of :829-830 are zeroed by the mask as well, :840)
+        else if (i == 0) ud = constant;
         else if (i == nb) ud = q4 ? 0.f : constant;
         else ud = ub[(int64_t)(2 * nb + i - 1) * u_cs];
         return min_d + softplus_f(ud);
@@ -1309,13 +1309,56 @@ __global__ void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, 
     const float cc = -delta * i2;
     const float disc = bq * bq - 4 * a * cc;
     const float root = (2 * cc) / (-bq - sqrtf(disc));
-    *zp = root * in_w + in_cw;
+    return root * in_w + in_cw;
+}
+
+__global__ __launch_bounds__(1024) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
+                                                      int nb, float B, float inv_sqrt, int mode) {
+    extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance
+    const int b = blockIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    const int tpad = (tmax + 63) & ~63;
+    float* s_val = spline_lds;
+    float* s_res = spline_lds + tpad;
+    int* s_in = reinterpret_cast<int*>(spline_lds + 2 * tpad);
+    float* zrow = z + (int64_t)b * z_bs + (int64_t)zc * z_cs;
+    const bool ref = mode == VITS_MODE_REFERENCE;
+    int any_outside = 0;
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+        const float x = zrow[t];
+        const bool inside = x >= -B && x <= B;
+        const float* ub = u + (int64_t)b * u_bs + t;
+        float r = x;  // HF: identity outside the interval (HF:143-151)
+        if (inside || ref) r = spline_row(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside);
+        if (ref) {
+            s_val[t] = inside ? x : 0.f;  // tensor_masked_get(inputs, inside_interval_mask): the shape is kept
+            s_res[t] = r;
+            s_in[t] = inside ? 1 : 0;
+            any_outside |= inside ? 0 : 1;
+        } else {
+            zrow[t] = r;
+        }
+    }
+    if (!ref) return;
+    if (!__syncthreads_or(any_outside)) {
+        // every latent inside: both masked_set calls are the identity permutation
+        for (int t = threadIdx.x; t < len; t += blockDim.x) zrow[t] = s_res[t];
+        return;
+    }
+    // Q6: the j-th outside token takes element j of the masked input (:832), the k-th inside token the result of token k (:849)
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+        int nout = 0;
+        for (int j = 0; j < t; ++j) nout += 1 - s_in[j];
+        zrow[t] = s_in[t] ? s_res[t - nout] : s_val[nout];
+    }
 }
 
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode, hipStream_t s) {
-    if (bins > MAX_BINS) return hipErrorInvalidValue;
-    dim3 grid((tmax + 63) / 64, batch);
-    VITS_KLAUNCH(spline_kernel, grid, dim3(64), 0, s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt, mode);
+    if (bins > MAX_BINS || tmax > 4096) return hipErrorInvalidValue;
+    const int tpad = (tmax + 63) & ~63;
+    const int threads = tpad < 1024 ? tpad : 1024;
+    VITS_KLAUNCH(spline_kernel, dim3(batch), dim3(threads), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt,
+                 mode);
     return hipGetLastError();
 }
 
