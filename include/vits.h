@@ -100,6 +100,18 @@ VITS_API int vits_model_get_arith(const vits_model* model);
 VITS_API int vits_model_set_arith_scope(vits_model* model, int scope);
 VITS_API int vits_model_get_arith_scope(const vits_model* model);
 
+/* EMULATED ggml lookup tables — INFERRED from upstream ggerganov/ggml of the reference's era: the maxilevi/ggml fork the
+ * reference is built against is absent (empty submodule), so this is a labelled emulation of what `ggml_gelu` (vits.cpp:673,687) and
+ * `ggml_soft_max` (vits.cpp:329,719,735) most probably compute there, not a pinned restatement:
+ *   ggml_gelu:     y = fp16->fp32( table_gelu_f16[ fp32->fp16(x) ] ), the table holding fp16( 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2))) );
+ *   ggml_soft_max: e_i = fp16->fp32( table_exp_f16[ fp32->fp16(x_i - max) ] ), the sum in double, p_i = e_i * (float)(1 / sum).
+ * on = 1 routes the GELU of the duration predictor's DDS layers and the soft-max of the text encoder's attention and of the spline bins
+ * through device copies of those tables (built on the host with the C library, as ggml_init does). Default 0: erf-GELU (what
+ * transformers.VitsModel computes) and fp32 soft-max — the mode every parity fixture is in. Durations carry the tables' 5e-4 relative
+ * rounding noise when on (bench.py reports how many of the benchmark batch's 8,192 durations move). Set between calls. */
+VITS_API int vits_model_set_ggml_tables(vits_model* model, int on);
+VITS_API int vits_model_get_ggml_tables(const vits_model* model);
+
 /* Noise source for the two N(0,1) draws (vits.cpp:948 [T,2] and :1059 [L,192]). */
 #define VITS_NOISE_REFERENCE 0 /* libstdc++ minstd_rand0 + normal_distribution<float>, global, host-serial */
 #define VITS_NOISE_COUNTER 1   /* include/vits_synth_noise.h, evaluated on the device                       */

@@ -370,6 +370,36 @@ inline float round_f16(float f) {
     return out;
 }
 inline float round_arith(float v, int arith) { return arith == 2 ? round_f16(v) : arith == 1 ? round_bf16(v) : v; }
+
+// ------------------------------------------------------------------------------------------------
+// EMULATED ggml arithmetic (Q8) — INFERRED from upstream ggerganov/ggml of the reference's era (late 2023); the maxilevi/ggml fork the
+// reference builds against is absent (empty submodule), so this is a labelled emulation, not a pinned restatement:
+//   ggml_gelu (vits.cpp:673,687): GGML_GELU_FP16 is on by default — y = FP16_TO_FP32(table_gelu_f16[FP32_TO_FP16(x)]) with
+//     table_gelu_f16[i] = FP32_TO_FP16(0.5 x (1 + tanhf(sqrt(2/pi) x (1 + 0.044715 x^2)))) of x = FP16_TO_FP32(i)      (ggml.c ggml_vec_gelu_f32)
+//   ggml_soft_max (vits.cpp:329,719,735): val_i = FP16_TO_FP32(table_exp_f16[FP32_TO_FP16(x_i - max)]), table_exp_f16[i] = FP32_TO_FP16(expf(..)),
+//     sum accumulated in double, then every val_i multiplied by (float)(1.0 / sum)                                  (ggml.c ggml_compute_forward_soft_max_f32)
+// A table indexed by the fp16 bits is a pure function of the rounded argument, so round_f16(f(round_f16(x))) IS the table lookup.
+// Selected per call with vo_opts.ggml_tables; default off (erf-GELU as in HF / fp32 soft-max).
+// ------------------------------------------------------------------------------------------------
+thread_local int g_ggml_tables = 0;
+inline float gelu_tanh_f32(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x))); }
+inline float gelu_ggml_table(float x) { return round_f16(gelu_tanh_f32(round_f16(x))); }
+inline float exp_ggml_table(float d) { return round_f16(expf(round_f16(d))); }
+// in place over s[0..n), n > 0
+inline void softmax_ggml_table(float* s, int n) {
+    float mx = -INFINITY;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, s[i]);
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (s[i] == -INFINITY) s[i] = 0.f;
+        else {
+            s[i] = exp_ggml_table(s[i] - mx);
+            sum += (double)s[i];
+        }
+    }
+    const float inv = (float)(1.0 / sum);
+    for (int i = 0; i < n; ++i) s[i] *= inv;
+}
 // weights rounded to the arithmetic type (cached per call site is not worth it: the oracle is a checker)
 inline const float* rounded_weights(const float* w, size_t n, int arith, std::vector<float>& store) {
     if (!arith) return w;
@@ -570,13 +600,17 @@ void rel_attention(const float* q, const float* k, const float* v, int H, int hd
                 s[j] = a;
                 mx = std::max(mx, a);
             }
-            float sum = 0.f;
-            for (int j = 0; j < len; ++j) {
-                s[j] = std::exp(s[j] - mx);
-                sum += s[j];
+            if (g_ggml_tables) {
+                softmax_ggml_table(s.data(), len);  // ref :329 ggml_soft_max (emulated, Q8)
+            } else {
+                float sum = 0.f;
+                for (int j = 0; j < len; ++j) {
+                    s[j] = std::exp(s[j] - mx);
+                    sum += s[j];
+                }
+                const float inv = 1.0f / sum;
+                for (int j = 0; j < len; ++j) s[j] *= inv;
             }
-            const float inv = 1.0f / sum;
-            for (int j = 0; j < len; ++j) s[j] *= inv;
             for (int d = 0; d < hd; ++d) {
                 float a = 0.f;
                 for (int j = 0; j < len; ++j) a += s[j] * vh[(size_t)d * stride + j];
@@ -704,11 +738,11 @@ Act dds(const Ctx& c, const std::string& base, Act x, const Act* g) {
             }
         }
         layer_norm_channels(h, m.T(base + "norms_1." + std::to_string(i) + ".weight"), m.T(base + "norms_1." + std::to_string(i) + ".bias"), 1e-5f);
-        for (auto& f : h.d) f = gelu_erf(f);  // ref :673 ggml_gelu (tanh-approx table in ggml, Q8 — unpinned); HF erf
+        for (auto& f : h.d) f = g_ggml_tables ? gelu_ggml_table(f) : gelu_erf(f);  // ref :673 ggml_gelu (tanh-approx fp16 table in ggml: Q8, emulated on request); HF erf
         Act p = conv1d(h, m.T(base + "convs_pointwise." + std::to_string(i) + ".weight"), &m.T(base + "convs_pointwise." + std::to_string(i) + ".bias"), 1,
                        0, 0, false, 0.f, c.threads);
         layer_norm_channels(p, m.T(base + "norms_2." + std::to_string(i) + ".weight"), m.T(base + "norms_2." + std::to_string(i) + ".bias"), 1e-5f);
-        for (auto& f : p.d) f = gelu_erf(f);
+        for (auto& f : p.d) f = g_ggml_tables ? gelu_ggml_table(f) : gelu_erf(f);  // ref :687
         for (size_t e = 0; e < x.d.size(); ++e) x.d[e] += p.d[e];  // ref :688
     }
     return x;
@@ -727,14 +761,19 @@ static float spline_row(float x, const float* uw, const float* uh, const float* 
     std::vector<float> W(nb), Hh(nb), cw(nb + 1), chh(nb + 1), D(nb + 1);
     // widths
     {
-        float mx = -INFINITY;
-        for (int i = 0; i < nb; ++i) mx = std::max(mx, uw[i]);
-        float sum = 0.f;
-        for (int i = 0; i < nb; ++i) {
-            W[i] = std::exp(uw[i] - mx);
-            sum += W[i];
+        if (g_ggml_tables) {  // ref :719 ggml_soft_max (emulated, Q8)
+            for (int i = 0; i < nb; ++i) W[i] = uw[i];
+            softmax_ggml_table(W.data(), nb);
+        } else {
+            float mx = -INFINITY;
+            for (int i = 0; i < nb; ++i) mx = std::max(mx, uw[i]);
+            float sum = 0.f;
+            for (int i = 0; i < nb; ++i) {
+                W[i] = std::exp(uw[i] - mx);
+                sum += W[i];
+            }
+            for (int i = 0; i < nb; ++i) W[i] /= sum;
         }
-        for (int i = 0; i < nb; ++i) W[i] /= sum;
         if (mode == VO_MODE_REFERENCE) {
             const float sc = min_w + (1 - min_w * nb);  // ref :720 (Q3)
             for (int i = 0; i < nb; ++i) W[i] = W[i] * sc;
@@ -754,14 +793,19 @@ static float spline_row(float x, const float* uw, const float* uh, const float* 
     }
     for (int i = 0; i <= nb; ++i) D[i] = min_d + softplusf(udp[i]);  // ref :733
     {
-        float mx = -INFINITY;
-        for (int i = 0; i < nb; ++i) mx = std::max(mx, uh[i]);
-        float sum = 0.f;
-        for (int i = 0; i < nb; ++i) {
-            Hh[i] = std::exp(uh[i] - mx);
-            sum += Hh[i];
+        if (g_ggml_tables) {  // ref :735
+            for (int i = 0; i < nb; ++i) Hh[i] = uh[i];
+            softmax_ggml_table(Hh.data(), nb);
+        } else {
+            float mx = -INFINITY;
+            for (int i = 0; i < nb; ++i) mx = std::max(mx, uh[i]);
+            float sum = 0.f;
+            for (int i = 0; i < nb; ++i) {
+                Hh[i] = std::exp(uh[i] - mx);
+                sum += Hh[i];
+            }
+            for (int i = 0; i < nb; ++i) Hh[i] /= sum;
         }
-        for (int i = 0; i < nb; ++i) Hh[i] /= sum;
         for (int i = 0; i < nb; ++i) Hh[i] = min_h + (1 - min_h * nb) * Hh[i];  // ref :736; HF:234
         float cum = 0.f;
         chh[0] = 0.f;
@@ -1134,8 +1178,9 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
         const int arith_all = opts ? opts->arith : 0;
         // scope FLOW_VOCODER: the text encoder and the duration predictor run in exact fp32, the 16-bit operand rounding starts at the flow
         g_arith = (opts && opts->arith_scope == VO_SCOPE_ALL_CONVS) ? arith_all : 0;
+        g_ggml_tables = opts ? opts->ggml_tables : 0;
         struct ArithReset {
-            ~ArithReset() { g_arith = 0; }
+            ~ArithReset() { g_arith = 0, g_ggml_tables = 0; }
         } arith_reset;
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         auto run = std::make_unique<vo_run>();
@@ -1235,8 +1280,9 @@ VO_API int vo_log_durations(vo_model* mp, const int32_t* ids, int32_t T, const v
         const vo_model& m = *mp;
         if (T <= 0) throw std::runtime_error("empty input");
         g_arith = (opts && opts->arith_scope == VO_SCOPE_ALL_CONVS) ? opts->arith : 0;
+        g_ggml_tables = opts ? opts->ggml_tables : 0;
         struct ArithReset {
-            ~ArithReset() { g_arith = 0; }
+            ~ArithReset() { g_arith = 0, g_ggml_tables = 0; }
         } arith_reset;
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         Act enc, m_p, logs_p;

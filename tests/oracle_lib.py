@@ -25,7 +25,7 @@ TAPS = ["enc_out", "prior_mean", "prior_logvar", "log_duration", "durations", "n
 class Opts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("noise_kind", C.c_int32), ("noise_seed", C.c_uint64), ("noise_dur", C.c_void_p),
                 ("noise_prior", C.c_void_p), ("noise_prior_stride", C.c_int64), ("fixed_duration", C.c_int32),
-                ("threads", C.c_int32), ("arith", C.c_int32), ("arith_scope", C.c_int32)]
+                ("threads", C.c_int32), ("arith", C.c_int32), ("arith_scope", C.c_int32), ("ggml_tables", C.c_int32)]
 
 
 class Conv1dDesc(C.Structure):
@@ -140,13 +140,13 @@ class Model:
         return buf[:n].copy()
 
     def process_ids(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, noise_dur=None,
-                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS, arith=0, arith_scope=SCOPE_FLOW_VOCODER):
+                    noise_prior=None, fixed_duration=0, threads=0, taps=TAPS, arith=0, arith_scope=SCOPE_FLOW_VOCODER, ggml_tables=False):
         """Runs the full restated graph for ONE utterance. Returns {tap: np.ndarray} (flat [C*len] arrays reshaped
         to [C, len] where C is known)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         nd, npr = _f32(noise_dur), _f32(noise_prior)
         o = Opts(mode, noise_kind, noise_seed, _ptr(nd), _ptr(npr), 0 if npr is None else npr.shape[-1], fixed_duration,
-                 threads, arith, arith_scope)
+                 threads, arith, arith_scope, int(ggml_tables))
         r = lib().vo_process_ids(self._h, _ptr(ids), ids.size, C.byref(o))
         if not r:
             raise OracleError(lib().vo_last_error().decode())
@@ -162,11 +162,12 @@ class Model:
             lib().vo_run_free(r)
 
 
-def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, threads=0, arith=0, arith_scope=SCOPE_FLOW_VOCODER, noise_dur=None):
+def _log_durations(self, ids, mode=MODE_REFERENCE, noise_kind=NOISE_COUNTER, noise_seed=4321, threads=0, arith=0, arith_scope=SCOPE_FLOW_VOCODER, noise_dur=None,
+                   ggml_tables=False):
     """Stage one only (text encoder + duration predictor): (log_duration [T], durations [T]) of one utterance."""
     ids = np.ascontiguousarray(ids, dtype=np.int32)
     nd = _f32(noise_dur)
-    o = Opts(mode, noise_kind, noise_seed, _ptr(nd), None, 0, 0, threads, arith, arith_scope)
+    o = Opts(mode, noise_kind, noise_seed, _ptr(nd), None, 0, 0, threads, arith, arith_scope, int(ggml_tables))
     logw, dur = np.zeros(ids.size, np.float32), np.zeros(ids.size, np.float32)
     if lib().vo_log_durations(self._h, _ptr(ids), ids.size, C.byref(o), _ptr(logw), _ptr(dur)) != 0:
         raise OracleError(lib().vo_last_error().decode())

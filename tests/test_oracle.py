@@ -334,3 +334,19 @@ def test_oracle_is_clean_under_asan_and_ubsan():
                        timeout=600, env=env)
     assert r.returncode == 0 and "asan driver ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_emulated_ggml_tables_option(pkg, oracle):
+    """vo_opts.ggml_tables (Q8; INFERRED from upstream ggml, the reference's fork is absent): tanh-GELU through an fp16 table and the
+    soft-max exponential through an fp16 table with a double sum. Off by default (every fixture is in the default arithmetic); on, the
+    log-durations move by ~1e-3..1e-2 and stay finite; the table functions themselves against numpy's float16 rounding."""
+    m = oracle.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_FULL))
+    ids = pkg.synth_ids(2, 64)
+    for u in range(2):
+        a = m.log_durations(ids[u], noise_seed=4321 + u)
+        b = m.log_durations(ids[u], noise_seed=4321 + u, ggml_tables=True)
+        c = m.log_durations(ids[u], noise_seed=4321 + u)
+        np.testing.assert_array_equal(a[0], c[0])  # the switch does not stick
+        d = np.abs(a[0] - b[0]).max()
+        assert 1e-5 < d < 5e-2 and np.isfinite(b[0]).all()
+        assert (a[1] != b[1]).mean() < 0.05

@@ -11,6 +11,7 @@ ap.add_argument("--arith", default="f16")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--ids", type=int, default=128)
+ap.add_argument("--stage-one", action="store_true", help="also time stage one alone (frames_only calls)")
 a = ap.parse_args()
 torch.zeros(1, device="cuda")  # (torch's HIP runtime first, as in bench.py: the other order leaves torch without a device)
 pkg = load_package()
@@ -35,7 +36,13 @@ for rep in range(2):
         _, lengths, _ = m.wait(keep_pcm=False)
     _, lengths, _ = m.wait(keep_pcm=False)
     torch.cuda.synchronize(); res["pipelined"] = (time.perf_counter() - t) / a.steps * 1e3
+if a.stage_one:
+    for rep in range(2):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for k in range(a.steps):
+            m.process_batch(ids, noise_seed=4321, frames_only=True, keep_pcm=False)
+        torch.cuda.synchronize(); res["stage1"] = (time.perf_counter() - t) / a.steps * 1e3
 samples = int(lengths.sum())
 print(f"{a.arith} batch {a.batch} x {a.ids}: serial {res['serial']:.3f} ms ({samples / res['serial'] / 1e3:.1f} M/s)  pipelined {res['pipelined']:.3f} ms "
-      f"({samples / res['pipelined'] / 1e3:.1f} M/s)  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
+      f"({samples / res['pipelined'] / 1e3:.1f} M/s)" + (f"  stage one alone {res['stage1']:.3f} ms" if "stage1" in res else "") + "  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
 m.close()

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "vits_model_file_tokenize", "vits_pcm16_from_float", "vits_write_wav16", "vits_pcm16_from_float_device",
     "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
     "vits_model_set_arith_scope", "vits_model_get_arith_scope", "vits_model_submit_batch", "vits_model_wait", "vits_model_pending",
+    "vits_model_set_ggml_tables", "vits_model_get_ggml_tables",
 ]
 
 
@@ -138,6 +139,10 @@ def lib():
     L.vits_free_batch_result.argtypes = [C.POINTER(BatchResult)]
     L.vits_model_sync.restype = i32
     L.vits_model_sync.argtypes = [vp]
+    L.vits_model_set_ggml_tables.restype = i32
+    L.vits_model_set_ggml_tables.argtypes = [vp, i32]
+    L.vits_model_get_ggml_tables.restype = i32
+    L.vits_model_get_ggml_tables.argtypes = [vp]
     L.vits_model_submit_batch.restype = i32
     L.vits_model_submit_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(ProcessOpts)]
     L.vits_model_wait.restype = i32
@@ -328,6 +333,15 @@ class Model:
         (the literal Q7 arithmetic: every conv of the path) — include/vits.h VITS_ARITH_SCOPE_*"""
         if lib().vits_model_set_arith_scope(self._h, scope) != 0:
             raise VitsError(last_error())
+
+    def set_ggml_tables(self, on):
+        """EMULATED ggml fp16 lookup tables for ggml_gelu / ggml_soft_max (Q8; inferred from upstream ggml, the reference's fork is absent)"""
+        if lib().vits_model_set_ggml_tables(self._h, int(on)) != 0:
+            raise VitsError(last_error())
+
+    @property
+    def ggml_tables(self):
+        return bool(lib().vits_model_get_ggml_tables(self._h))
 
     @property
     def arith_scope(self):

@@ -135,7 +135,11 @@ __device__ __forceinline__ void zero_oob_columns(float* lbase, int ts, int len, 
     const int noob = nl + XWP - rs;
     if (noob <= 0) return;
     float* row = lbase + (lane & 31) * XWP;
+#ifdef VITS_ZERO_OOB_NOROT  // ablation: every row starts at outside-column 0 (the round-3 walk, 16-way conflicts)
+    int k = 0;
+#else
     int k = (lane & 31) % noob;  // (loop-invariant over the chunks of a block: computed once)
+#endif
     for (int i = lane >> 5; i < noob; i += 2) {
         int kk = k + i;
         kk = kk >= noob ? kk - noob : kk;

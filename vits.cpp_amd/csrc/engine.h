@@ -149,6 +149,10 @@ class Engine {
     // takes this flag around every entry point that touches the engine; a second thread gets "model busy" instead of a race.
     std::atomic<bool> busy{false};
     int set_arith(int arith, std::string& err);  // VITS_ARITH_*: packs the 16-bit weight fragments on first use
+    // EMULATED ggml fp16 lookup tables for ggml_gelu / ggml_soft_max (Q8; inferred from upstream ggml, the fork is absent): builds the two
+    // tables on the host as ggml_init does and uploads them on first use
+    int set_ggml_tables(bool on, std::string& err);
+    bool ggml_tables = false;
     int arith = VITS_ARITH_F32;
     // which convolutions a 16-bit arithmetic mode applies to (include/vits.h VITS_ARITH_SCOPE_*)
     int arith_scope = VITS_ARITH_SCOPE_FLOW_VOCODER;
@@ -232,6 +236,8 @@ class Engine {
     // arithmetic of the convolutions being queued right now: `arith`, or fp32 while stage one runs under
     // VITS_ARITH_SCOPE_FLOW_VOCODER (every conv wrapper and fused kernel reads this one, never `arith` itself)
     int arith_now_ = VITS_ARITH_F32;
+    GgmlTables ggml_tabs_;              // what the stage-one kernels receive: null pointers unless ggml_tables
+    uint16_t* ggml_tab_dev_ = nullptr;  // [2][65536]: gelu, exp
     struct HStage {  // pinned staging of the per-call host header (ids, lengths, stage tables)
         int* p = nullptr;
         size_t cap = 0;

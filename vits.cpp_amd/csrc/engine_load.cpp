@@ -35,6 +35,34 @@ Engine::~Engine() {
     if (stream) hipStreamDestroy(stream);
 }
 
+// ggml_init builds table_gelu_f16 / table_exp_f16 on the host by evaluating ggml_gelu_f32 / expf on every fp16 value (upstream ggml.c of the
+// reference's era; GGML_GELU_FP16 is on by default) — the same here, with this host's C library, then the 2 x 128 KB go to the device.
+int Engine::set_ggml_tables(bool on, std::string& err) {
+    if (on && !ggml_tab_dev_) {
+        std::vector<uint16_t> tab(2 * 65536);
+        for (uint32_t i = 0; i < 65536; ++i) {
+            const float x = f16_to_f32((uint16_t)i);
+            tab[i] = f32_to_f16(0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x))));
+            tab[65536 + i] = f32_to_f16(expf(x));
+        }
+        uint16_t* d = nullptr;
+        if (hipMalloc((void**)&d, tab.size() * sizeof(uint16_t)) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+            if (d) hipFree(d);
+            err = "could not upload the ggml lookup tables";
+            return -1;
+        }
+        ggml_tab_dev_ = d;
+        owned_.push_back(d);
+    }
+    ggml_tables = on;
+    ggml_tabs_ = GgmlTables();
+    if (on) {
+        ggml_tabs_.gelu = ggml_tab_dev_;
+        ggml_tabs_.exp = ggml_tab_dev_ + 65536;
+    }
+    return 0;
+}
+
 float* Engine::upload(const std::vector<float>& v) {
     if (dry_run_) return reinterpret_cast<float*>(16);  // validation only (vits_model_file_validate): nothing is allocated
     float* d = nullptr;

@@ -20,7 +20,7 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
             TensorRef dst = i == n - 1 ? x : (src.p == y.p ? p : y);
             prof.begin("dds_layer_fused", 2.0 * H * H * (double)sum_t, 8.0 * H * (double)sum_t + (double)(arith_now_ == VITS_ARITH_F32 ? d.pw[i].bytes : d.pw[i].bytes16), stream);
             hipError_t e = launch_dds_layer(src, dst, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], d.pw[i], d.n2_g[i], d.n2_b[i], lens, batch, H, tmax, hp.dp_k, dil, 1e-5f,
-                                            arith_now_, stream);
+                                            arith_now_, stream, ggml_tabs_);
             prof.end(stream);
             if (e != hipSuccess) return e;
             src = dst;
@@ -29,7 +29,7 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
         return hipSuccess;
     }
     for (int i = 0; i < hp.dds_layers; ++i) {
-        KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream, arith_now_));
+        KPROF("dds_depthwise_ln_gelu", launch_dds_depthwise(x, none, d.dw_w[i], d.dw_b[i], d.n1_g[i], d.n1_b[i], y, lens, batch, H, tmax, hp.dp_k, dil, 1e-5f, stream, arith_now_, ggml_tabs_));
         ConvCall c;
         c.x = y;
         c.y = p;
@@ -40,7 +40,7 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
         c.sum_in = c.sum_out = sum_t;
         hipError_t e = conv("conv1x1_dp", d.pw[i], c);
         if (e != hipSuccess) return e;
-        KPROF("ln_gelu_residual", launch_add_layer_norm(p, none, d.n2_g[i], d.n2_b[i], none, lens, batch, H, tmax, 1e-5f, 1, x, stream));
+        KPROF("ln_gelu_residual", launch_add_layer_norm(p, none, d.n2_g[i], d.n2_b[i], none, lens, batch, H, tmax, 1e-5f, 1, x, stream, ggml_tabs_));
         dil *= hp.dp_k;
     }
     return hipSuccess;
@@ -178,7 +178,7 @@ int Engine::run_text_encoder(Call& c) {
         const EncoderLayerW& L = enc_[l];
         HIP_OK(conv("enc_qkv_gemm", L.qkv, mk(x, qkv, Tmax)));
         prof.begin("rel_attention", 0, 0, stream);
-        HIP_OK(launch_rel_attention(sub(qkv, 0), sub(qkv, H), sub(qkv, 2 * H), L.rel_k, L.rel_v, att, dl, B, heads, hd, Tmax, hp.window, q_scale, stream));
+        HIP_OK(launch_rel_attention(sub(qkv, 0), sub(qkv, H), sub(qkv, 2 * H), L.rel_k, L.rel_v, att, dl, B, heads, hd, Tmax, hp.window, q_scale, stream, ggml_tabs_));
         prof.end(stream);
         {
             ConvCall c = mk(att, tmp, Tmax);
@@ -287,7 +287,7 @@ int Engine::run_duration_predictor(Call& c) {
             HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax, sum_t));
             HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
             prof.begin("dp_spline", 0, 0, stream);
-            HIP_OK(launch_spline(u, z, 1 - c_first, dl, B, Tmax, hp.dp_bins, hp.dp_tail, inv_sqrt, md, stream));
+            HIP_OK(launch_spline(u, z, 1 - c_first, dl, B, Tmax, hp.dp_bins, hp.dp_tail, inv_sqrt, md, stream, ggml_tabs_));
             prof.end(stream);
         }
     }

@@ -240,20 +240,30 @@ hipError_t launch_conv_post16(Ref16 x, const float* w, int cin, int k, TensorRef
 hipError_t launch_embed(const int* ids, int id_stride, const int* lens, const float* table, int hidden, float scale, TensorRef x, int batch, int tmax,
                         hipStream_t s);
 hipError_t launch_scale_rows(TensorRef x, int channels, float scale, int batch, int tmax, hipStream_t s);
+// EMULATED ggml lookup tables (INFERRED from upstream ggerganov/ggml of the reference's era, the maxilevi/ggml fork is
+// absent): device copies of the two 65536-entry fp16 tables ggml builds at init — gelu[i] = fp16(tanh-GELU(fp16 value i)), exp[i] =
+// fp16(expf(fp16 value i)) — built on the host with the C library (Engine::set_ggml_tables). Kernels that receive a non-null pointer route
+// ggml_gelu (vits.cpp:673,687) / the exponential of ggml_soft_max (vits.cpp:329,719,735) through it; null = erf-GELU / fp32 soft-max.
+struct GgmlTables {
+    const uint16_t* gelu = nullptr;
+    const uint16_t* exp = nullptr;
+};
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
-                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s);
+                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s, GgmlTables tabs = GgmlTables());
 hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
-                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s);
+                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s, GgmlTables tabs = GgmlTables());
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
-                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith = 0);
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith = 0,
+                                GgmlTables tabs = GgmlTables());
 // one DDS layer (depthwise + LN + gelu + 1x1 conv + LN + gelu + residual) as one kernel; y must not alias x
 bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int arith);
 hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
-                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s);
+                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s,
+                            GgmlTables tabs = GgmlTables());
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch,
                                   int channels, int tmax, hipStream_t s, int arith = 0);
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode,
-                         hipStream_t s);
+                         hipStream_t s, GgmlTables tabs = GgmlTables());
 hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
                          hipStream_t s);
 hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, const int* seed_off, float scale, hipStream_t s);

@@ -56,10 +56,48 @@ constexpr int ATT_Q = 16;
 // latencies that only more waves hide — and 256 on large ones (16-wave blocks pack worse: 73 -> 107 us per launch at batch 64).
 // Both give the same bits: scores and outputs are per-element sums in a fixed order, and the softmax always runs on 16 lanes per query.
 
+// ---------------------------------------------------------------------------------------------------------
+// EMULATED ggml lookup tables (Q8; kernels.h GgmlTables): when a table pointer is given, GELU / the soft-max exponential go through the
+// 65536-entry fp16 table indexed by the fp16 bits of the argument, as upstream ggml's ggml_vec_gelu_f32 / ggml_compute_forward_soft_max_f32
+// do (the tables are built on the HOST with the C library's tanhf / expf, like ggml_init). Null pointers = the default arithmetic.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ggml_table_lookup(const uint16_t* tab, float x) {
+    const uint16_t i = __builtin_bit_cast(uint16_t, (_Float16)x);  // GGML_FP32_TO_FP16: round to nearest even
+    return (float)__builtin_bit_cast(_Float16, tab[i]);
+}
+// soft-max of one score row shared by 16 lanes (lane l16 owns columns l16, l16 + 16, ...), in place. exp_tab == nullptr: expf, fp32 sum,
+// multiply by 1 / sum. exp_tab: ggml's table, the sum in double (terms are fp16 values <= 1: exact in any order), multiply by (float)(1 / sum).
+__device__ __forceinline__ void softmax_row16(float* row, int len, int l16, const uint16_t* exp_tab) {
+    float mx = -INFINITY;
+    for (int j = l16; j < len; j += 16) mx = fmaxf(mx, row[j]);
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    if (exp_tab) {
+        double sum = 0.0;
+        for (int j = l16; j < len; j += 16) {
+            const float e = ggml_table_lookup(exp_tab, row[j] - mx);
+            row[j] = e;
+            sum += (double)e;
+        }
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = (float)(1.0 / sum);
+        for (int j = l16; j < len; j += 16) row[j] *= inv;
+        return;
+    }
+    float sum = 0.f;
+    for (int j = l16; j < len; j += 16) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+    const float inv = 1.0f / sum;
+    for (int j = l16; j < len; j += 16) row[j] *= inv;
+}
+
 template <int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                             int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
-                                                            int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift) {
+                                                            int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int vshift, const uint16_t* exp_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ATT_PASSES = 512 / ATT_THREADS < 1 ? 1 : 512 / ATT_THREADS;  // (d, 4-query group) items per thread: head_dim <= 128 (256 threads) / 256
     const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_Q;
@@ -135,18 +173,7 @@ __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float*
     // softmax per query: 16 lanes per query (the first 256 threads)
     if (tid < 256) {
         const int qi = tid >> 4, l16 = tid & 15;
-        float mx = -INFINITY;
-        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        float sum = 0.f;
-        for (int j = l16; j < len; j += 16) {
-            const float e = expf(sc[qi * lp + j] - mx);
-            sc[qi * lp + j] = e;
-            sum += e;
-        }
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.0f / sum;
-        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
+        softmax_row16(sc + qi * lp, len, l16, exp_tab);
     }
     __syncthreads();
     // o[qi][d] = sum_j p[qi][j] v[d][j] + windowed relative-value term; thread -> (d, 4-query group), up to ATT_PASSES items per thread.
@@ -284,7 +311,7 @@ __device__ unsigned long long vits_att_phase[8 * 65536];
 template <int NW, int MAXS, bool SHORT>
 __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                                      int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
-                                                                     int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int v16) {
+                                                                     int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int v16, const uint16_t* exp_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NT = 64 * NW;
     // XCD-aware order: the dispatcher deals workgroups to the 8 XCDs round-robin by linear id and every XCD has its own L2. All query
@@ -418,18 +445,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
     // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole groups) ----
     if (tid < 16 * ATT_Q) {
         const int qi = tid >> 4, l16 = tid & 15;
-        float mx = -INFINITY;
-        for (int j = l16; j < len; j += 16) mx = fmaxf(mx, sc[qi * lp + j]);
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        float sum = 0.f;
-        for (int j = l16; j < len; j += 16) {
-            const float e = expf(sc[qi * lp + j] - mx);
-            sc[qi * lp + j] = e;
-            sum += e;
-        }
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.0f / sum;
-        for (int j = l16; j < len; j += 16) sc[qi * lp + j] *= inv;
+        softmax_row16(sc + qi * lp, len, l16, exp_tab);
         for (int j = len + l16; j < lp; j += 16) sc[qi * lp + j] = 0.f;
     }
     __syncthreads();
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
 }
 
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
-                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s) {
+                                int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s, GgmlTables tabs) {
     static const bool valu_only = getenv("VITS_ATT_VALU") != nullptr;
     // matrix-core version. The number of waves (= how the key tiles and the d tiles are dealt out) does not change a single sum, so it may
     // depend on the launch: four waves while two or more blocks fit the LDS of a CU (up to ~1200 tokens: 1024 ids 0.178 ms against 0.222
@@ -539,7 +555,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             if (e != hipSuccess) return e;                                                                                                       \
         }                                                                                                                                        \
         VITS_KLAUNCH((rel_attention_mfma_kernel<NW, MS, SH>), gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
-                           out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0);                                            \
+                           out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0, tabs.exp);                                            \
     } while (0)
             static const int short_max = getenv("VITS_ATT_SHORT") ? atoi(getenv("VITS_ATT_SHORT")) : 512;  // tokens; 0 disables the short variant
             // (the long variants keep their arrays at 32 k-steps: sized for 24 the four-wave kernel measured 0.22 against 0.18 ms at 1024 tokens)
@@ -567,7 +583,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             if (e != hipSuccess) return e;                                                                                                  \
         }                                                                                                                                   \
         VITS_KLAUNCH(rel_attention_kernel<T>, grid, dim3(T), lds, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, out.bs, \
-                           out.cs, lens, head_dim, tmax, window, q_scale, vshift);                                                         \
+                           out.cs, lens, head_dim, tmax, window, q_scale, vshift, tabs.exp);                                                         \
     } while (0)
     if (small_grid) VITS_ATT_LAUNCH(1024);
     else VITS_ATT_LAUNCH(256);
@@ -582,6 +598,8 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
 // Block = 64 time steps x all channels; the tile is held in LDS so x is read from HBM once.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// vits.cpp:673,687 ggml_gelu: erf-GELU (HF) by default; with a table, ggml's tanh-GELU through its fp16 lookup table (Q8, emulated)
+__device__ __forceinline__ float gelu_op(float x, const uint16_t* gelu_tab) { return gelu_tab ? ggml_table_lookup(gelu_tab, x) : gelu_erf(x); }
 
 // channel groups per block of the two LayerNorm kernels: 16 x 64 threads, every thread walks channels/16 rows. (4 groups
 // made each thread chain 48 dependent loads: 26-58 us per launch at batch 1, where these launches have 2 blocks.) The
@@ -590,7 +608,7 @@ constexpr int LN_GROUPS = 16;
 
 __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
                                                              const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs, float* addto,
-                                                             int64_t a_bs, int a_cs, const int* lens, int channels, int tmax, float eps, int post_gelu) {
+                                                             int64_t a_bs, int a_cs, const int* lens, int channels, int tmax, float eps, int post_gelu, const uint16_t* gelu_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* tile = sm;                    // [channels][64]
     float* red = sm + channels * 64;     // [LN_GROUPS][64] x2
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const fl
     if (!ok) return;
     for (int c = g; c < channels; c += LN_GROUPS) {
         float v = (tile[c * 64 + tl] - mean) * inv * gamma[c] + beta[c];
-        if (post_gelu) v = gelu_erf(v);
+        if (post_gelu) v = gelu_op(v, gelu_tab);
         if (addto) {
             float* a = addto + (int64_t)b * a_bs + (int64_t)c * a_cs + t;
             *a = *a + v;
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const fl
 }
 
 hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
-                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s) {
+                                 int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s, GgmlTables tabs) {
     const size_t lds = sizeof(float) * ((size_t)channels * 64 + 2 * 64 * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
@@ -666,7 +684,7 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
     }
     dim3 grid((tmax + 63) / 64, batch);
     VITS_KLAUNCH(add_layer_norm_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
-                       add_to.cs, lens, channels, tmax, eps, post_gelu);
+                       add_to.cs, lens, channels, tmax, eps, post_gelu, tabs.gelu);
     return hipGetLastError();
 }
 
@@ -687,7 +705,7 @@ __device__ __forceinline__ float round_arith(float v, int arith) {
 
 __global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x, int64_t x_bs, int x_cs, const float* g, int64_t g_bs, int g_cs, const float* w,
                                                             const float* bias, const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs,
-                                                            const int* lens, int channels, int tmax, int k, int dil, float eps, int arith) {
+                                                            const int* lens, int channels, int tmax, int k, int dil, float eps, int arith, const uint16_t* gelu_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int pad = (k * dil - dil) / 2;  // vits.cpp:660
     const int xw = 64 + 2 * pad;
@@ -746,11 +764,11 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void dds_depthwise_kernel(float* x,
     const float inv = 1.0f / sqrtf(var + eps);
     const int t = t0 + tl;
     if (t >= len) return;
-    for (int c = gq; c < channels; c += LN_GROUPS) y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = gelu_erf((ht[c * 64 + tl] - mean) * inv * gamma[c] + beta[c]);
+    for (int c = gq; c < channels; c += LN_GROUPS) y[(int64_t)b * y_bs + (int64_t)c * y_cs + t] = gelu_op((ht[c * 64 + tl] - mean) * inv * gamma[c] + beta[c], gelu_tab);
 }
 
 hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const float* bias, const float* gamma, const float* beta, TensorRef y,
-                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith) {
+                                const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, hipStream_t s, int arith, GgmlTables tabs) {
     const int pad = (k * dil - dil) / 2;
     const size_t lds = sizeof(float) * ((size_t)channels * (64 + 2 * pad) + (size_t)channels * 64 + 2 * 64 * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -760,7 +778,7 @@ hipError_t launch_dds_depthwise(TensorRef x, TensorRef g, const float* w, const 
     }
     dim3 grid((tmax + 63) / 64, batch);
     VITS_KLAUNCH(dds_depthwise_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, g.p, g.bs, g.cs, w, bias, gamma, beta, y.p, y.bs, y.cs, lens, channels, tmax,
-                       k, dil, eps, arith);
+                       k, dil, eps, arith, tabs.gelu);
     return hipGetLastError();
 }
 
@@ -793,6 +811,7 @@ struct DdsLayerParams {
     const int* lens;
     int channels, tmax, k, dil, nchunks;
     float eps;
+    const uint16_t* gelu_tab;  // emulated ggml GELU table (Q8) or nullptr
 #ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/dds_micro.hip): per-block phase timestamps, 100 MHz clock
     unsigned long long* dbg;
 #endif
@@ -965,7 +984,7 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
             for (int u = 0; u < UB; ++u) {
                 const int c = c0 + u * LN_GROUPS;
                 if (c >= H) continue;
-                float v = gelu_erf((hv[u] - mean) * inv * gg[u] + bb[u]);
+                float v = gelu_op((hv[u] - mean) * inv * gg[u] + bb[u], p.gelu_tab);
                 if constexpr (ARITH == 0) {
                     ht[c * NT + tl] = v;
                 } else {
@@ -1091,7 +1110,7 @@ __global__ __launch_bounds__(32 * LN_GROUPS) void dds_layer_kernel(DdsLayerParam
                 const int c = c0 + u * LN_GROUPS;
                 if (c >= H) continue;
                 float v = (hv[u] - mean) * inv * gg[u] + bb[u];
-                v = gelu_erf(v);
+                v = gelu_op(v, p.gelu_tab);
                 asm volatile("" : "+v"(v));  // (the three-launch path adds in a separate statement behind a branch: no fma of gelu's last product with this add)
                 yb[(int64_t)c * p.y_cs] = xr[u] + v;
             }
@@ -1117,7 +1136,7 @@ bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int
 }
 
 hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
-                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s) {
+                            const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s, GgmlTables tabs) {
     if (!dds_layer_supported(pw, channels, k, dil, arith) || x.p == y.p) return hipErrorInvalidValue;
     DdsLayerParams p;
     p.x = x.p;
@@ -1142,6 +1161,7 @@ hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const f
     p.dil = dil;
     p.nchunks = pw.nchunks;
     p.eps = eps;
+    p.gelu_tab = tabs.gelu;
 #ifdef VITS_PHASE_TIMING
     p.dbg = g_dds_dbg;
 #endif
@@ -1204,7 +1224,7 @@ hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int t
 // ---------------------------------------------------------------------------------------------------------
 // Inverse rational-quadratic spline on latent row zc (unconstrained_rational_quadratic_spline, vits.cpp:804-852 + :695-802;
 // HF modeling_vits.py:139-163,211-302). u = conv_proj output [3*bins-1][T]. One block per utterance, one thread per token (tokens
-// beyond 1024 loop).
+// beyond 512 loop).
 //   VITS_MODE_HF: identity outside [-B, B], the spline inside (HF:143-151).
 //   VITS_MODE_REFERENCE: Q3 (:720), on the LAST token Q4 (ggml-util.h:235-236,252-253), and the masked get / set pair of :832-849
 //   LITERALLY (Q6): tensor_masked_get keeps the shape (custom-ops.h:746-749) while tensor_masked_set consumes its values sequentially
@@ -1218,22 +1238,35 @@ constexpr int MAX_BINS = 16;
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : (float)log(1.0 + exp((double)x)); }  // custom-ops.h:872-879
 
 // rational_quadratic_spline (vits.cpp:695-802) on one token's row; masked: the row's parameters were zeroed by :837-840
-__device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, int nb, float B, float inv_sqrt, int mode, bool q4, bool masked) {
+// ggml_soft_max over the bins (vits.cpp:719,735), in place: fp32 by default, ggml's fp16 exp table + double sum when exp_tab is given (Q8)
+__device__ __forceinline__ void spline_softmax(float* v, int nb, const uint16_t* exp_tab) {
+    float mx = -INFINITY;
+    for (int i = 0; i < nb; ++i) mx = fmaxf(mx, v[i]);
+    if (exp_tab) {
+        double sum = 0.0;
+        for (int i = 0; i < nb; ++i) {
+            v[i] = ggml_table_lookup(exp_tab, v[i] - mx);
+            sum += (double)v[i];
+        }
+        const float inv = (float)(1.0 / sum);
+        for (int i = 0; i < nb; ++i) v[i] *= inv;
+        return;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < nb; ++i) {
+        v[i] = expf(v[i] - mx);
+        sum += v[i];
+    }
+    for (int i = 0; i < nb; ++i) v[i] /= sum;
+}
+
+__device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, int nb, float B, float inv_sqrt, int mode, bool q4, bool masked, const uint16_t* exp_tab) {
     const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
     float W[MAX_BINS], H[MAX_BINS], cw[MAX_BINS + 1], ch[MAX_BINS + 1];
     // widths
     {
-        float mx = -INFINITY;
-        for (int i = 0; i < nb; ++i) {
-            W[i] = masked ? 0.f : ub[(int64_t)i * u_cs] * inv_sqrt;
-            mx = fmaxf(mx, W[i]);
-        }
-        float sum = 0.f;
-        for (int i = 0; i < nb; ++i) {
-            W[i] = expf(W[i] - mx);
-            sum += W[i];
-        }
-        for (int i = 0; i < nb; ++i) W[i] /= sum;
+        for (int i = 0; i < nb; ++i) W[i] = masked ? 0.f : ub[(int64_t)i * u_cs] * inv_sqrt;
+        spline_softmax(W, nb, exp_tab);
         if (mode == VITS_MODE_REFERENCE) {
             const float sc = min_w + (1 - min_w * nb);  // Q3
             for (int i = 0; i < nb; ++i) W[i] = W[i] * sc;
@@ -1252,17 +1285,8 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
         for (int i = 0; i < nb; ++i) W[i] = cw[i + 1] - cw[i];
     }
     {
-        float mx = -INFINITY;
-        for (int i = 0; i < nb; ++i) {
-            H[i] = masked ? 0.f : ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
-            mx = fmaxf(mx, H[i]);
-        }
-        float sum = 0.f;
-        for (int i = 0; i < nb; ++i) {
-            H[i] = expf(H[i] - mx);
-            sum += H[i];
-        }
-        for (int i = 0; i < nb; ++i) H[i] /= sum;
+        for (int i = 0; i < nb; ++i) H[i] = masked ? 0.f : ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
+        spline_softmax(H, nb, exp_tab);
         for (int i = 0; i < nb; ++i) H[i] = min_h + (1 - min_h * nb) * H[i];
         float cum = 0.f;
         ch[0] = 0.f;
@@ -1312,8 +1336,8 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
     return root * in_w + in_cw;
 }
 
-__global__ __launch_bounds__(1024) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
-                                                      int nb, float B, float inv_sqrt, int mode) {
+__global__ __launch_bounds__(512) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
+                                                      int nb, float B, float inv_sqrt, int mode, const uint16_t* exp_tab) {
     extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance
     const int b = blockIdx.x;
     const int len = lens ? lens[b] : tmax;
@@ -1329,7 +1353,7 @@ __global__ __launch_bounds__(1024) void spline_kernel(const float* u, int64_t u_
         const bool inside = x >= -B && x <= B;
         const float* ub = u + (int64_t)b * u_bs + t;
         float r = x;  // HF: identity outside the interval (HF:143-151)
-        if (inside || ref) r = spline_row(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside);
+        if (inside || ref) r = spline_row(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside, exp_tab);
         if (ref) {
             s_val[t] = inside ? x : 0.f;  // tensor_masked_get(inputs, inside_interval_mask): the shape is kept
             s_res[t] = r;
@@ -1353,12 +1377,13 @@ __global__ __launch_bounds__(1024) void spline_kernel(const float* u, int64_t u_
     }
 }
 
-hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode, hipStream_t s) {
+hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode, hipStream_t s,
+                         GgmlTables tabs) {
     if (bins > MAX_BINS || tmax > 4096) return hipErrorInvalidValue;
     const int tpad = (tmax + 63) & ~63;
-    const int threads = tpad < 1024 ? tpad : 1024;
+    const int threads = tpad < 512 ? tpad : 512;
     VITS_KLAUNCH(spline_kernel, dim3(batch), dim3(threads), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt,
-                 mode);
+                 mode, tabs.exp);
     return hipGetLastError();
 }
 
