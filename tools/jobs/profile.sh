@@ -15,7 +15,12 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLE
   name=$(echo $pass | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $pass -d $O/pmc_$name --output-format csv -- python3 $BENCH --steps 2 --warmup 1 > /dev/null 2> $O/pmc_$name.err
 done
+# the library-default schedule (no per-kernel events: three streams, separate launches) for bench.py's roofline_default_schedule block
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats_default --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-prof --no-sub-results --no-extra-passes $* --steps 5 --warmup 2 > $O/bench_default_under_rocprof.json 2> $O/stats_default.err
 cd $GRAFT_REPO_ROOT
+cp $(find $O/stats_default -name "*kernel_stats.csv" | head -1) $O/default_kernel_stats.csv 2>/dev/null
+python3 tools/default_schedule.py $O/default_schedule.json $O/default_kernel_stats.csv --workload "$WTAG" --steps-in-trace 7
+rm -rf $O/stats_default
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 SPS=$(python3 -c "import json; print(json.load(open('$O/bench_under_rocprof.json'))['config']['samples_per_step'])" 2>/dev/null || echo 0)
 python3 tools/pmc_traffic.py $O/pmc_traffic.json --workload "$WTAG" --steps-in-trace 3 --samples-per-step $SPS --fetch-cal 2.0 --write-cal 1.0 "$O/pmc_FETCH_SIZE/**/*counter_collection.csv" "$O/pmc_WRITE_SIZE/**/*counter_collection.csv"
