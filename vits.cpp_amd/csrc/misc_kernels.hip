@@ -65,6 +65,12 @@ __device__ __forceinline__ float ggml_table_lookup(const uint16_t* tab, float x)
     const uint16_t i = __builtin_bit_cast(uint16_t, (_Float16)x);  // GGML_FP32_TO_FP16: round to nearest even
     return (float)__builtin_bit_cast(_Float16, tab[i]);
 }
+// Which of the block's 16 queries the 16-lane group t16 = tid / 16 normalises. ds_read_b32 / ds_write_b32 are served in groups of 32 lanes
+// on banks (address / 4) mod 32, and the score rows are lp = 4 (mod 64) floats apart: two ADJACENT queries in one group of 32 lanes put
+// their 16 columns on overlapping bank ranges (2-way conflicts on three passes over every row: the LDS_BANK_CONFLICT / LDS_IDX_ACTIVE = 0.37
+// of the round-3 PMC pass). Queries q and q + 4 sit 16 banks apart: pair those. Each query's own 16-lane sums are untouched (same bits).
+__device__ __forceinline__ int softmax_query_of(int t16) { return ((t16 & 1) << 2) | ((t16 >> 1) & 3) | (t16 & 8); }
+
 // soft-max of one score row shared by 16 lanes (lane l16 owns columns l16, l16 + 16, ...), in place. exp_tab == nullptr: expf, fp32 sum,
 // multiply by 1 / sum. exp_tab: ggml's table, the sum in double (terms are fp16 values <= 1: exact in any order), multiply by (float)(1 / sum).
 __device__ __forceinline__ void softmax_row16(float* row, int len, int l16, const uint16_t* exp_tab) {
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(ATT_THREADS) void rel_attention_kernel(const float*
     __syncthreads();
     // softmax per query: 16 lanes per query (the first 256 threads)
     if (tid < 256) {
-        const int qi = tid >> 4, l16 = tid & 15;
+        const int qi = softmax_query_of(tid >> 4), l16 = tid & 15;
         softmax_row16(sc + qi * lp, len, l16, exp_tab);
     }
     __syncthreads();
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
     ATT_STAMP(2);
     // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole groups) ----
     if (tid < 16 * ATT_Q) {
-        const int qi = tid >> 4, l16 = tid & 15;
+        const int qi = softmax_query_of(tid >> 4), l16 = tid & 15;
         softmax_row16(sc + qi * lp, len, l16, exp_tab);
         for (int j = len + l16; j < lp; j += 16) sc[qi * lp + j] = 0.f;
     }
