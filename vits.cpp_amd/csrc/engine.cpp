@@ -128,12 +128,6 @@ int Engine::submit_batch(const int32_t* ids, const int32_t* id_lens, int B, int 
         HIP_OK(hipEventCreateWithFlags(&p.s1_done, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     }
-    if (!front_ && !knobs.no_pipeline) {
-        int least = 0, greatest = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // high priority: the small stage-one launches take the next free wave slots ahead of the vocoder's queued blocks
-        HIP_OK(hipStreamCreateWithPriority(&front_, hipStreamNonBlocking, knobs.front_prio ? greatest : least));
-    }
     a1_slot_ = (int)(submit_seq_ & 1);
     const int rc = process_impl(ids, id_lens, B, id_stride, o, nullptr, err, &p);
     a1_slot_ = 0;
