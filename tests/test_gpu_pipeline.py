@@ -167,3 +167,37 @@ def test_a_busy_handle_refuses_a_second_caller(pkg, full_model):
     assert done and done[0] > 0
     assert errs and "model busy" in errs[0]
     m.process_batch(ids, id_lengths=lens)  # released again
+
+
+def test_pipeline_survives_failed_submits_and_an_early_close(pkg, full_bytes):
+    """A submit that fails — before anything is queued (bad id) or in the middle (out_device too narrow: stage one and the flow are
+    already queued) — leaves the pipeline as it was: the batch in flight is delivered, bit-identical; a handle closed with batches in
+    flight drains them first."""
+    ids = pkg.synth_ids(3, 40)
+    with pkg.Model(full_bytes) as m:
+        want = m.process_batch(ids, noise_seed=9)
+        m.submit_batch(ids, noise_seed=9)
+        bad = ids.copy()
+        bad[1, 5] = 10 ** 6
+        with pytest.raises(pkg.VitsError, match="token id out of range"):
+            m.submit_batch(bad, noise_seed=9)
+        assert m.pending == 1
+        # a device buffer that is too narrow is only noticed once the frame counts are known (no torch here: any non-null address will do,
+        # the call fails before a kernel could write to it)
+        with pytest.raises(pkg.VitsError, match="out_device_stride"):
+            m.submit_batch(ids, noise_seed=9, out_device=0x1000, out_device_stride=16, skip_host_copy=True)
+        assert m.pending == 1
+        got = m.wait()
+        for a, b in zip(want[0], got[0]):
+            assert np.array_equal(a, b)
+        m.submit_batch(ids, noise_seed=10)
+        m.submit_batch(ids, noise_seed=11)
+        again = [m.wait(), m.wait()]
+        assert np.array_equal(again[0][1], m.process_batch(ids, noise_seed=10)[1])
+        m.submit_batch(ids, noise_seed=12)
+        m.submit_batch(ids, noise_seed=13)
+        # leaving the `with` block closes the handle with two batches in flight
+    with pkg.Model(full_bytes) as m2:
+        p2 = m2.process_batch(ids, noise_seed=9)
+        for a, b in zip(want[0], p2[0]):
+            assert np.array_equal(a, b)
