@@ -45,6 +45,39 @@ int main(int argc, char** argv) {
                 for (float v : w) sum += v;
                 vo_run_free(r);
             }
+    // Q6 (latents outside the spline interval: the masked get / set walk of vits.cpp:832-849) and the emulated ggml tables (Q8), stage one
+    // only, explicit noise large enough to leave [-5, 5] — first / last token outside included
+    {
+        float nd[2 * 23];
+        for (int i = 0; i < 2 * 23; ++i) nd[i] = ((i * 37) % 11 - 5) * 1.9f;
+        nd[0] = nd[23] = 9.f;
+        nd[22] = nd[45] = -9.f;
+        for (int mode = 0; mode < 2; ++mode)
+            for (int tables = 0; tables < 2; ++tables)
+                for (int n : {1, 2, 23}) {
+                    vo_opts o{};
+                    o.mode = mode;
+                    o.noise_kind = VO_NOISE_EXPLICIT;
+                    o.noise_dur = nd;
+                    o.threads = 2;
+                    o.ggml_tables = tables;
+                    float logw[23], dur[23];
+                    float nd_n[2 * 23];
+                    for (int c = 0; c < 2; ++c)
+                        for (int t = 0; t < n; ++t) nd_n[c * n + t] = nd[c * 23 + t];
+                    o.noise_dur = nd_n;
+                    if (vo_log_durations(m, ids, n, &o, logw, dur) != 0) {
+                        std::fprintf(stderr, "log_durations failed: %s\n", vo_last_error());
+                        return 5;
+                    }
+                    for (int t = 0; t < n; ++t) sum += logw[t] + dur[t];
+                    sum += (double)vo_outside_latents();
+                }
+        const float tt[6] = {1, 2, 3, 4, 5, 6}, mk[6] = {0, 1, 0, 1, 1, 0};
+        float o6[6];
+        vo_masked_get(tt, mk, 6, o6);
+        sum += o6[1];
+    }
     // reference noise stream + a truncated file + helper ops with the -1 wrap
     vo_reference_noise_seed(1);
     float nz[8];
