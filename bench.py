@@ -293,6 +293,10 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     out["c2_f32"] = entry(e, s_, fr, n, 128, "f32", 1)
     out["c2_f32"]["ms_per_utterance"] = 1000.0 * e / n
     out["c2_f32"]["schedule"] = "serial calls (latency figure: one utterance in, its PCM out)"
+    b2, _ = buf_for(1, 128, 2)
+    e, s_, fr = run([(base_model, ids1, noise_base, b2, cap)], n, warmup=1, pipelined=True)
+    out["c2_f32"]["pipelined_throughput"] = {"value": s_ / e, "ms_per_utterance": 1000.0 * e / n,
+                                             "note": "batch-1 utterances through the single-handle pipeline (two in flight): throughput, not latency"}
     # c3 in fp32 (pipelined beside the headline's serial figure) and in the 16-bit arithmetic modes (default scope: stage one exact,
     # durations identical to the fp32 run's)
     ids64 = pkg.synth_ids(64, 128)
