@@ -1230,7 +1230,7 @@ hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int t
 // ---------------------------------------------------------------------------------------------------------
 // Inverse rational-quadratic spline on latent row zc (unconstrained_rational_quadratic_spline, vits.cpp:804-852 + :695-802;
 // HF modeling_vits.py:139-163,211-302). u = conv_proj output [3*bins-1][T]. One block per utterance, one thread per token (tokens
-// beyond 512 loop).
+// beyond 1024 loop).
 //   VITS_MODE_HF: identity outside [-B, B], the spline inside (HF:143-151).
 //   VITS_MODE_REFERENCE: Q3 (:720), on the LAST token Q4 (ggml-util.h:235-236,252-253), and the masked get / set pair of :832-849
 //   LITERALLY (Q6): tensor_masked_get keeps the shape (custom-ops.h:746-749) while tensor_masked_set consumes its values sequentially
@@ -1342,7 +1342,8 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
     return root * in_w + in_cw;
 }
 
-__global__ __launch_bounds__(512) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
+template <int NT>
+__global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
                                                       int nb, float B, float inv_sqrt, int mode, const uint16_t* exp_tab) {
     extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance
     const int b = blockIdx.x;
@@ -1387,9 +1388,14 @@ hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int 
                          GgmlTables tabs) {
     if (bins > MAX_BINS || tmax > 4096) return hipErrorInvalidValue;
     const int tpad = (tmax + 63) & ~63;
-    const int threads = tpad < 512 ? tpad : 512;
-    VITS_KLAUNCH(spline_kernel, dim3(batch), dim3(threads), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt,
-                 mode, tabs.exp);
+    // one token per thread up to 1024 tokens (the 1024-thread build is capped at 128 VGPRs and spills a little; two tokens per thread one after
+    // the other doubled the launch for 1024-id inputs); 512 threads otherwise
+    if (tpad > 512)
+        VITS_KLAUNCH(spline_kernel<1024>, dim3(batch), dim3(tpad < 1024 ? tpad : 1024), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax,
+                     bins, tail, inv_sqrt, mode, tabs.exp);
+    else
+        VITS_KLAUNCH(spline_kernel<512>, dim3(batch), dim3(tpad), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt,
+                     mode, tabs.exp);
     return hipGetLastError();
 }
 
