@@ -1230,7 +1230,7 @@ hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int t
 // ---------------------------------------------------------------------------------------------------------
 // Inverse rational-quadratic spline on latent row zc (unconstrained_rational_quadratic_spline, vits.cpp:804-852 + :695-802;
 // HF modeling_vits.py:139-163,211-302). u = conv_proj output [3*bins-1][T]. One block per utterance, one thread per token (tokens
-// beyond 1024 loop).
+// beyond 512 loop).
 //   VITS_MODE_HF: identity outside [-B, B], the spline inside (HF:143-151).
 //   VITS_MODE_REFERENCE: Q3 (:720), on the LAST token Q4 (ggml-util.h:235-236,252-253), and the masked get / set pair of :832-849
 //   LITERALLY (Q6): tensor_masked_get keeps the shape (custom-ops.h:746-749) while tensor_masked_set consumes its values sequentially
@@ -1245,10 +1245,11 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : (fl
 
 // rational_quadratic_spline (vits.cpp:695-802) on one token's row; masked: the row's parameters were zeroed by :837-840
 // ggml_soft_max over the bins (vits.cpp:719,735), in place: fp32 by default, ggml's fp16 exp table + double sum when exp_tab is given (Q8)
+template <bool TAB>
 __device__ __forceinline__ void spline_softmax(float* v, int nb, const uint16_t* exp_tab) {
     float mx = -INFINITY;
     for (int i = 0; i < nb; ++i) mx = fmaxf(mx, v[i]);
-    if (exp_tab) {
+    if constexpr (TAB) {
         double sum = 0.0;
         for (int i = 0; i < nb; ++i) {
             v[i] = ggml_table_lookup(exp_tab, v[i] - mx);
@@ -1266,13 +1267,14 @@ __device__ __forceinline__ void spline_softmax(float* v, int nb, const uint16_t*
     for (int i = 0; i < nb; ++i) v[i] /= sum;
 }
 
+template <bool TAB>
 __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, int nb, float B, float inv_sqrt, int mode, bool q4, bool masked, const uint16_t* exp_tab) {
     const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
     float W[MAX_BINS], H[MAX_BINS], cw[MAX_BINS + 1], ch[MAX_BINS + 1];
     // widths
     {
         for (int i = 0; i < nb; ++i) W[i] = masked ? 0.f : ub[(int64_t)i * u_cs] * inv_sqrt;
-        spline_softmax(W, nb, exp_tab);
+        spline_softmax<TAB>(W, nb, exp_tab);
         if (mode == VITS_MODE_REFERENCE) {
             const float sc = min_w + (1 - min_w * nb);  // Q3
             for (int i = 0; i < nb; ++i) W[i] = W[i] * sc;
@@ -1292,7 +1294,7 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
     }
     {
         for (int i = 0; i < nb; ++i) H[i] = masked ? 0.f : ub[(int64_t)(nb + i) * u_cs] * inv_sqrt;
-        spline_softmax(H, nb, exp_tab);
+        spline_softmax<TAB>(H, nb, exp_tab);
         for (int i = 0; i < nb; ++i) H[i] = min_h + (1 - min_h * nb) * H[i];
         float cum = 0.f;
         ch[0] = 0.f;
@@ -1342,7 +1344,8 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
     return root * in_w + in_cw;
 }
 
-template <int NT>
+// (TAB: the emulated-ggml soft-max is a separate build, so that the default one carries no table code)
+template <int NT, bool TAB>
 __global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
                                                       int nb, float B, float inv_sqrt, int mode, const uint16_t* exp_tab) {
     extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs
         const bool inside = x >= -B && x <= B;
         const float* ub = u + (int64_t)b * u_bs + t;
         float r = x;  // HF: identity outside the interval (HF:143-151)
-        if (inside || ref) r = spline_row(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside, exp_tab);
+        if (inside || ref) r = spline_row<TAB>(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside, exp_tab);
         if (ref) {
             s_val[t] = inside ? x : 0.f;  // tensor_masked_get(inputs, inside_interval_mask): the shape is kept
             s_res[t] = r;
@@ -1388,14 +1391,17 @@ hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int 
                          GgmlTables tabs) {
     if (bins > MAX_BINS || tmax > 4096) return hipErrorInvalidValue;
     const int tpad = (tmax + 63) & ~63;
-    // one token per thread up to 1024 tokens (the 1024-thread build is capped at 128 VGPRs and spills a little; two tokens per thread one after
-    // the other doubled the launch for 1024-id inputs); 512 threads otherwise
-    if (tpad > 512)
-        VITS_KLAUNCH(spline_kernel<1024>, dim3(batch), dim3(tpad < 1024 ? tpad : 1024), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax,
-                     bins, tail, inv_sqrt, mode, tabs.exp);
-    else
-        VITS_KLAUNCH(spline_kernel<512>, dim3(batch), dim3(tpad), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt,
-                     mode, tabs.exp);
+    // 512 threads: one token per thread up to 512 tokens, two rounds for 1024-id inputs (a 1024-thread build is capped at 128 VGPRs and spills
+    // the bin arrays: 74 us per launch against 32 at 8 x 1024 ids)
+#define VITS_SPLINE_LAUNCH(NT, TAB)                                                                                                                 \
+    VITS_KLAUNCH((spline_kernel<NT, TAB>), dim3(batch), dim3(tpad < NT ? tpad : NT), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, \
+                 tmax, bins, tail, inv_sqrt, mode, tabs.exp)
+    if (tabs.exp) {
+        VITS_SPLINE_LAUNCH(512, true);
+    } else {
+        VITS_SPLINE_LAUNCH(512, false);
+    }
+#undef VITS_SPLINE_LAUNCH
     return hipGetLastError();
 }
 
