@@ -343,7 +343,71 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
             }
             xb += 4 * XW;
         }
-        // ---- epilogue: the four phases of a line back to back (same expressions as conv16's E16_CONVT_GROUP) ----
+        // ---- epilogue (same expressions as conv16's E16_CONVT_GROUP). In the MFMA C layout a lane holds ONE position q (its column) and, in
+        // acc[k], the four phases of it: a store instruction for phase k then touches 32 different 128-byte lines (one per position, 256
+        // bytes apart) with 32 bytes each, and every line is completed by four instructions: quarter-line writes, 2.6 TB/s on the 256 -> 128
+        // upsampler where coalesced stores reach 6. A 4 x 4 transpose inside each quad of lanes (two DPP quad_perm butterflies per value, as in
+        // conv_mfma.hip's wide epilogue) hands lane j of a quad phase j of the quad's four positions: a store instruction then writes the
+        // four phases (x two channel halves from lanes l, l + 32) of EIGHT positions = eight complete lines.
+#ifndef VITS_CT16L_OLD_EPI
+        {
+            const int qj = lane & 3;  // phase this lane stores after the transpose
+            const bool odd1 = lane & 1, odd2 = lane & 2;
+            auto quad_transpose = [&](float& v0, float& v1, float& v2, float& v3) __attribute__((always_inline)) {
+                {
+                    float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+                    s01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                    s23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                    if (odd1) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
+                }
+                {
+                    float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+                    s02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                    s13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                    if (odd2) { v0 = s02; v1 = s13; } else { v2 = s02; v3 = s13; }
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = cb * 32 + 8 * g + 4 * h;
+                const float4v bias = bias4[g];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    // t[i][e]: position (quad base + i), phase qj, channel e of this lane's half slot
+                    float t[4][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v0 = acc[0][nr][4 * g + e], v1 = acc[1][nr][4 * g + e], v2 = acc[2][nr][4 * g + e], v3 = acc[3][nr][4 * g + e];
+                        quad_transpose(v0, v1, v2, v3);  // (every lane of the quad takes part: the guards below only cover the stores)
+                        t[0][e] = v0;
+                        t[1][e] = v1;
+                        t[2][e] = v2;
+                        t[3][e] = v3;
+                    }
+                    const int qb = t0 + cp * 64 + nr * 32 + (col & ~3);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = qb + i;
+                        if (q >= ncols) continue;
+                        const int n = p.s * q + half * PH + qj - p.crop;
+                        if (n < 0 || n >= out_len) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = t[i][e] + bias[e];
+                        if (yg) *reinterpret_cast<float4v*>(yg + ((int64_t)(co0 >> 3) * p.g_ts + n) * 8 + (co0 & 7)) = float4v{v[0], v[1], v[2], v[3]};
+                        if (y16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
+                            int2v w2;
+                            w2.x = (int)pack16<BF>(v[0], v[1]);
+                            w2.y = (int)pack16<BF>(v[2], v[3]);
+                            *reinterpret_cast<int2v*>(y16 + ((int64_t)(co0 >> 3) * p.y16_ts + n) * 8 + (co0 & 7)) = w2;
+                        }
+                    }
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cb * 32 + 8 * g + 4 * h;
@@ -371,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
                 }
             }
         }
+#endif
     }
 }
 
