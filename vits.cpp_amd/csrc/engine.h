@@ -125,6 +125,7 @@ struct Knobs {
     bool no_flow_fuse = false;   // VITS_NO_FLOW_FUSE: 16-bit modes: a coupling layer of the flow as nine launches instead of one kernel
     bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
     int front_prio = 1;          // VITS_FRONT_PRIO=0: the front-end stream of pipelined batches at normal instead of high priority
+    bool keep_stage_sum32 = false;  // VITS_KEEP_STAGE_SUM32: 16-bit vocoder: also store the fp32 resblock sum of a stage's last resblock (nobody reads it)
     bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
     void read();
 };

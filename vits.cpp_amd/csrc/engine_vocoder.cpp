@@ -149,6 +149,12 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                     }
                     f.y16 = bsum16;
                     f.y16_slope = i + 1 < n_up ? hp.lrelu : final_slope;
+                    // the stage output has ONE reader — the next upsampler or conv_post, through the 16-bit copy: the fp32 sum of the last
+                    // resblock is a dead store (4 of its 10-14 bytes per element: 1.5 GB per batch of 64 x 128 ids over the four stages)
+                    if (!knobs.keep_stage_sum32) {
+                        f.yg = nullptr;
+                        bytes -= 4.0 * n_out;
+                    }
                     bytes += 2.0 * n_out;
                 }
                 if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));  // (the accumulation is inside the kernel: the resblocks chain)
@@ -214,6 +220,10 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                         c2.y16 = bsum16;
                         c2.y16_slope = i + 1 < n_up ? hp.lrelu : final_slope;
                         bytes2 += 2.0 * n_out;
+                        if (!knobs.keep_stage_sum32) {  // (dead store: see the whole-resblock path above)
+                            c2.yg = nullptr;
+                            bytes2 -= 4.0 * n_out;
+                        }
                     } else {
                         c2.scale = 1.f;
                     }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     // dependent HBM round trips — the compiler may not move a later load above an earlier store that could alias it (the WaveNet kernels
     // spent 15 of 48 us that way). All addends first (the conv accumulators are dead: their registers hold them), then every store.
     {
-        float* yg = p.yg + (int64_t)b * p.g_bs;
+        float* yg = p.yg ? p.yg + (int64_t)b * p.g_bs : nullptr;  // (null: only the 16-bit copy is wanted — the last resblock of a stage)
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
         float4v av[MRW][4][NRW];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                             v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
                         }
                     }
-                    *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+                    if (yg) *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
                     if (y16) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);
@@ -380,7 +380,7 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
         p.b2[i] = c2[i]->bias;
     }
     const int dils[3] = {1, 3, 5};
-    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || !c.yg) return hipErrorInvalidValue;
+    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || (!c.yg && !c.y16.p)) return hipErrorInvalidValue;
     p.y0 = c.y0;
     p.lens = c.lens;
     p.tmax = c.tmax;
