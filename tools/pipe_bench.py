@@ -11,6 +11,7 @@ ap.add_argument("--arith", default="f16")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--ids", type=int, default=128)
+ap.add_argument("--delay-ms", type=float, default=0.0, help="experiment: sleep this long before every submit of the pipelined loop (moves stage one later into the previous batch's vocoder)")
 ap.add_argument("--stage-one", action="store_true", help="also time stage one alone (frames_only calls)")
 a = ap.parse_args()
 torch.zeros(1, device="cuda")  # (torch's HIP runtime first, as in bench.py: the other order leaves torch without a device)
@@ -32,6 +33,8 @@ for rep in range(2):
     torch.cuda.synchronize(); t = time.perf_counter()
     m.submit_batch(ids, out_device=bufs[0].data_ptr(), **kw)
     for k in range(1, a.steps):
+        if a.delay_ms > 0:
+            time.sleep(a.delay_ms * 1e-3)
         m.submit_batch(ids, out_device=bufs[k % 2].data_ptr(), **kw)
         _, lengths, _ = m.wait(keep_pcm=False)
     _, lengths, _ = m.wait(keep_pcm=False)
@@ -44,5 +47,5 @@ if a.stage_one:
         torch.cuda.synchronize(); res["stage1"] = (time.perf_counter() - t) / a.steps * 1e3
 samples = int(lengths.sum())
 print(f"{a.arith} batch {a.batch} x {a.ids}: serial {res['serial']:.3f} ms ({samples / res['serial'] / 1e3:.1f} M/s)  pipelined {res['pipelined']:.3f} ms "
-      f"({samples / res['pipelined'] / 1e3:.1f} M/s)" + (f"  stage one alone {res['stage1']:.3f} ms" if "stage1" in res else "") + "  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
+      f"({samples / res['pipelined'] / 1e3:.1f} M/s)" + (f"  stage one alone {res['stage1']:.3f} ms" if "stage1" in res else "") + (f"  delay {a.delay_ms} ms" if a.delay_ms else "") + "  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
 m.close()
