@@ -13,7 +13,12 @@
  *     NULL / {NULL,0}; the message is available from vits_last_error().
  *   - nothing is printed to stdout (reference prints at src/vits.cpp:27,1200 and in the loaders).
  *   - everything below "extensions" is new: id-level and batched entry points (the reference is batch-1,
- *     text-only), synthetic model generation, taps, profiling, operator-level entry points for parity tests.
+ *     text-only), pipelined batches on one handle, synthetic model generation, taps, profiling, operator-level
+ *     entry points for parity tests.
+ *   - threading: one call at a time per model handle, as in the reference (vits_model::process writes member
+ *     tensors, vits.h:22-30) — but ENFORCED: an entry point entered while another call on the same handle is in
+ *     progress (from a second thread, or from an on_chunk callback) returns its failure value with
+ *     vits_last_error() = "model busy: ...". Distinct handles may be used from distinct threads concurrently.
  *
  * Plain C types only: pointers, sizes, PODs. No torch / HIP types appear in any signature; device buffers are
  * passed as `void*` device addresses.

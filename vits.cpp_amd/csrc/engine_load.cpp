@@ -263,8 +263,11 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
             hipStreamCreateWithPriority(&front_, hipStreamNonBlocking, knobs.front_prio ? greatest : least) != hipSuccess) {
-            err = "hipStreamCreate failed";
-            return false;
+            front_ = nullptr;  // (no priorities on this device: a plain stream does the same job — the priority measured +-0)
+            if (hipStreamCreateWithFlags(&front_, hipStreamNonBlocking) != hipSuccess) {
+                err = "hipStreamCreate failed";
+                return false;
+            }
         }
     }
     if (knobs.rb_streams > 1 && !dry_run_) {
