@@ -48,3 +48,26 @@ def test_the_engine_labels_use_the_same_tile_tags():
     assert "convt16_stream_tag(U.up, tag, sizeof(tag))" in src
     ct = open(os.path.join(ROOT, "vits.cpp_amd", "csrc", "convt16.hip")).read()
     assert '"SL%d"' in ct and '"S%d.%d.%d"' in ct
+
+
+def test_default_schedule_reducer_on_a_committed_trace(tmp_path):
+    """tools/default_schedule.py (the library-default schedule's rocprofv3 summary -> what bench.py joins into roofline_default_schedule):
+    run on a committed trace, every matrix-core instantiation gets a bench key with calls per step and an average duration, and the summed
+    kernel time is the CSV's total."""
+    import json
+    import subprocess
+    src = sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_default_kernel_stats.csv")))
+    assert src, "no committed default-schedule trace"
+    out = tmp_path / "ds.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "default_schedule.py"), str(out), src[0], "--workload", "c3|b64|f32", "--steps-in-trace", "7"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(out))
+    assert d["workload_tag"] == "c3|b64|f32" and d["steps_in_trace"] == 7 and len(d["source_sha16"]) == 16
+    total = 0.0
+    with open(src[0]) as fh:
+        for row in csv.DictReader(fh):
+            total += float(row["TotalDurationNs"])
+    assert abs(d["summed_kernel_ms_per_step"] - total / 7 / 1e6) < 1e-6
+    keys = d["by_bench_key"]
+    assert any(k.startswith("k11|d1|") for k in keys) and all(v["calls_per_step"] > 0 and v["avg_us"] > 0 for v in keys.values())
