@@ -149,9 +149,8 @@ int Engine::wait_batch(vits_batch_result* out, std::string& err) {
     }
     Pending& p = pend_[wait_seq_ & 1];
     HIP_OK(hipEventSynchronize(p.done));
-    p.active = false;
-    ++wait_seq_;
     if (out) {
+        // (the slot is released only once the result has been handed over: an allocation failure below leaves the batch waitable)
         out->batch = (size_t)p.B;
         out->stride = p.stride;
         out->lengths = new int64_t[p.B];
@@ -164,6 +163,8 @@ int Engine::wait_batch(vits_batch_result* out, std::string& err) {
             std::memcpy(out->data, p.host, sizeof(float) * (size_t)p.B * p.stride);
         }
     }
+    p.active = false;
+    ++wait_seq_;
     return 0;
 }
 

@@ -144,7 +144,7 @@ class Engine {
     // pipelined batches (include/vits.h vits_model_submit_batch / vits_model_wait): up to two in flight
     int submit_batch(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, std::string& err);
     int wait_batch(vits_batch_result* out, std::string& err);
-    int pending() const { return (int)(submit_seq_ - wait_seq_); }
+    int pending() const { return (int)(submit_seq_.load(std::memory_order_acquire) - wait_seq_.load(std::memory_order_acquire)); }  // (any thread may ask)
     int sync(std::string& err);
     // One call at a time per handle (the reference's contract too: process writes member tensors, src/include/vits.h:22-30). The ABI
     // takes this flag around every entry point that touches the engine; a second thread gets "model busy" instead of a race.
@@ -223,7 +223,7 @@ class Engine {
         size_t frames_cap = 0;  // ints
         hipEvent_t s1_done = nullptr, done = nullptr;
     } pend_[2];
-    uint64_t submit_seq_ = 0, wait_seq_ = 0;  // batch n lives in pend_[n & 1]
+    std::atomic<uint64_t> submit_seq_{0}, wait_seq_{0};  // batch n lives in pend_[n & 1]; written under the busy flag, read by vits_model_pending
     hipStream_t front_ = nullptr;             // stage one of pipelined batches (created on first use)
     int process_impl(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out, std::string& err,
                      Pending* pend);
