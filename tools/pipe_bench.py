@@ -11,6 +11,7 @@ ap.add_argument("--arith", default="f16")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--ids", type=int, default=128)
+ap.add_argument("--mode", choices=["both", "serial", "pipelined"], default="both", help="which schedule(s) to run (a profiler trace wants exactly one)")
 ap.add_argument("--delay-ms", type=float, default=0.0, help="experiment: sleep this long before every submit of the pipelined loop (moves stage one later into the previous batch's vocoder)")
 ap.add_argument("--stage-one", action="store_true", help="also time stage one alone (frames_only calls)")
 a = ap.parse_args()
@@ -26,10 +27,15 @@ for k in range(3):
     m.process_batch(ids, out_device=bufs[k % 2].data_ptr(), keep_pcm=False, **kw)
 res = {}
 for rep in range(2):
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for k in range(a.steps):
-        m.process_batch(ids, out_device=bufs[k % 2].data_ptr(), keep_pcm=False, **kw)
-    torch.cuda.synchronize(); res["serial"] = (time.perf_counter() - t) / a.steps * 1e3
+    if a.mode != "pipelined":
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for k in range(a.steps):
+            _, lengths, _ = m.process_batch(ids, out_device=bufs[k % 2].data_ptr(), keep_pcm=False, **kw)
+        torch.cuda.synchronize(); res["serial"] = (time.perf_counter() - t) / a.steps * 1e3
+    if a.mode == "serial":
+        res["pipelined"] = float("nan")
+        continue
+    res.setdefault("serial", float("nan"))
     torch.cuda.synchronize(); t = time.perf_counter()
     m.submit_batch(ids, out_device=bufs[0].data_ptr(), **kw)
     for k in range(1, a.steps):
