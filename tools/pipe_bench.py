@@ -38,11 +38,18 @@ for rep in range(2):
     res.setdefault("serial", float("nan"))
     torch.cuda.synchronize(); t = time.perf_counter()
     m.submit_batch(ids, out_device=bufs[0].data_ptr(), **kw)
+    t_sub = t_wait = 0.0
     for k in range(1, a.steps):
         if a.delay_ms > 0:
             time.sleep(a.delay_ms * 1e-3)
+        ta = time.perf_counter()
         m.submit_batch(ids, out_device=bufs[k % 2].data_ptr(), **kw)
+        tb = time.perf_counter()
         _, lengths, _ = m.wait(keep_pcm=False)
+        t_sub += tb - ta
+        t_wait += time.perf_counter() - tb
+    res["submit_ms"] = t_sub / max(a.steps - 1, 1) * 1e3  # host time inside submit (stage one + the frame-count read + queueing stage two)
+    res["wait_ms"] = t_wait / max(a.steps - 1, 1) * 1e3   # host time blocked in wait: the slack before the previous batch's vocoder ends
     _, lengths, _ = m.wait(keep_pcm=False)
     torch.cuda.synchronize(); res["pipelined"] = (time.perf_counter() - t) / a.steps * 1e3
 if a.stage_one:
@@ -53,5 +60,5 @@ if a.stage_one:
         torch.cuda.synchronize(); res["stage1"] = (time.perf_counter() - t) / a.steps * 1e3
 samples = int(lengths.sum())
 print(f"{a.arith} batch {a.batch} x {a.ids}: serial {res['serial']:.3f} ms ({samples / res['serial'] / 1e3:.1f} M/s)  pipelined {res['pipelined']:.3f} ms "
-      f"({samples / res['pipelined'] / 1e3:.1f} M/s)" + (f"  stage one alone {res['stage1']:.3f} ms" if "stage1" in res else "") + (f"  delay {a.delay_ms} ms" if a.delay_ms else "") + "  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
+      f"({samples / res['pipelined'] / 1e3:.1f} M/s)" + (f"  stage one alone {res['stage1']:.3f} ms" if "stage1" in res else "") + (f"  [submit {res['submit_ms']:.2f} ms, wait {res['wait_ms']:.2f} ms]" if "submit_ms" in res else "") + (f"  delay {a.delay_ms} ms" if a.delay_ms else "") + "  env " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VITS_")))
 m.close()

@@ -612,16 +612,17 @@ __device__ __forceinline__ float gelu_op(float x, const uint16_t* gelu_tab) { re
 // partial sums are combined in a fixed order, so results do not depend on the batch.
 constexpr int LN_GROUPS = 16;
 
-__global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
+template <int TW>
+__global__ __launch_bounds__(TW * LN_GROUPS) void add_layer_norm_kernel(const float* x, int64_t x_bs, int x_cs, const float* res, int64_t r_bs, int r_cs,
                                                              const float* gamma, const float* beta, float* y, int64_t y_bs, int y_cs, float* addto,
                                                              int64_t a_bs, int a_cs, const int* lens, int channels, int tmax, float eps, int post_gelu, const uint16_t* gelu_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* tile = sm;                    // [channels][64]
-    float* red = sm + channels * 64;     // [LN_GROUPS][64] x2
-    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    float* tile = sm;                    // [channels][TW]
+    float* red = sm + channels * TW;     // [LN_GROUPS][TW] x2
+    const int b = blockIdx.y, t0 = blockIdx.x * TW;
     const int len = lens ? lens[b] : tmax;
     if (t0 >= len) return;
-    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int tl = threadIdx.x % TW, g = threadIdx.x / TW;
     const int t = t0 + tl;
     const bool ok = t < len;
     float s = 0.f;
@@ -646,31 +647,31 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const fl
                 v = xv[u];
                 if (res) v += rv[u];
             }
-            tile[c * 64 + tl] = v;
+            tile[c * TW + tl] = v;
             s += v;
         }
     }
-    red[g * 64 + tl] = s;
+    red[g * TW + tl] = s;
     __syncthreads();
     float msum = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * 64 + tl];
+    for (int q = 0; q < LN_GROUPS; ++q) msum += red[q * TW + tl];
     const float mean = msum / (float)channels;
     float vs = 0.f;
     for (int c = g; c < channels; c += LN_GROUPS) {
-        const float d = tile[c * 64 + tl] - mean;
+        const float d = tile[c * TW + tl] - mean;
         vs += d * d;
     }
-    red[(LN_GROUPS + g) * 64 + tl] = vs;
+    red[(LN_GROUPS + g) * TW + tl] = vs;
     __syncthreads();
     float vsum = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * 64 + tl];
+    for (int q = 0; q < LN_GROUPS; ++q) vsum += red[(LN_GROUPS + q) * TW + tl];
     const float var = vsum / (float)channels;
     const float inv = 1.0f / sqrtf(var + eps);
     if (!ok) return;
     for (int c = g; c < channels; c += LN_GROUPS) {
-        float v = (tile[c * 64 + tl] - mean) * inv * gamma[c] + beta[c];
+        float v = (tile[c * TW + tl] - mean) * inv * gamma[c] + beta[c];
         if (post_gelu) v = gelu_op(v, gelu_tab);
         if (addto) {
             float* a = addto + (int64_t)b * a_bs + (int64_t)c * a_cs + t;
@@ -682,15 +683,28 @@ __global__ __launch_bounds__(64 * LN_GROUPS) void add_layer_norm_kernel(const fl
 
 hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma, const float* beta, TensorRef y, const int* lens, int batch, int channels,
                                  int tmax, float eps, int post_gelu, TensorRef add_to, hipStream_t s, GgmlTables tabs) {
-    const size_t lds = sizeof(float) * ((size_t)channels * 64 + 2 * 64 * LN_GROUPS);
+    // tile width (time steps per block): 32 = eight waves and channels x 128 B of LDS per block (29 KB at 192 channels); VITS_LN_TW=64 = the
+    // sixteen-wave, 57 KB blocks of rounds 1-3. Every token's sums are the same either way (its channels are summed by the same sixteen channel
+    // groups in the same order). The small block matters when this kernel shares the chip with another batch's vocoder (vits_model_submit_batch):
+    // a 57 KB block only finds room in the tail of a vocoder kernel — stage one of a pipelined f16 batch took 10.2 ms of wall with it, 8.8 with
+    // the small one (alone: 1.91 -> 1.87 ms).
+    static const int tw_env = getenv("VITS_LN_TW") ? atoi(getenv("VITS_LN_TW")) : 32;
+    const int tw = tw_env == 64 ? 64 : 32;
+    const size_t lds = sizeof(float) * ((size_t)channels * tw + 2 * tw * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(add_layer_norm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    dim3 grid((tmax + 63) / 64, batch);
-    VITS_KLAUNCH(add_layer_norm_kernel, grid, dim3(64 * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, add_to.bs,
-                       add_to.cs, lens, channels, tmax, eps, post_gelu, tabs.gelu);
+    dim3 grid((tmax + tw - 1) / tw, batch);
+#define VITS_LN_LAUNCH(TW)                                                                                                                           \
+    do {                                                                                                                                             \
+        if (lds > 64 * 1024) {                                                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(add_layer_norm_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                                           \
+        }                                                                                                                                            \
+        VITS_KLAUNCH(add_layer_norm_kernel<TW>, grid, dim3(TW * LN_GROUPS), lds, s, x.p, x.bs, x.cs, res.p, res.bs, res.cs, gamma, beta, y.p, y.bs, y.cs, add_to.p, \
+                     add_to.bs, add_to.cs, lens, channels, tmax, eps, post_gelu, tabs.gelu);                                                       \
+    } while (0)
+    if (tw == 32) VITS_LN_LAUNCH(32);
+    else VITS_LN_LAUNCH(64);
+#undef VITS_LN_LAUNCH
     return hipGetLastError();
 }
 
