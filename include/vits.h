@@ -67,7 +67,10 @@ VITS_API const char* vits_last_error(void);
 /* Semantics mode:
  *   VITS_MODE_REFERENCE: what /root/reference/src/vits.cpp literally computes: ConvTranspose1d without
  *     crop (Q1, vits.cpp:187), final LeakyReLU slope 0.1 (Q2, :638), spline width affine (Q3, :720),
- *     index -1 wrap on the last token (Q4, ggml-util.h:235), exp(+log_scale) (Q5, :913-918).
+ *     index -1 wrap on the last token (Q4, ggml-util.h:235), exp(+log_scale) (Q5, :913-918), and the masked get / set
+ *     pair of the spline tails as implemented (Q6, :832-849 with custom-ops.h:739-752,829-862: masked_get keeps the
+ *     shape, masked_set consumes compacted values — a latent outside [-5, 5] shifts the log-durations of every later
+ *     token; the identity permutation while every latent is inside).
  *   VITS_MODE_HF: what transformers.VitsModel (the model the reference ports, vits.cpp:113) computes. */
 #define VITS_MODE_DEFAULT (-1)
 #define VITS_MODE_REFERENCE 0
