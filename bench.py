@@ -776,7 +776,7 @@ def main():
             mfma_keys = [kk for kk in groups if kk.startswith("k") and groups[kk]["flop"] > 0]
             family_of = lambda kk: (kk.split("|")[2][0] if len(kk.split("|")) >= 3 else "?")
             FAMILY_NAMES = {"F": "rbpair16_kernel (fused ResBlock conv pair)", "T": "conv16_kernel", "W": "wavenet16_kernel", "f": "rbpair32_kernel",
-                            "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "conv_group_kernel", "B": "rbblock16_kernel (whole ResBlock)",
+                            "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "conv_group_kernel", "B": "rbblock16_kernel (whole ResBlock)", "b": "rbblock32_kernel (whole 3-tap ResBlock, fp32)",
                             "C": "flow_couple16_kernel (whole coupling layer)"}
             dom_members = None
             if args.arith != "f32" and mfma_keys:

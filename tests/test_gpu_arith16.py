@@ -459,3 +459,37 @@ def test_converter_path_keeps_its_arithmetic_under_the_profiler_and_the_grouped_
         for x, y in zip(outs["plain"][0], outs[k][0]):
             assert np.array_equal(x, y), k
     assert any(not np.array_equal(x, y) for x, y in zip(outs["plain"][0], f32[0]))
+
+
+def test_whole_fp32_resblock_kernel_is_bit_identical_to_the_pair_path(pkg, full_bytes, monkeypatch):
+    """rbblock32.hip (the 3-tap resblocks of the C = 32 / 64 stages as ONE fp32 kernel: the stream stays in registers across the three
+    pairs) uses the same MFMA chain per output and the same epilogue expressions as three rbpair32 launches: the PCM must not move by a
+    bit — ragged batch with one-token members, windowed vocoder, both semantics modes, 700-id utterances (many more blocks than the GPU
+    holds at once), the serialised / grouped schedule of the profiler."""
+    Ts = [30, 11, 40, 1, 2]
+    ids = np.zeros((len(Ts), 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = _ids(T, 190 + b)
+    long_ids = pkg.synth_ids(2, 700, ids_seed=4243)
+    outs = {}
+    for block in (True, False):
+        if not block:
+            monkeypatch.setenv("VITS_NO_RBBLOCK32", "1")
+        with pkg.Model(full_bytes) as m:
+            for mode in (0, 1):
+                outs[(block, mode, 0)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=35)
+                outs[(block, mode, 1)] = m.process_batch(ids, id_lengths=Ts, mode=mode, noise_seed=35, vocoder_chunk_frames=24)
+            outs[(block, "long", 0)] = m.process_batch(long_ids, noise_seed=36, fixed_duration=2)
+            m.prof_enable(True)
+            outs[(block, "prof", 0)] = m.process_batch(ids, id_lengths=Ts, noise_seed=35)
+            names = [k["name"] for k in m.prof_report()["kernels"]]
+            assert any("hifigan_resblock_block|k3" in n for n in names) == block, names
+            m.prof_enable(False)
+    for key in [(m_, w) for m_ in (0, 1) for w in (0, 1)] + [("long", 0), ("prof", 0)]:
+        a, b_ = outs[(True,) + key], outs[(False,) + key]
+        assert np.array_equal(a[1], b_[1])
+        for x, y in zip(a[0], b_[0]):
+            assert np.array_equal(x, y), key
+    for mode in (0, 1):
+        for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
+            assert np.array_equal(x, y)

@@ -40,6 +40,7 @@ def test_every_matrix_core_kernel_of_the_committed_traces_has_a_bench_key():
     assert bench_key("void vits::rbblock16_kernel<11, 32, 4, 3, 1, 1, 3, 5, false>(vits::RbBlockParams)") == "k11|d135|B32|e0g"
     assert bench_key("void vits::convt16_kernel<4, 1, 16, false>(vits::ConvT16Params)") == "k2|d-1|S4.1.16|e2g"
     assert bench_key("void vits::convt16_lines_kernel<64, false>(vits::ConvT16Params)") == "k2|d-1|SL64|e2g"
+    assert bench_key("void vits::rbblock32_kernel<32, 2>(vits::RbBlock32Params)") == "k3|d135|b32|e0"
 
 
 def test_the_engine_labels_use_the_same_tile_tags():

@@ -16,6 +16,7 @@ _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
 _RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+)(?:, \d+)*?, (\d+), (\d+), (\d+), (\w+)>")
 _CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\d+), (\w+)>")
 _CONVT16L = re.compile(r"convt16_lines_kernel<(\d+), (\w+)>")
+_RBBLOCK32 = re.compile(r"rbblock32_kernel<(\d+), (\d+)>")
 _GROUP = re.compile(r"conv_group_kernel<(-?\d+)>")
 _RBPAIR32 = re.compile(r"rbpair32_kernel<(-?\d+), (-?\d+), (\d+)>")
 _RBPAIR16 = re.compile(r"rbpair16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\w+)(?:, \w+)?>")
@@ -54,6 +55,9 @@ def bench_key(kernel_name):
     if m:  # `rbblock16_kernel<11, 32, 4, 3, 1, 1, 3, 5, false>` -> `k11|d135|B32|e0g`
         kt, c, d0, d1, d2, _ = m.groups()
         return f"k{kt}|d{d0}{d1}{d2}|B{c}|e0g"
+    m = _RBBLOCK32.search(kernel_name)
+    if m:  # `rbblock32_kernel<32, 2>` -> `k3|d135|b32|e0` (whole 3-tap resblock, fp32)
+        return f"k3|d135|b{m.group(1)}|e0"
     m = _CONVT16.search(kernel_name)
     if m:  # `convt16_kernel<4, 1, 16, false>` -> `k2|d-1|S4.1.16|e2g` (the engine prints the same tag: kernels.h convt16_stream_tag)
         nr, cs, rs, _ = m.groups()

@@ -120,6 +120,7 @@ struct Knobs {
     bool no_fuse16 = false;      // VITS_NO_FUSE16: 16-bit resblock conv pairs as two launches
     bool no_rbblock16 = false;   // VITS_NO_RBBLOCK16: 16-bit narrow-stage resblocks as three fused pairs instead of one kernel
     bool no_fuse32 = false;      // VITS_NO_FUSE32: fp32 resblock conv pairs as two launches
+    bool no_rbblock32 = false;   // VITS_NO_RBBLOCK32: fp32 3-tap resblocks of the narrow stages as three fused pairs instead of one kernel
     bool no_rb_group = false;    // VITS_NO_RB_GROUP: the resblocks of a stage as separate launches (no grouped launch)
     bool rb_group_always = false;  // VITS_RB_GROUP=1: grouped launches also when the three streams are available
     bool no_flow_fuse = false;   // VITS_NO_FLOW_FUSE: 16-bit modes: a coupling layer of the flow as nine launches instead of one kernel

@@ -33,6 +33,7 @@ void Knobs::read() {
     no_fuse16 = flag("VITS_NO_FUSE16");
     no_rbblock16 = flag("VITS_NO_RBBLOCK16");
     no_fuse32 = flag("VITS_NO_FUSE32");
+    no_rbblock32 = flag("VITS_NO_RBBLOCK32");
     no_rb_group = flag("VITS_NO_RB_GROUP");
     rb_group_always = flag("VITS_RB_GROUP");
     no_flow_fuse = flag("VITS_NO_FLOW_FUSE");

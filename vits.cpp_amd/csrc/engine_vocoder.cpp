@@ -353,6 +353,55 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             for (size_t d = 0; d < R.dil.size() && f; ++d) f = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
             fusedrb[j] = f;
         }
+        // narrow stages, 3-tap resblocks: the WHOLE resblock as one kernel (rbblock32.hip: the stream stays in registers across its three pairs;
+        // bit-identical to the fused pairs). It carries the accumulation into the shared sum itself, so it is launched where the resblock's last
+        // launch would be.
+        bool blockrb[3] = {false, false, false};
+        for (size_t j = 0; j < nk && j < 3; ++j) {
+            const ResBlockW& R = U.rbs[j];
+            bool f = fusedrb[j] && !knobs.no_rbblock32 && rbblock32_supported(C, R.k, R.dil.data(), (int)R.dil.size());
+            for (size_t d = 0; d < R.dil.size() && f; ++d) f = R.c1[d].wp && R.c2[d].wp;
+            blockrb[j] = f;
+        }
+        auto run_block = [&](size_t j, hipStream_t sj) -> int {
+            const ResBlockW& R = U.rbs[j];
+            const PackedConv* w1[3] = {&R.c1[0], &R.c1[1], &R.c1[2]};
+            const PackedConv* w2[3] = {&R.c2[0], &R.c2[1], &R.c2[2]};
+            RbBlock32Call f;
+            f.x = bu;
+            f.lens = d_len[st_out];
+            f.batch = B;
+            f.tmax = smax[st_out];
+            f.slope = hp.lrelu;
+            f.y = bsum;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635), as the last pair of the pair path
+            if (j > 0) f.acc = bsum;
+            if (j + 1 == nk) {
+                if (refmode) {
+                    f.scale = (float)(1.0 / (double)nk);
+                    f.scale_div = 0;
+                } else {
+                    f.scale = (float)nk;
+                    f.scale_div = 1;
+                }
+                if (i + 1 < n_up) {
+                    f.post_act = 2;
+                    f.post_slope = hp.lrelu;
+                }
+            } else {
+                f.scale = 1.f;
+            }
+            if (prof.on) {
+                char full[160];
+                std::snprintf(full, sizeof(full), "hifigan_resblock_block|k%d|d135|b%d|e0|c%dx%d", R.k, C, C, C);
+                const double n_out = (double)C * (double)ssum[st_out];
+                double bytes = 4.0 * n_out * (2 + (f.acc.p ? 1 : 0));
+                for (size_t d = 0; d < R.dil.size(); ++d) bytes += (double)R.c1[d].bytes + (double)R.c2[d].bytes;
+                prof.begin(full, 3.0 * 2.0 * 2.0 * (double)C * C * R.k * (double)ssum[st_out], bytes, sj, true);
+            }
+            HIP_OK(launch_rbblock32(w1, w2, f, sj));
+            prof.end(sj);
+            return 0;
+        };
         // grouped schedule: at least two un-fused resblocks with distinct tap counts of {11, 7, 3}, the same dilation list, on the 128 x 128 tile
         // (measured, batch 64 x 128 ids: serialised launches 79.7 ms per step, grouped 79.1, three streams 76.8 — kernels of DIFFERENT
         // launches share a CU, which blocks of one launch do not, so the streams win where they can be used: the
@@ -496,14 +545,14 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             // fused resblocks: their chain up to (not including) the last pair, beside the group — on a side stream unless the profiler
             // needs kernels that do not overlap
             bool any_fused = false;
-            for (size_t j = 0; j < nk; ++j) any_fused = any_fused || fusedrb[j];
+            for (size_t j = 0; j < nk; ++j) any_fused = any_fused || (fusedrb[j] && !blockrb[j]);
             hipStream_t sf = (any_fused && !prof.on) ? side_[0] : stream;
             if (sf != stream) {
                 HIP_OK(hipEventRecord(ev_fork_, stream));
                 HIP_OK(hipStreamWaitEvent(sf, ev_fork_, 0));
             }
             for (size_t j = 0; j < nk; ++j)
-                if (fusedrb[j])
+                if (fusedrb[j] && !blockrb[j])
                     for (size_t d = 0; d + 1 < nd; ++d)
                         if (run_fused(j, d, sf)) return -1;
             if (sf != stream) HIP_OK(hipEventRecord(ev_done_[0], sf));
@@ -538,7 +587,9 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             // the last launch of every resblock, in the reference's order of the additions
             if (sf != stream) HIP_OK(hipStreamWaitEvent(stream, ev_done_[0], 0));
             for (size_t j = 0; j < nk; ++j) {
-                if (fusedrb[j]) {
+                if (blockrb[j]) {
+                    if (run_block(j, stream)) return -1;
+                } else if (fusedrb[j]) {
                     if (run_fused(j, nd - 1, stream)) return -1;
                 } else {
                     HIP_OK(conv("hifigan_resblock_conv", U.rbs[j].c2[nd - 1], mk_c2(j, nd - 1), stream));
@@ -557,6 +608,13 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             const size_t nd = R.dil.size();
             hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
             const bool fuse_rb = j < 3 ? fusedrb[j] : false;
+            if (j < 3 && blockrb[j]) {
+                // (the kernel adds into the shared sum: it takes the place of the resblock's last launch in the chain of additions)
+                if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                if (run_block(j, sj)) return -1;
+                if (par) HIP_OK(hipEventRecord(ev_done_[j], sj));
+                continue;
+            }
             for (size_t d = 0; d < nd; ++d) {
                 const bool last = d + 1 == nd;
                 if (!fuse_rb) HIP_OK(conv("hifigan_resblock_conv", R.c1[d], mk_c1(j, d), sj));

@@ -201,6 +201,20 @@ struct RbPair32Call {
     float post_slope = 0.f;
 };
 bool rbpair32_supported(int channels, int kt, int dil);
+// fp32: one WHOLE 3-tap ResBlock (dilations 1 / 3 / 5) of a narrow stage as one kernel (rbblock32.hip): the stream stays in registers across the three
+// pairs; bit-identical to three launch_rbpair32 calls. y must not alias x (acc may alias y).
+struct RbBlock32Call {
+    TensorRef x, y, acc;
+    const int* lens = nullptr;
+    int batch = 1, tmax = 0;
+    float slope = 0.1f;
+    float scale = 1.f;
+    int scale_div = 0;
+    int post_act = 0;
+    float post_slope = 0.f;
+};
+bool rbblock32_supported(int channels, int kt, const int* dils, int ndil);
+hipError_t launch_rbblock32(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock32Call& c, hipStream_t s);
 // one WaveNet layer of the flow (gated conv + 1x1 res/skip conv + the two adds) as one fp32 kernel (wavenet32.hip); h_out must not alias h
 struct WaveNet32Call {
     TensorRef h, h_out, outputs;
