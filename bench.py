@@ -845,6 +845,10 @@ def main():
                 wsum = lambda f: (sum(ents[kk].get(f) * groups[kk]["ms"] for kk in dom_members) / dom["ms"]) if all(ents[kk].get(f) is not None for kk in dom_members) else None
                 res["roofline"]["mfma_busy_frac"] = wsum("mfma_busy_frac")
                 res["roofline"]["lds_bank_conflict_frac"] = wsum("lds_bank_conflict_frac")
+                # the shader clock the dominant launches ran at (GRBM_GUI_ACTIVE / 8 XCDs / duration, tools/pmc_mfma.py): 2.36-2.42 GHz for the fp32
+                # kernels, 1.25-1.8 GHz for the MFMA-dense 16-bit ones (power budget) — the nominal peaks assume 2.4 GHz
+                res["roofline"]["clock_ghz_estimate"] = wsum("clock_ghz_estimate")
+                res["roofline"]["mfma_busy_frac_of_elapsed_clocks"] = wsum("mfma_busy_frac_of_elapsed_clocks")
                 res["roofline"]["pmc_source"] = os.path.relpath(art[0], ROOT)
             conv_ms = sum(g["ms"] for kk, g in groups.items() if kk.startswith("k"))
             conv_flop = sum(g["flop"] for kk, g in groups.items() if kk.startswith("k"))

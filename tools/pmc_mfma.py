@@ -8,9 +8,13 @@ mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)  — t
 pipe is busy (MI355X_MICROARCH.md: 64 cycles per v_mfma_f32_32x32x2_f32, 32 per 32x32x16 bf16), SQ_BUSY_CU_CYCLES once per
 cycle a CU has a wave: the fraction of the time CUs are occupied that their four matrix pipes are issuing. A second figure
 normalises by the whole launch instead: busy / (1024 SIMDs x launch duration x 2.4 GHz) (lower bound: the clock under load is
-2.15-2.35 GHz). lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles lost to conflicts over LDS-busy cycles).
+2.15-2.35 GHz in fp32 mode). clock_ghz_estimate = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / launch duration: the shader clock the
+launch actually ran at (fp32 kernels: 2.36-2.42 GHz; MFMA-dense 16-bit kernels: 1.25-1.8 GHz — the power budget; launches under ~100 us
+are dominated by the counter window and are not meaningful). mfma_busy_frac_of_elapsed_clocks = busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8):
+the same fraction against the clocks that really elapsed. lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles lost to conflicts over LDS-busy cycles).
 
-usage: pmc_mfma.py OUT.json DIR_OR_CSV_GLOB..."""
+usage: pmc_mfma.py OUT.json DIR_OR_CSV_GLOB...
+       pmc_mfma.py --refresh FILE.json...      (recompute the derived fields of an existing artefact from its own counters_per_launch)"""
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_common import bench_key, source_sha16
@@ -22,6 +26,36 @@ if "--workload" in sys.argv:
     i = sys.argv.index("--workload")
     WORKLOAD_TAG = sys.argv[i + 1]
     del sys.argv[i:i + 2]
+
+
+
+def derive(e):
+    """Derived fractions of one kernel entry from its per-launch counters (and its average duration, if the trace had it)."""
+    per, us = e["counters_per_launch"], e.get("avg_duration_us")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
+        if per.get("SQ_BUSY_CU_CYCLES"):
+            e["mfma_busy_frac"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * per["SQ_BUSY_CU_CYCLES"])
+        if us:
+            e["mfma_busy_frac_of_launch_at_2p4ghz"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 1e3 * 2.4)
+        if per.get("GRBM_GUI_ACTIVE"):
+            e["mfma_busy_frac_of_elapsed_clocks"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * per["GRBM_GUI_ACTIVE"] / 8.0)
+    if per.get("GRBM_GUI_ACTIVE") and us:
+        e["clock_ghz_estimate"] = per["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)
+    if per.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_bank_conflict_frac"] = per.get("SQ_LDS_BANK_CONFLICT", 0.0) / per["SQ_LDS_IDX_ACTIVE"]
+    return e
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--refresh":
+    for path in sys.argv[2:]:
+        d = json.load(open(path))
+        for e in d["kernels"].values():
+            derive(e)
+        for e in d["by_bench_key"].values():
+            derive(e)
+        json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+        print("refreshed", path)
+    sys.exit(0)
 
 out = sys.argv[1]
 ctr = collections.defaultdict(lambda: collections.defaultdict(float))   # kernel -> counter -> sum
@@ -52,14 +86,7 @@ for name, c in ctr.items():
     e = {"counters_per_launch": per, "launches_sampled": max(n.values())}
     if dur_n[name]:
         e["avg_duration_us"] = dur_ns[name] / dur_n[name] / 1e3
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
-        if per.get("SQ_BUSY_CU_CYCLES"):
-            e["mfma_busy_frac"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * per["SQ_BUSY_CU_CYCLES"])
-        if dur_n[name]:
-            e["mfma_busy_frac_of_launch_at_2p4ghz"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * (dur_ns[name] / dur_n[name]) * 2.4)
-    if per.get("SQ_LDS_IDX_ACTIVE"):
-        e["lds_bank_conflict_frac"] = per.get("SQ_LDS_BANK_CONFLICT", 0.0) / per["SQ_LDS_IDX_ACTIVE"]
-    res[name] = e
+    res[name] = derive(e)
     key = bench_key(name)
     if key and (key not in by_key or e["launches_sampled"] > by_key[key]["launches_sampled"]):
         by_key[key] = dict(e, kernel_name=name)
