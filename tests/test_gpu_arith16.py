@@ -493,3 +493,35 @@ def test_whole_fp32_resblock_kernel_is_bit_identical_to_the_pair_path(pkg, full_
     for mode in (0, 1):
         for x, y in zip(outs[(True, mode, 0)][0], outs[(True, mode, 1)][0]):
             assert np.array_equal(x, y)
+
+
+def test_kernel_tuning_knobs_belong_to_the_handle_that_read_them(pkg, full_bytes, monkeypatch):
+    """The launch functions' tuning knobs (kernels.h KernelKnobs) are read when a model is loaded and travel with that handle: two handles
+    loaded under different environments keep their own kernel choices while both are alive and their calls interleave — here the stride-8
+    upsamplers of the f16 mode (VITS_NO_CONVT16L: conv16's polyphase epilogue instead of the four-phase streaming kernel) and the
+    LayerNorm tile (VITS_LN_TW=64) — and the PCM is the same bit for bit."""
+    ids = pkg.synth_ids(3, 48, ids_seed=77)
+    monkeypatch.setenv("VITS_NO_CONVT16L", "1")
+    monkeypatch.setenv("VITS_LN_TW", "64")
+    a = pkg.Model(full_bytes)
+    monkeypatch.delenv("VITS_NO_CONVT16L")
+    monkeypatch.delenv("VITS_LN_TW")
+    b = pkg.Model(full_bytes)
+    try:
+        outs, names = {}, {}
+        for rnd in range(2):
+            for tag, m in (("a", a), ("b", b)):
+                if rnd == 0:
+                    m.set_arith(pkg.ARITH_F16)
+                    m.prof_enable(True)
+                outs[(tag, rnd)] = m.process_batch(ids, noise_seed=5)
+                names.setdefault(tag, set()).update(k["name"] for k in m.prof_report()["kernels"])
+        assert not any("|SL" in n for n in names["a"]), sorted(names["a"])
+        assert any("|SL" in n for n in names["b"]), sorted(names["b"])
+        for rnd in range(2):
+            assert np.array_equal(outs[("a", rnd)][1], outs[("b", rnd)][1])
+            for x, y in zip(outs[("a", rnd)][0], outs[("b", rnd)][0]):
+                assert np.array_equal(x, y)
+    finally:
+        a.close()
+        b.close()

@@ -38,6 +38,7 @@ VITS_API const char* vits_last_error(void) { return g_last_error.c_str(); }
 // One call at a time per model handle, enforced (busy_guard.h). Distinct handles run concurrently.
 #define VITS_ENTER(model, ret)                                                                                                          \
     vits::BusyGuard busy_guard_((model) ? &const_cast<vits_model*>(model)->eng.busy : nullptr);                                        \
+    vits::KernelKnobsScope kernel_knobs_scope_((model) ? &(model)->eng.knobs.kernel : nullptr);                                        \
     if ((model) && !busy_guard_.entered()) {                                                                                                 \
         set_err("model busy: another call is in progress on this handle (one call at a time per model; use one handle per thread)"); \
         return ret;                                                                                                                     \

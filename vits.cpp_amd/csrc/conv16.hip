@@ -804,7 +804,7 @@ int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int ba
     // c_out multiple of 128: 128 x 128 tiles (default) read the input tile once per 128 rows at 3 blocks per CU. 128 x 256 tiles
     // (VITS_T16_TILE0=1) hold one block per CU (196 VGPRs: K loop and epilogue run back to back: 33.6 ms per step); 64 x 256 tiles
     // (VITS_T16_TILE0=2: 29.6 ms) overlap epilogue traffic with MFMAs but fetch the input once per 64 rows.
-    static const int tile0 = getenv("VITS_T16_TILE0") ? atoi(getenv("VITS_T16_TILE0")) : 0;
+    const int tile0 = kernel_knobs().t16_tile0;
     if (epi == EPI_GATE) tile = small_t ? 3 : 1;
     else if (rows % 128 == 0) tile = small_t ? 3 : (tile0 == 1 ? 0 : tile0 == 2 ? 1 : tile0 == 3 ? 5 : tile0 == 4 ? 3 : 6);
     else if (rows % 64 == 0) tile = small_t ? 3 : 1;

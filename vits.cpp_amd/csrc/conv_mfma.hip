@@ -987,10 +987,10 @@ static TileShape tile_shape(int tile) {
 int choose_conv_tile(int rows, int epi, int t_hint) {
     // rows <= 64 (few MFMAs per staged tile): 128-column tiles -> twice as many independent blocks per CU keep more
     // loads in flight (measured 120.5 -> 116.4 ms per step); VITS_NARROW_TILES=0 restores 256-column tiles
-    static const int narrow = getenv("VITS_NARROW_TILES") ? atoi(getenv("VITS_NARROW_TILES")) : 64;
+    const int narrow = kernel_knobs().narrow_tiles;
     const bool small_t = t_hint <= 128 || (narrow && rows <= narrow);
     if (epi == EPI_GATE) return small_t ? TILE_64x64 : TILE_64x256;
-    static const int t128 = getenv("VITS_TILE128") ? atoi(getenv("VITS_TILE128")) : 1;
+    const int t128 = kernel_knobs().tile128;
     if (rows % 128 == 0 && t128) return TILE_128x128;
     if (rows % 64 == 0) return small_t ? TILE_64x64 : TILE_64x256;
     return small_t ? TILE_32x64 : TILE_32x256;
@@ -1204,7 +1204,7 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         };
         // (k <= 3: 1024 — a short K loop costs a small tile little, and e.g. the encoder's 192 -> 768 FFN conv at batch 64 x 128 tokens is
         // 768 blocks of 64 x 128 = 1.5 rounds of the 512 resident blocks, but 3 even rounds of 32 x 128: 82 -> 74 us)
-        static const int64_t min_blocks_env = getenv("VITS_MIN_BLOCKS") ? atoi(getenv("VITS_MIN_BLOCKS")) : 0;
+        const int64_t min_blocks_env = kernel_knobs().min_blocks;
         const int64_t min_blocks = min_blocks_env > 0 ? min_blocks_env : (w.kt <= 3 ? 1024 : 512);
         if (blocks(tile) < min_blocks && (tile == TILE_128x128 || tile == TILE_64x256)) tile = TILE_64x64;  // 64 x 128
         if (blocks(tile) < min_blocks && (tile == TILE_64x64 || tile == TILE_32x256)) tile = TILE_32x64;    // 32 x 128
@@ -1214,7 +1214,7 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         // 128-column tile streams the WHOLE input in through its one producer wave, and that stream, not the MFMA chain, is the
         // launch time (768 -> 192 FFN conv, k = 3, 128 tokens: 78 us for a 31 us chain). Blocks of four row tiles x ONE 32-column
         // strip need a quarter of the input each. Same per-output accumulation order (the tile shape never changes it).
-        static const bool no_narrow = getenv("VITS_NO_NARROW") != nullptr;
+        const bool no_narrow = kernel_knobs().no_narrow;
         const int dil_eff = w.kt == 1 ? 1 : c.dil;
         const bool shape_ok = dil_eff == 1 && ((w.epi == EPI_STD && w.kt <= 3) || (w.epi == EPI_GATE && w.kt == 5));
         const TileShape t2 = tile_shape(tile);
@@ -1222,7 +1222,7 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         // 1x1 convs (QKV / output / projection convs of the encoder, the flow's pre / post convs): the narrow tile on large grids too —
         // 192 -> 576 at batch 64 x 128 tokens 34 -> 26 us, 192 -> 192 21 -> 13 us; at 1024 tokens (config 5) the 1x1 convs of a step 0.83 ->
         // 0.65 ms (bf16 run), 1.34 -> 1.05 ms (fp32 run). VITS_NARROW_K1 = longest sequence that takes it (0: small grids only)
-        static const int narrow_k1 = getenv("VITS_NARROW_K1") ? atoi(getenv("VITS_NARROW_K1")) : (1 << 30);
+        const int narrow_k1 = kernel_knobs().narrow_k1;
         const bool k1_short = narrow_k1 > 0 && w.epi == EPI_STD && w.kt == 1 && ncols_max <= narrow_k1;
         if (!no_narrow && shape_ok && (nb <= 128 || k1_short)) tile = TILE_NARROW;
     }
@@ -1280,13 +1280,13 @@ hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, Co
     {
         // third LDS buffer (DMA two chunks ahead) where a chunk is less MFMA work than a DMA round trip (~2.5 us = 6k cycles):
         // taps x (MFMAs per k-step) x 16 k-steps x 64 cycles
-        static const int nbuf_env = getenv("VITS_NBUF") ? atoi(getenv("VITS_NBUF")) : 0;
+        const int nbuf_env = kernel_knobs().nbuf;
         const TileShape t3 = ts;
         const bool short_chunk = w.kt * t3.mr * t3.nr * 1024 < 8000 && w.nchunks >= 3 && bn == 128;
         p.nbuf = nbuf_env == 2 || nbuf_env == 3 ? nbuf_env : (short_chunk ? 3 : 2);
         if (w.nchunks < 2 || (size_t)p.nbuf * CK * ((p.xw + 3 + VITS_XWP_GRAN - 1) / VITS_XWP_GRAN * VITS_XWP_GRAN) * 4 > 150 * 1024) p.nbuf = 2;
         // latency-bound launch on a small tile whose whole input fits in LDS: cooperative one-shot fill (see the kernel)
-        static const bool no_oneshot = getenv("VITS_NO_ONESHOT") != nullptr;
+        const bool no_oneshot = kernel_knobs().no_oneshot;
         const int64_t nblocks = (int64_t)((ncols_max + bn - 1) / bn) * ((w.mtiles_used + t3.wm * t3.mr - 1) / (t3.wm * t3.mr)) * c.batch;
         p.oneshot = 0;
         if (!no_oneshot && t3.mr * t3.nr <= 2 && nblocks <= 512 && w.nchunks >= 2 &&
@@ -1310,7 +1310,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     // producer-wave path for every compile-time-dilation conv: with dwordx4 LDS-DMA it also wins for single-chunk inputs
     // (c_in = 32: 109 -> 120 TFLOP/s on the k = 11 layers; with dword DMA it lost 8 % there). VITS_DB_MIN=2 restores the
     // register-staged kernels for them.
-    static const int db_min = getenv("VITS_DB_MIN") ? atoi(getenv("VITS_DB_MIN")) : 1;
+    const int db_min = kernel_knobs().db_min;
     const bool db = w.nchunks >= db_min;
 #ifdef VITS_MICRO_KT  // developer microbenchmark (tools/conv_micro.hip): instantiate a single (taps, dilation) pair
     VITS_GO(VITS_MICRO_KT, VITS_MICRO_DIL, EPI_STD);

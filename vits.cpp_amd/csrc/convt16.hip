@@ -441,10 +441,10 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 bool convt16_stream_supported(const PackedConv& w) {
-    static const bool off = getenv("VITS_NO_CONVT16S") != nullptr;
+    const bool off = kernel_knobs().no_convt16s;
     // (VITS_CONVT16S_ALL=1: the one-row-tile-at-a-time kernel also for stride 8 — the slow first version, kept for the comparison)
-    static const bool all = getenv("VITS_CONVT16S_ALL") != nullptr;
-    static const bool no_lines = getenv("VITS_NO_CONVT16L") != nullptr;  // (the four-phase variant for strides that are multiples of 4)
+    const bool all = kernel_knobs().convt16s_all;
+    const bool no_lines = kernel_knobs().no_convt16l;  // (the four-phase variant for strides that are multiples of 4)
     if (off || w.epi != EPI_CONVT || w.kt != 2 || !w.wp16 || w.cin % 64 != 0 || w.cout % 32 != 0 || w.rows % 32 != 0 || w.cin > 512) return false;
     if (w.rows <= 128 || all) return true;
     return !no_lines && w.ct_stride % 4 == 0;
@@ -475,7 +475,7 @@ struct CtChoice {
     int lines_bn = 0, nr = 0, csplit = 0, rs = 0;
 };
 CtChoice ct_choice(const PackedConv& w) {
-    static const bool all_s = getenv("VITS_CONVT16S_ALL") != nullptr;
+    const bool all_s = kernel_knobs().convt16s_all;
     CtChoice c;
     if (w.rows > 128 && w.ct_stride % 4 == 0 && !all_s) {
         c.lines_bn = w.cin > 256 ? 64 : 128;

@@ -128,6 +128,7 @@ struct Knobs {
     int front_prio = 1;          // VITS_FRONT_PRIO=0: the front-end stream of pipelined batches at normal instead of high priority
     bool keep_stage_sum32 = false;  // VITS_KEEP_STAGE_SUM32: 16-bit vocoder: also store the fp32 resblock sum of a stage's last resblock (nobody reads it)
     bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
+    KernelKnobs kernel;          // the launch functions' own tuning knobs (kernels.h), installed per call by KernelKnobsScope
     void read();
 };
 

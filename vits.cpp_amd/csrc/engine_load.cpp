@@ -253,6 +253,7 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
         return false;
     }
     knobs.read();
+    KernelKnobsScope kernel_knobs_scope(&knobs.kernel);  // (load decides which fused kernels a stage can take)
     prof.attach = knobs.prof_attach;
     if (!dry_run_ && !knobs.no_pipeline) {
         // The front-end stream of pipelined batches (vits_model_submit_batch) is created HERE, right behind the main stream, not on first

@@ -41,6 +41,7 @@ void Knobs::read() {
     if (const char* e = std::getenv("VITS_FRONT_PRIO")) front_prio = std::atoi(e);
     no_pipeline = flag("VITS_NO_PIPELINE");
     keep_stage_sum32 = flag("VITS_KEEP_STAGE_SUM32");
+    kernel = KernelKnobs::from_env();
 }
 
 // ---- reference noise stream (vits.cpp:31 global engine; ggml-util.h:187-199 fresh distribution per tensor) ----

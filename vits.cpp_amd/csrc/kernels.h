@@ -11,9 +11,85 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace vits {
+
+// Tuning knobs of the launch functions: which tile shape / kernel variant a launch takes. None of them changes a bit of a result (GPU test:
+// tools/knob_identity.py). They are read from the environment ONCE per model handle, when it is loaded (Engine::knobs.kernel), and installed
+// for the calling thread around every engine entry point (KernelKnobsScope in the ABI); the model-free entry points (vits_op_*) and the
+// developer harnesses under tools/ see the process defaults, read at first use. Header-only so that the harnesses that include a single
+// kernel file link without the engine.
+struct KernelKnobs {
+    int narrow_tiles = 64;       // VITS_NARROW_TILES: fp32 convs of at most this many rows take 128-column tiles (0: 256-column tiles)
+    int tile128 = 1;             // VITS_TILE128=0: no 128 x 128 tiles in conv_mfma
+    int min_blocks = 0;          // VITS_MIN_BLOCKS: grid size under which conv_mfma steps down to a smaller tile (0: 1024 for k <= 3, else 512)
+    bool no_narrow = false;      // VITS_NO_NARROW: no 32-column strips for tiny grids / 1x1 convs
+    int narrow_k1 = 1 << 30;     // VITS_NARROW_K1: longest sequence whose 1x1 convs take the narrow tile (0: small grids only)
+    int nbuf = 0;                // VITS_NBUF=2|3: LDS ring depth of conv_mfma (0: chosen per launch)
+    bool no_oneshot = false;     // VITS_NO_ONESHOT: no cooperative one-shot fill for latency-bound launches
+    int db_min = 1;              // VITS_DB_MIN=2: register-staged kernels for single-chunk inputs
+    int t16_tile0 = 0;           // VITS_T16_TILE0: conv16 tile for c_out multiples of 128 (0: 128 x 128)
+    bool no_convt16s = false;    // VITS_NO_CONVT16S: 16-bit transposed convs through conv16's polyphase epilogue
+    bool convt16s_all = false;   // VITS_CONVT16S_ALL: the one-row-tile streaming kernel also for stride 8
+    bool no_convt16l = false;    // VITS_NO_CONVT16L: no four-phase lines kernel for strides that are multiples of 4
+    bool att_valu = false;       // VITS_ATT_VALU: attention without the matrix cores
+    int att_nw = 0;              // VITS_ATT_NW=4|8: waves per attention block (0: by LDS footprint)
+    int att_short = 512;         // VITS_ATT_SHORT: longest sequence (tokens) for the short-sequence attention variant (0: off)
+    int ln_tw = 32;              // VITS_LN_TW=64: LayerNorm tiles of 64 time steps (sixteen waves)
+    bool rbb_c128 = true;        // VITS_RBB_C128=0: C = 128, k = 3 resblocks as fused pairs instead of rbblock16
+    bool rbb_c64k11 = false;     // VITS_RBB_C64K11: C = 64, k = 11 resblocks through rbblock16 as well
+    int fuse16_maxc = 256;       // VITS_FUSE16_MAXC: widest stage whose 16-bit conv pairs are fused
+    bool fuse32_c128 = true;     // VITS_FUSE32_C128=0: fp32 k = 3 pairs at C = 128 as two launches
+    int wn16_ncw = 1;            // VITS_WN16_NCW=2: 16-bit WaveNet layer with six waves, both column tiles each
+    int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
+    static KernelKnobs from_env() {
+        KernelKnobs k;
+        auto num = [](const char* name, int& v) {
+            if (const char* e = getenv(name)) v = atoi(e);
+        };
+        auto flag = [](const char* name, bool& v) { v = getenv(name) != nullptr; };
+        num("VITS_NARROW_TILES", k.narrow_tiles);
+        num("VITS_TILE128", k.tile128);
+        num("VITS_MIN_BLOCKS", k.min_blocks);
+        flag("VITS_NO_NARROW", k.no_narrow);
+        num("VITS_NARROW_K1", k.narrow_k1);
+        num("VITS_NBUF", k.nbuf);
+        flag("VITS_NO_ONESHOT", k.no_oneshot);
+        num("VITS_DB_MIN", k.db_min);
+        num("VITS_T16_TILE0", k.t16_tile0);
+        flag("VITS_NO_CONVT16S", k.no_convt16s);
+        flag("VITS_CONVT16S_ALL", k.convt16s_all);
+        flag("VITS_NO_CONVT16L", k.no_convt16l);
+        flag("VITS_ATT_VALU", k.att_valu);
+        num("VITS_ATT_NW", k.att_nw);
+        num("VITS_ATT_SHORT", k.att_short);
+        num("VITS_LN_TW", k.ln_tw);
+        if (const char* e = getenv("VITS_RBB_C128")) k.rbb_c128 = atoi(e) != 0;
+        flag("VITS_RBB_C64K11", k.rbb_c64k11);
+        num("VITS_FUSE16_MAXC", k.fuse16_maxc);
+        if (const char* e = getenv("VITS_FUSE32_C128")) k.fuse32_c128 = atoi(e) != 0;
+        num("VITS_WN16_NCW", k.wn16_ncw);
+        num("VITS_FLOW_NCW", k.flow_ncw);
+        return k;
+    }
+};
+namespace detail {
+inline thread_local const KernelKnobs* tl_kernel_knobs = nullptr;
+}
+inline const KernelKnobs& kernel_knobs() {
+    if (detail::tl_kernel_knobs) return *detail::tl_kernel_knobs;
+    static const KernelKnobs process_default = KernelKnobs::from_env();
+    return process_default;
+}
+struct KernelKnobsScope {
+    const KernelKnobs* prev;
+    explicit KernelKnobsScope(const KernelKnobs* k) : prev(detail::tl_kernel_knobs) { detail::tl_kernel_knobs = k; }
+    ~KernelKnobsScope() { detail::tl_kernel_knobs = prev; }
+    KernelKnobsScope(const KernelKnobsScope&) = delete;
+    KernelKnobsScope& operator=(const KernelKnobsScope&) = delete;
+};
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a function ON A DEVICE. A kernel instantiation that needs more than
 // 64 KB of LDS raises its limit once per device: the once-flag is one bit per device, so a process that loads models on several

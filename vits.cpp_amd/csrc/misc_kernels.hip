@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
 
 hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const float* rel_k, const float* rel_v, TensorRef out, const int* lens, int batch,
                                 int heads, int head_dim, int tmax, int window, float q_scale, hipStream_t s, GgmlTables tabs) {
-    static const bool valu_only = getenv("VITS_ATT_VALU") != nullptr;
+    const bool valu_only = kernel_knobs().att_valu;
     // matrix-core version. The number of waves (= how the key tiles and the d tiles are dealt out) does not change a single sum, so it may
     // depend on the launch: four waves while two or more blocks fit the LDS of a CU (up to ~1200 tokens: 1024 ids 0.178 ms against 0.222
     // with six waves), eight once the scores of a block leave room for one block only (2049 tokens: 0.87 against 1.29 ms with four)
@@ -551,7 +551,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
         const size_t ldsm = sizeof(float) * ((((size_t)ATT_Q * head_dim + ATT_Q * (2 * window + 1) + 3) & ~(size_t)3) + (size_t)ATT_Q * att_lp(tmax));
         if (ldsm <= 160 * 1024) {
             dim3 gridm((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
-            static const int nw_env = getenv("VITS_ATT_NW") ? atoi(getenv("VITS_ATT_NW")) : 0;
+            const int nw_env = kernel_knobs().att_nw;
             int nw = 2 * ldsm > 160 * 1024 ? 8 : 4;
             if (nw_env == 4 || nw_env == 8) nw = nw_env;
 #define VITS_ATTM_LAUNCH(NW, MS, SH)                                                                                                                   \
@@ -563,7 +563,7 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
         VITS_KLAUNCH((rel_attention_mfma_kernel<NW, MS, SH>), gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
                            out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0, tabs.exp);                                            \
     } while (0)
-            static const int short_max = getenv("VITS_ATT_SHORT") ? atoi(getenv("VITS_ATT_SHORT")) : 512;  // tokens; 0 disables the short variant
+            const int short_max = kernel_knobs().att_short;  // tokens; 0 disables the short variant
             // (the long variants keep their arrays at 32 k-steps: sized for 24 the four-wave kernel measured 0.22 against 0.18 ms at 1024 tokens)
             if (nw == 4 && head_dim <= 96 && tmax <= short_max) VITS_ATTM_LAUNCH(4, 24, true);
             else if (nw == 4) VITS_ATTM_LAUNCH(4, 32, false);
@@ -688,7 +688,7 @@ hipError_t launch_add_layer_norm(TensorRef x, TensorRef res, const float* gamma,
     // groups in the same order). The small block matters when this kernel shares the chip with another batch's vocoder (vits_model_submit_batch):
     // a 57 KB block only finds room in the tail of a vocoder kernel — stage one of a pipelined f16 batch took 10.2 ms of wall with it, 8.8 with
     // the small one (alone: 1.91 -> 1.87 ms).
-    static const int tw_env = getenv("VITS_LN_TW") ? atoi(getenv("VITS_LN_TW")) : 32;
+    const int tw_env = kernel_knobs().ln_tw;
     const int tw = tw_env == 64 ? 64 : 32;
     const size_t lds = sizeof(float) * ((size_t)channels * tw + 2 * tw * LN_GROUPS);
     if (lds > 150 * 1024) return hipErrorInvalidValue;

@@ -357,12 +357,12 @@ static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
 }
 
 bool rbblock16_supported(int channels, int kt, const int* dils, int ndil) {
-    static const bool c128 = getenv("VITS_RBB_C128") ? atoi(getenv("VITS_RBB_C128")) != 0 : true;
+    const bool c128 = kernel_knobs().rbb_c128;
     if (channels == 128) return c128 && kt == 3 && ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
     if (!(channels == 32 || channels == 64) || !(kt == 3 || kt == 7 || kt == 11)) return false;
     // C = 64, k = 11: with 1.45 x the MFMA work the whole-resblock kernel is bound by the matrix cores (at the clock the power budget
     // leaves them) and loses to three fused pairs, 1.59 against 1.45 ms per step (batch 64 x 128 ids); VITS_RBB_C64K11=1 runs it anyway
-    static const bool c64k11 = getenv("VITS_RBB_C64K11") != nullptr;
+    const bool c64k11 = kernel_knobs().rbb_c64k11;
     if (channels == 64 && kt == 11 && !c64k11) return false;
     return ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
 }

@@ -421,7 +421,7 @@ static hipError_t launch_rb_kt(int kt, int dil, const RbPairParams& p, int batch
 
 bool rbpair16_supported(int channels, int kt, int dil) {
     // VITS_FUSE16_MAXC=64 keeps the C = 128 pairs on two kernels
-    static const int maxc = getenv("VITS_FUSE16_MAXC") ? atoi(getenv("VITS_FUSE16_MAXC")) : 256;
+    const int maxc = kernel_knobs().fuse16_maxc;
     if (!(kt == 3 || kt == 7 || kt == 11) || channels > maxc) return false;
     if (channels == 32 || channels == 64 || channels == 128 || channels == 256) return dil == 1 || dil == 3 || dil == 5;
     return false;

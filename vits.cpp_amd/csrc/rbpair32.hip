@@ -265,7 +265,7 @@ bool rbpair32_supported(int channels, int kt, int dil) {
     if (!(dil == 1 || dil == 3 || dil == 5)) return false;
     if (channels == 32 || channels == 64) return true;
     // C = 128: only the k = 3 pairs — their 128-column tile with its small halo is 74 KB (two blocks per CU); k = 7 / 11 would be 84-94 KB
-    static const bool c128 = getenv("VITS_FUSE32_C128") ? atoi(getenv("VITS_FUSE32_C128")) != 0 : true;
+    const bool c128 = kernel_knobs().fuse32_c128;
     return channels == 128 && kt == 3 && c128;
 }
 

@@ -858,7 +858,7 @@ hipError_t launch_wavenet16(const PackedConv& in, const PackedConv& rs, const Wa
     p.w_rs16 = rs.wp16;
     const size_t ldsz = (size_t)(H / 8) * (64 + KT - 1) * 16;
     dim3 grid((c.tmax + 63) / 64, c.batch);
-    static const int ncw = getenv("VITS_WN16_NCW") ? atoi(getenv("VITS_WN16_NCW")) : 1;  // (2: six waves, both column tiles each — measured 40.6 vs 38.4 us per layer)
+    const int ncw = kernel_knobs().wn16_ncw;  // (2: six waves, both column tiles each — measured 40.6 vs 38.4 us per layer)
     if (ncw == 1) {
         if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((wavenet16_kernel<H, KT, true, 1>), grid, dim3(4 * H), ldsz, s, p);
         else VITS_KLAUNCH((wavenet16_kernel<H, KT, false, 1>), grid, dim3(4 * H), ldsz, s, p);
@@ -905,7 +905,7 @@ hipError_t launch_flow_couple16(const PackedConv& pre, const PackedConv* in, con
     constexpr int H = 192, XS = 64 + 4, NGRP = H / 8, LB_N = H + 2 * 4 * 2 * H + 96;
     const size_t ldsz = (size_t)(NGRP * XS + NGRP * 64) * 16 + (size_t)LB_N * 4;
     // six waves owning both column tiles of their channel group (VITS_FLOW_NCW=1: twelve waves, one column tile each)
-    static const int ncw = getenv("VITS_FLOW_NCW") ? atoi(getenv("VITS_FLOW_NCW")) : 2;
+    const int ncw = kernel_knobs().flow_ncw;
     dim3 grid((c.tmax + 47) / 48, c.batch);
     if (ncw == 1) {
         if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 1>), grid, dim3(768), ldsz, s, p);
