@@ -137,6 +137,41 @@ int main() {
                     if (((xcc << 16) | ((hw >> 8) & 0xff)) != want) continue;
                     tl.push_back({(q[0] - tmin0) / 100.0, (q[1] - tmin0) / 100.0, (q[2] - tmin0) / 100.0, (q[3] - tmin0) / 100.0});
                 }
+                {
+                    std::vector<unsigned long long> we(8 * 65536);
+                    hipMemcpyFromSymbol(we.data(), HIP_SYMBOL(vits_wave_end), we.size() * 8);
+                    std::vector<unsigned long long> ws(8 * 65536);
+                    hipMemcpyFromSymbol(ws.data(), HIP_SYMBOL(vits_wave_start), ws.size() * 8);
+                    std::vector<std::array<double, 9>> tws;
+                    for (size_t i = 0; i < nb; ++i) {
+                        const unsigned long long* q = &ph[8 * i];
+                        if (!q[0] || !q[3] || q[3] < q[0]) continue;
+                        const unsigned hw = (unsigned)q[6], xcc = (unsigned)q[7] & 0xf;
+                        if (((xcc << 16) | ((hw >> 8) & 0xff)) != want) continue;
+                        std::array<double, 9> a{};
+                        for (int w = 0; w < 5; ++w) a[w] = ws[8 * i + w] ? ((double)ws[8 * i + w] - (double)tmin0) / 100.0 : -1.0;
+                        // HW_ID: [3:0] wave slot, [5:4] SIMD
+                        for (int k = 0; k < 3; ++k) a[5 + k] = (double)((ws[8 * i + 5 + k] >> 4) & 3);
+                        a[8] = (q[2] - tmin0) / 100.0;
+                        tws.push_back(a);
+                    }
+                    std::sort(tws.begin(), tws.end());
+                    for (size_t i = 12; i < tws.size() && i < 18; ++i)
+                        printf("   cu0 block %2zu: waves start %8.2f %8.2f %8.2f %8.2f producer %8.2f | SIMD of wave 0 / 1 / producer: %.0f %.0f %.0f | kloop-end %8.2f\n", i, tws[i][0], tws[i][1], tws[i][2], tws[i][3], tws[i][4], tws[i][5], tws[i][6], tws[i][7], tws[i][8]);
+                    std::vector<std::array<double, 7>> tw;
+                    for (size_t i = 0; i < nb; ++i) {
+                        const unsigned long long* q = &ph[8 * i];
+                        if (!q[0] || !q[3] || q[3] < q[0]) continue;
+                        const unsigned hw = (unsigned)q[6], xcc = (unsigned)q[7] & 0xf;
+                        if (((xcc << 16) | ((hw >> 8) & 0xff)) != want) continue;
+                        std::array<double, 7> a{(q[0] - tmin0) / 100.0, (q[2] - tmin0) / 100.0, 0, 0, 0, 0, 0};
+                        for (int w = 0; w < 5; ++w) a[2 + w] = we[8 * i + w] ? ((double)we[8 * i + w] - (double)tmin0) / 100.0 : -1.0;
+                        tw.push_back(a);
+                    }
+                    std::sort(tw.begin(), tw.end());
+                    for (size_t i = 12; i < tw.size() && i < 18; ++i)
+                        printf("   cu0 block %2zu: start %8.2f kloop-end %8.2f | waves retire: %8.2f %8.2f %8.2f %8.2f producer %8.2f\n", i, tw[i][0], tw[i][1], tw[i][2], tw[i][3], tw[i][4], tw[i][5], tw[i][6]);
+                }
                 std::sort(tl.begin(), tl.end());
                 for (size_t i = 8; i < tl.size() && i < 20; ++i) printf("   cu0 block %2zu: start %8.2f  kloop %8.2f .. %8.2f  end %8.2f\n", i, tl[i][0], tl[i][1], tl[i][2], tl[i][3]);
             }
@@ -174,6 +209,18 @@ int main() {
             }
             const int nch = (CIN_ + 31) / 32 - 1;
             if (n) printf("producer per chunk (cycles, 3-buffer path): issue %.0f | DMA wait %.0f | post-process %.0f | barrier %.0f\n", s4[0] / n / nch, s4[1] / n / nch, s4[2] / n / nch, s4[3] / n / nch);
+        }
+        {
+            std::vector<unsigned long long> eb(8 * 65536);
+            hipMemcpyFromSymbol(eb.data(), HIP_SYMBOL(vits_epi_buf), eb.size() * 8);
+            double d[6] = {0, 0, 0, 0, 0, 0}; size_t n = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                const unsigned long long* q = &eb[8 * i];
+                if (!q[0] || !q[6] || !q[2]) continue;  // (only blocks that took the wide path stamp 1..5)
+                for (int k = 0; k < 6; ++k) d[k] += (double)(q[k + 1] - q[k]);
+                ++n;
+            }
+            if (n) printf("epilogue of wave 0 (cycles, %zu wide blocks): entry->setup %.0f | setup->sub-tile 0 %.0f | sub-tile 0 %.0f | 1 %.0f | 2 %.0f | 3 + exit %.0f\n", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
         }
         std::sort(kls.begin(), kls.end());
         printf("phases over %zu blocks (tile %dx%d), 10 ns ticks -> us: prologue %.2f  k-loop %.2f (p10 %.2f p90 %.2f)  epilogue %.2f; span %.1f us; blocks*life/span = %.1f resident; shader clock in the K loop %.3f GHz, MFMA issue efficiency of the K loop %.3f\n",

@@ -110,8 +110,42 @@ __device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]
             }                                                                                                       \
         }                                                                                                           \
     } while (0)
+__device__ unsigned long long vits_epi_buf[8 * 65536];  // [block][0..6]: shader clock at the epilogue's entry, in front of its first sub-tile, behind each of (up to) four sub-tiles, at its end
+__device__ unsigned long long vits_wave_end[8 * 65536];  // [block][wave]: 100 MHz clock when wave 0..4 retires
+#define VITS_WSTAMP()                                                                                               \
+    do {                                                                                                            \
+        if (lane == 0) {                                                                                            \
+            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
+            if (lin < 65536) vits_wave_end[8 * lin + wid] = __builtin_amdgcn_s_memrealtime();                       \
+        }                                                                                                           \
+    } while (0)
+__device__ unsigned long long vits_wave_start[8 * 65536];  // [block][wave]: 100 MHz clock at the first instructions of wave 0..4; [5..7]: HW_ID of waves 0, 1, 4
+#define VITS_WSTART()                                                                                               \
+    do {                                                                                                            \
+        if (lane == 0) {                                                                                            \
+            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
+            if (lin < 65536) {                                                                                      \
+                vits_wave_start[8 * lin + wid] = __builtin_amdgcn_s_memrealtime();                                  \
+                if (wid == 0 || wid == 1 || wid == 4) {                                                             \
+                    unsigned hw;                                                                                    \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
+                    vits_wave_start[8 * lin + (wid == 0 ? 5 : wid == 1 ? 6 : 7)] = hw;                             \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#define VITS_ESTAMP(k)                                                                                              \
+    do {                                                                                                            \
+        if (tid == 0) {                                                                                             \
+            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
+            if (lin < 65536) vits_epi_buf[8 * lin + (k)] = __builtin_amdgcn_s_memtime();                           \
+        }                                                                                                           \
+    } while (0)
 #else
 #define VITS_STAMP(k)
+#define VITS_ESTAMP(k)
+#define VITS_WSTAMP()
+#define VITS_WSTART()
 #endif
 
 #ifndef VITS_WAVES_ATTR
@@ -168,6 +202,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
     const int wm = wid / WN, wn = wid % WN;
     const int b = bz;
     const int t0 = bx * BN;
+#ifdef VAR_SETPRIO  // ablation (tools/conv_micro.hip): prologue / producer / epilogue at wave priority 3, the K loop at 0 — no effect on the
+                   // starvation described at the K loop (DESIGN.md 4.1 "what the remaining 20 % are")
+    if constexpr (DB) __builtin_amdgcn_s_setprio(3);
+#endif
+    VITS_WSTART();
     const int len_in = p.len_in ? p.len_in[b] : p.t_in;
     // number of valid GEMM columns for this utterance
     int ncols;
@@ -371,7 +410,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                 }
 #endif
             }
-            if (wid == 4) return;
+            if (wid == 4) {
+                VITS_WSTAMP();
+                return;
+            }
         }
     }
 
@@ -506,7 +548,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                         const float4 a4 = ring[p4][mr];
                         const float av = q == 0 ? a4.x : q == 1 ? a4.y : q == 2 ? a4.z : a4.w;
 #pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[nr], acc[mr][nr], 0, 0, 0);
+                        for (int nr = 0; nr < NR; ++nr) {
+                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[nr], acc[mr][nr], 0, 0, 0);
+#ifdef VAR_NOPS  // ablation: VAR_NOPS x 64 idle cycles behind every MFMA (the next block then launches as soon as this one's producer retires)
+#pragma unroll
+                            for (int z = 0; z < VAR_NOPS; ++z) asm volatile("s_nop 15");
+#endif
+                        }
                     }
                 }
                 ++gstep;
@@ -604,6 +652,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         auto k_loop = [&](auto lr) __attribute__((always_inline)) {
             int buf = 0;
             for (int c = 0; c < p.nchunks; ++c) {
+#ifdef VAR_YIELD  // ablation: the compute waves sleep VAR_YIELD x 64 cycles in front of the last chunk (lets the next block launch there)
+                if (c + 1 == p.nchunks) __builtin_amdgcn_s_sleep(VAR_YIELD);
+#endif
                 compute_chunk(xrow0 + buf * (CK * xw), lr);
                 buf = buf + 1 == p.nbuf ? 0 : buf + 1;
 #ifdef VITS_PHASE_TIMING
@@ -621,8 +672,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
 #endif
             }
         };
+#ifdef VAR_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (LRELU_AT_READ && p.pre_act) k_loop(std::true_type{});
         else k_loop(std::false_type{});
+#ifdef VAR_SETPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         VITS_STAMP(2);
     } else {
         // single LDS buffer (few chunks: nothing to overlap inside the block; other resident blocks hide the latency)
@@ -653,6 +710,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         return;
     }
 #endif
+    VITS_ESTAMP(0);
     const int colbase = t0 + wn * (NR * 32) + (lane & 31);
     const int rowoff = 4 * (lane >> 5);
     if (EPI == EPI_STD) {
@@ -684,9 +742,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                 }
             };
             if (rb) load_res(0, rv[0]);
+            VITS_ESTAMP(1);
 #pragma unroll
             for (int it = 0; it < MR * NR; ++it) {
                 const int mr = it / NR, nr = it % NR;
+                if (it < 4) VITS_ESTAMP(2 + it);
                 {
                     const int tcol = t0 + wn * (NR * 32) + nr * 32 + cq;
                     if (rb && it + 1 < MR * NR) load_res(it + 1, rv[(it + 1) & 1]);
@@ -939,6 +999,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
             }
         }
     }
+    VITS_ESTAMP(6);
+    VITS_WSTAMP();
     VITS_STAMP(3);
 }
 
