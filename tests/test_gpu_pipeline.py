@@ -3,6 +3,7 @@
 The contract of the pipeline is BIT-IDENTITY with vits_model_process_batch (which the other GPU tests pin against the oracle):
 stage one of batch i + 1 runs on the handle's front-end stream under the vocoder of batch i, in its own stage-one arena; every
 kernel is batch-invariant and sees the same operands, so PCM, lengths and frames cannot change — whatever the interleaving."""
+import os
 import threading
 import time
 
@@ -201,3 +202,15 @@ def test_pipeline_survives_failed_submits_and_an_early_close(pkg, full_bytes):
         p2 = m2.process_batch(ids, noise_seed=9)
         for a, b in zip(want[0], p2[0]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_randomised_identities_hold():
+    """tests/fuzz_identity.py with a small budget: random batches / lengths / modes / arithmetic switches on one handle / window sizes /
+    emulated tables — a row alone == the row in its batch, windowed == whole, two pipelined batches == process_batch, 16-bit durations ==
+    fp32 durations (all bit for bit), and the small architecture against the oracle in the same arithmetic. (By hand: 2,400 trials, three
+    seeds, no identity ever failed; the oracle comparison met two isolated fp16 rounding flips, 3 of 1,984 samples.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_identity.py"), "--trials", "120", "--seed", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
