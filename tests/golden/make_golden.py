@@ -441,6 +441,10 @@ def main():
     print("reference mode: frames", int(rtaps["durations"].sum()), "vs HF", int(taps["durations"].sum()), "; samples", rtaps["waveform"].size, "vs", taps["waveform"].size)
     for k, v in taps.items():
         print(k, v.shape, float(np.sqrt((v.astype(np.float64) ** 2).mean())))
+    # (C2) the two lengths SURVEY section 7 step 1 names (T = 8 and 32 ids), full architecture, both modes
+    for T, seed in ((8, 31), (32, 32)):
+        np.savez_compressed(os.path.join(HERE, "full_synth_T%d_taps.npz" % T), **taps_for(parse_model_file(data), T, seed))
+        np.savez_compressed(os.path.join(HERE, "full_synth_T%d_refmode_taps.npz" % T), **taps_for(parse_model_file(data), T, seed, refmode=True))
     # (D) Q6: latents outside the spline interval (duration noise x 4: |0.8 * 4 * n| > 5 for one draw in eight), stage one only
     q = q6_taps_for(parse_model_file(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)), 24, 21, 4.0)
     np.savez(os.path.join(HERE, "tiny_synth_q6_refmode_taps.npz"), **q)

@@ -15,7 +15,7 @@ def _bytes_for(name, pkg, tiny_hf_bytes):
     return pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY if name.startswith("tiny") else pkg.SYNTH_FULL)
 
 
-@pytest.mark.parametrize("fixture", ["tiny_hf_export_taps.npz", "tiny_synth_taps.npz", "full_synth_taps.npz"])
+@pytest.mark.parametrize("fixture", ["tiny_hf_export_taps.npz", "tiny_synth_taps.npz", "full_synth_taps.npz", "full_synth_T8_taps.npz", "full_synth_T32_taps.npz"])
 def test_oracle_hf_mode_reproduces_transformers_taps(pkg, oracle, tiny_hf_bytes, fixture):
     """oracle(VO_MODE_HF) == transformers.VitsModel stage by stage (<= 1e-4 of each tap's RMS; durations exact).
     tiny_hf_export.ggml was written by the REFERENCE'S OWN exporter (scripts/export_vits.py), so this also pins the reader."""
@@ -27,7 +27,8 @@ def test_oracle_hf_mode_reproduces_transformers_taps(pkg, oracle, tiny_hf_bytes,
         assert rel_err(r[name], g[name]) < 1e-4, name
 
 
-@pytest.mark.parametrize("fixture", ["tiny_hf_export_refmode_taps.npz", "tiny_synth_refmode_taps.npz", "full_synth_refmode_taps.npz"])
+@pytest.mark.parametrize("fixture", ["tiny_hf_export_refmode_taps.npz", "tiny_synth_refmode_taps.npz", "full_synth_refmode_taps.npz", "full_synth_T8_refmode_taps.npz",
+                                     "full_synth_T32_refmode_taps.npz"])
 def test_oracle_reference_mode_reproduces_the_patched_transformers_taps(pkg, oracle, tiny_hf_bytes, fixture):
     """oracle(VO_MODE_REFERENCE) == a transformers.VitsModel PATCHED with torch restatements of the reference lines where
     vits.cpp deviates from the model it ports (Q1 vits.cpp:187, Q2 :638, Q3 :720, Q4 ggml-util.h:235,252 via vits.cpp:726,742,750,830,
