@@ -581,9 +581,14 @@ VITS_API int vits_op_conv1d(const vits_conv1d_desc* d, const float* x, const flo
     pc.kt = d->k;
     pc.epi = gate ? EPI_GATE : EPI_STD;
     std::vector<float> packed = pack_conv_weights(w, d->cout, d->cin, d->k, pc.epi, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
-    DevBuf dw, db, dx, dy, dr, da;
+    DevBuf dw, dwl, db, dx, dy, dr, da;
     DevInts dl;
     const size_t nx = (size_t)d->batch * d->cin * d->t_stride, ny = (size_t)d->batch * cy * d->t_stride;
+    if (conv_lat16_candidate(pc.epi, d->k, d->cin)) {
+        const std::vector<float> pl = repack_conv_weights_l16(packed, pc.mtiles, pc.nchunks, d->k);
+        if (!dwl.put(pl.data(), pl.size())) return fail("device allocation failed");
+        pc.wp_l16 = dwl.p;
+    }
     if (!dw.put(packed.data(), packed.size()) || !dx.put(x, nx) || !dy.put(nullptr, ny) || !dl.put(lens, d->batch)) return fail("device allocation failed");
     if (bias && !db.put(bias, d->cout)) return fail("device allocation failed");
     if (residual && !dr.put(residual, ny)) return fail("device allocation failed");

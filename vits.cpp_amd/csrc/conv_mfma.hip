@@ -76,6 +76,8 @@ struct ConvParams {
     float scale;
     int scale_div;
     int ct_stride, ct_crop;
+    int kt_rt;  // taps (the latency kernel below takes them at run time; every other kernel has them as a template parameter)
+    const float* wl16;  // conv_lat16_kernel's A fragments
 };
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
@@ -1010,6 +1012,248 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
     conv_mfma_body<KT, DIL, DB, WM, WN, MR, NR, EPI>(p, xs_dyn, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+
+#if VITS_CONV_PART == 0
+// ---- latency-bound launches (batch 1, short inputs): 16 x 16 output tiles on v_mfma_f32_16x16x4_f32 ----------------------------------
+// A launch of the tiny grids (the encoder's FFN convs, the flow's gated convs at 128 tokens / 225 frames) has far fewer 32 x 32 output
+// tiles than the chip has SIMDs (768 -> 192, k = 3, 128 tokens: 24 tiles on 1024 SIMDs), and the time of such a launch is ONE wave's
+// dependent MFMA chain over the whole K range: 1152 x 64 cycles = 31 us of a 50 us launch. Splitting K is ruled out (batch 1 must equal
+// a row of a batch bit for bit). But v_mfma_f32_16x16x4_f32 is, like v_mfma_f32_32x32x2_f32, bit for bit a sequential fmaf chain over
+// its k indices (tools/mfma_bits.hip: both equal the scalar chain on 1,024 outputs x 256 products), at the same 32 MACs per cycle and SIMD:
+// the same K order on 16 x 16 tiles gives FOUR times as many waves with a quarter of the chain each — 18k instead of 74k cycles for that
+// conv — and the same bits. The price is operand traffic per MAC (A and B fragments feed a quarter of the MACs), which these launches have
+// to spare.
+//   block = 4 waves = 64 rows x 16 columns: wave w owns the 16-row half (w >> 1) of 32-row tile 2 * blockIdx.y + (w & 1) — for the
+//   gated conv that is the tanh tile and the sigmoid tile of one channel group, and the odd wave hands its accumulators to the even one;
+//   the whole input tile [c_in][16 + span] is staged in LDS once by all four waves (LeakyReLU and zero padding applied there);
+//   A fragments: a second copy of the layer's weights in the operand order of this instruction (repack_conv_weights_l16; only for the
+//   layers conv_lat16_candidate names): one 16-byte load per lane feeds four MFMAs = 16 input channels, fetched 14 loads ahead (read out
+//   of the 32 x 32 array — half of every float4 unused — the stream was latency-bound: 768 -> 192, k = 3: 38 us against 41 for the 32 x 32
+//   tile); K order = (chunk, tap, channel), as everywhere.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
+    float* xs = xs_dyn;
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int b = blockIdx.z, t0 = blockIdx.x * 16;
+    const int len_in = p.len_in ? p.len_in[b] : p.t_in;
+    const int ncols = p.len_out ? p.len_out[b] : p.t_out;
+    if (t0 >= ncols || len_in <= 0) return;
+#ifdef VITS_PHASE_TIMING
+#define L16_STAMP(k)                                                                                      \
+    do {                                                                                                  \
+        if (tid == 0) {                                                                                   \
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);          \
+            if (lin < 65536) vits_phase_buf[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();            \
+        }                                                                                                 \
+    } while (0)
+#else
+#define L16_STAMP(k)
+#endif
+    L16_STAMP(0);
+    constexpr int P = 24;  // LDS row pitch (floats): 16 columns + span (<= 4) + shift (<= 3), a compile-time constant so that the B reads of a tap
+                           // are ONE base register + immediate offsets
+    const int KT = p.kt_rt, dil = p.dil;
+    const int cin_pad = p.nchunks * CK;
+    const int tile_start = t0 - p.pad_l;
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    const int jg = lane >> 4, col = lane & 15;
+    const int mtile = 2 * blockIdx.y + (wm & 1), half = wm >> 1;
+    const int G = p.nchunks * KT;  // taps over the whole K range
+    const int NQ = 2 * G;          // quads (16 channels of one tap: four MFMAs, one float4 of A per lane)
+    // A stream: descriptor + per-lane byte offset (loop-invariant VGPR) + scalar quad offset — no vector ALU work per load; the array
+    // carries AHEAD quads of slack at its end (repack_conv_weights_l16), so the look-ahead needs no clamp
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wl16), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = (int)((((size_t)(mtile < p.mtiles ? mtile : p.mtiles - 1) * 2 + half) * (size_t)NQ * 64 + lane) * 16);
+    typedef float vfloat4 __attribute__((ext_vector_type(4)));
+    auto load_q = [&](int q) __attribute__((always_inline)) -> float4 {
+        const vfloat4 v = __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, q * 1024, 0));
+        return make_float4(v.x, v.y, v.z, v.w);
+    };
+    constexpr int R = 32, AHEAD = 30;  // A ring: 32 float4, fetched 30 quads (120 MFMAs, ~4k cycles) ahead: the weights of a batch-1 step come from HBM / the MALL, not from L2
+    float4 ar[R];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) ar[i] = load_q(i);  // (in front of the fill: one memory latency for both)
+    // ---- fill. 16-byte aligned rows (the engine's arenas): the 24 floats from the 4-aligned time below tile_start as six float4 per row,
+    // ten rows per wave instruction, every load of a thread in flight at once; LDS column 0 = that aligned time, the B operands are read
+    // `shift` floats further right (launch_lat16 sizes the pitch for it). Otherwise element by element.
+    L16_STAMP(1);
+    int shift = 0;
+    if (p.oneshot) {  // (set by launch_lat16: rows 16-byte aligned, pitch 24)
+        shift = tile_start & 3;
+        const int ts = tile_start - shift;
+        const int rsub = lane / 6, c4 = lane - 6 * rsub;  // 10 rows x 6 float4 per wave pass (lanes 60-63 idle)
+        const int t4 = ts + 4 * c4;
+        const bool act = lane < 60;
+        const bool ld = act && t4 + 3 >= 0 && t4 < len_in;  // (t4 is a multiple of 4: t4 >= 0 or t4 <= -4)
+        const float* src = xb + (ld ? t4 : 0);
+        constexpr int U = 10;
+        for (int rb = wm * 10 + rsub; rb < cin_pad; rb += 40 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = rb + 40 * u;
+                v[u] = (ld && r < p.cin) ? *reinterpret_cast<const float4*>(src + (int64_t)r * p.x_cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = rb + 40 * u;
+                float4 x = v[u];
+                if (t4 + 1 >= len_in) x.y = 0.f;
+                if (t4 + 2 >= len_in) x.z = 0.f;
+                if (t4 + 3 >= len_in) x.w = 0.f;
+                if (p.pre_act) {
+                    x.x = fmaxf(x.x, x.x * p.slope);
+                    x.y = fmaxf(x.y, x.y * p.slope);
+                    x.z = fmaxf(x.z, x.z * p.slope);
+                    x.w = fmaxf(x.w, x.w * p.slope);
+                }
+                if (act && r < cin_pad) *reinterpret_cast<float4*>(xs + r * P + 4 * c4) = x;
+            }
+        }
+    } else {
+        const int cc = tid & 31, r0 = tid >> 5;
+        const int t = tile_start + cc;
+        const bool tok = cc < P && t >= 0 && t < len_in;
+        const float* src = xb + (tok ? t : 0);
+        constexpr int U = 16;
+        for (int rb = r0; rb < cin_pad; rb += 8 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = rb + 8 * u;
+                v[u] = (tok && r < p.cin) ? src[(int64_t)r * p.x_cs] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = rb + 8 * u;
+                float x = v[u];
+                if (p.pre_act) x = fmaxf(x, x * p.slope);
+                if (cc < P && r < cin_pad) xs[r * P + cc] = x;
+            }
+        }
+    }
+    L16_STAMP(2);
+    __syncthreads();
+    L16_STAMP(3);
+    typedef const volatile __attribute__((address_space(3))) float* LdsVF;
+    LdsVF xl = (LdsVF)(xs + jg * P + col + shift);
+    float bq[2][8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) bq[0][s8] = xl[(4 * s8) * P];  // tap 0 = (chunk 0, tap 0)
+    int cj = 0, toff = 0;  // tap counter within the chunk; LDS offset (floats) of the current tap = chunk * 32 * P + tap * dil
+    const int wrap = CK * P - (KT - 1) * dil;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < NQ; q0 += R) {
+#pragma unroll
+        for (int tp = 0; tp < R / 2; ++tp) {  // (no break in here: the ring and the B registers need compile-time indices)
+            if (q0 + 2 * tp < NQ) {
+                // B operands of the NEXT tap (behind the last tap: one chunk of slack rows, allocated by launch_lat16, value unused)
+                ++cj;
+                if (cj == KT) {
+                    cj = 0;
+                    toff += wrap;
+                } else {
+                    toff += dil;
+                }
+                LdsVF nx = xl + toff;
+                // issue order inside the tap, pinned: one of the next tap's eight LDS reads (and, twice, a look-ahead A load) behind every
+                // MFMA. Left alone, hipcc puts all of them in front of the tap's first MFMA, where they are 60-100 cycles with the matrix
+                // pipe idle (48 instead of 32 cycles per MFMA); sched_group_barrier patterns were only half honoured (42).
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int u = 2 * tp + h;
+                    const float4 a4 = ar[u];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float av = k == 0 ? a4.x : k == 1 ? a4.y : k == 2 ? a4.z : a4.w;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[tp & 1][4 * h + k], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bq[(tp + 1) & 1][4 * h + k] = nx[(4 * (4 * h + k)) * P];
+                        if (k == 1) ar[(u + AHEAD) % R] = load_q(q0 + u + AHEAD);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+    L16_STAMP(4);
+    // ---- epilogue: reg r of lane l = row 4 * (l >> 4) + r, column l & 15 of the 16 x 16 tile
+    const int t = t0 + col;
+    if (EPI == EPI_STD) {
+        float* yb = p.y + (int64_t)b * p.y_bs;
+        float* y2b = p.y2 ? p.y2 + (int64_t)b * p.y_bs : nullptr;
+        const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+        const float* ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = mtile * 32 + 16 * half + 4 * jg + r;
+            if (co >= p.cout || t >= ncols) continue;
+            float v = acc[r] + (p.bias ? p.bias[co] : 0.f);
+            if (p.post_act == 1) v = v > 0.f ? v : 0.f;
+            if (rb) v = rb[(int64_t)co * p.r_cs + t] + v;
+            if (ab) {
+                v = ab[(int64_t)co * p.a_cs + t] + v;
+                v = p.scale_div ? v / p.scale : v * p.scale;
+            }
+            if (p.post_act == 2) v = fmaxf(v, v * p.post_slope);
+            yb[(int64_t)co * p.y_cs + t] = v;
+            if (y2b) y2b[(int64_t)co * p.y_cs + t] = fmaxf(v, v * p.post_slope);
+        }
+    } else {
+        // gated conv: tile 2i = tanh rows of channels 32i.., tile 2i + 1 = their sigmoid rows (pack_conv_weights): the odd wave's
+        // accumulators go to the even wave of the pair through LDS, lane for lane
+        float* ex = xs + (wm >> 1) * 256;
+        __syncthreads();  // every wave has left the K loop: the input tile is free
+        if (wm & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ex[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wm & 1) return;
+        float* yb = p.y + (int64_t)b * p.y_bs;
+        const int halfc = p.cout / 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = (int)blockIdx.y * 32 + 16 * half + 4 * jg + r;
+            if (ch >= halfc || t >= ncols) continue;
+            const float b0 = p.bias ? p.bias[ch] : 0.f, b1 = p.bias ? p.bias[ch + halfc] : 0.f;
+            yb[(int64_t)ch * p.y_cs + t] = wavenet_gate(acc[r] + b0, ex[r * 64 + lane] + b1);
+        }
+    }
+}
+
+// the launch: TILE_LAT16 from resolve_conv_tile
+static hipError_t launch_lat16(const PackedConv& w, const ConvParams& p0, int ncols_max, int batch, hipStream_t s) {
+    ConvParams p = p0;
+    const int span = (w.kt - 1) * p.dil;
+    // 16-byte aligned rows: float4 fill from the 4-aligned time below the tile's first input (pitch 24 = 16 + span + shift <= 23 rounded up)
+    p.oneshot = span <= 4 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0;
+    p.xw = 24;
+    p.kt_rt = w.kt;
+    p.wl16 = w.wp_l16;
+    const size_t lds = ((size_t)w.nchunks + 1) * CK * p.xw * sizeof(float);  // (+ one chunk of slack rows: the look-ahead of the last tap)
+    dim3 grid((ncols_max + 15) / 16, (w.mtiles_used + 1) / 2, batch);
+    if (w.epi == EPI_GATE) {
+        static BigLdsOnce big;
+        if (lds > 64 * 1024 && big.needed()) {
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat16_kernel<EPI_GATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+            big.done();
+        }
+        VITS_KLAUNCH((conv_lat16_kernel<EPI_GATE>), grid, dim3(256), lds, s, p);
+    } else {
+        static BigLdsOnce big;
+        if (lds > 64 * 1024 && big.needed()) {
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat16_kernel<EPI_STD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+            big.done();
+        }
+        VITS_KLAUNCH((conv_lat16_kernel<EPI_STD>), grid, dim3(256), lds, s, p);
+    }
+    return hipGetLastError();
+}
+#endif  // VITS_CONV_PART == 0
+
 // ---- grouped launch: the convolutions of the SAME position in the (up to) three ResBlocks of a vocoder stage (kernel sizes 11 / 7 /
 // 3, one dilation, one channel count; vits.cpp:622-635 runs the resblocks on the same input) as ONE launch -----------------------
 // The resblocks are independent chains, so conv number i of each can run side by side; launched one by one, each of them ends in a
@@ -1040,6 +1284,7 @@ static TileShape tile_shape(int tile) {
         case TILE_64x256: return {1, 4, 2, 2};
         case TILE_32x256: return {1, 4, 1, 2};
         case TILE_64x64: return {1, 4, 2, 1};  // 64 x 128
+        case TILE_LAT16:  // (conv_lat16_kernel has its own grid; parameters are set up as for the narrow tile)
         case TILE_NARROW: return {4, 1, 1, 1};  // 128 x 32: four row tiles of ONE 32-column strip
         default: return {1, 4, 1, 1};          // TILE_32x64: 32 x 128
     }
@@ -1108,6 +1353,28 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
     *rows_out = rows;
     *mtiles_out = mtiles;
     *nchunks_out = nchunks;
+    return out;
+}
+
+bool conv_lat16_candidate(int epi, int kt, int cin) {
+    return ((epi == EPI_STD && kt <= 3) || (epi == EPI_GATE && kt == 5)) && (int64_t)kt * cin >= 512;
+}
+
+std::vector<float> repack_conv_weights_l16(const std::vector<float>& packed, int mtiles, int nchunks, int kt) {
+    std::vector<float> out(packed.size() + 32 * 256, 0.f);  // (+ 32 quads of slack: conv_lat16_kernel's look-ahead reads past the last stream)
+    const size_t G = (size_t)nchunks * kt;
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int half = 0; half < 2; ++half)
+            for (size_t g = 0; g < G; ++g)
+                for (int hq = 0; hq < 2; ++hq)  // the two 16-channel quads of a tap's 32-channel chunk
+                    for (int l = 0; l < 64; ++l)
+                        for (int sc = 0; sc < 4; ++sc) {
+                            const int ci = 16 * hq + 4 * sc + (l >> 4);  // channel within the chunk
+                            const int pr = ci >> 1, par = ci & 1;
+                            const size_t src = (((((size_t)mt * G + g) * (CK / 8)) + pr / 4) * 64 + (16 * half + (l & 15) + 32 * par)) * 4 + (pr & 3);
+                            const size_t dst = (((((size_t)mt * 2 + half) * (2 * G)) + 2 * g + hq) * 64 + l) * 4 + sc;
+                            out[dst] = packed[src];
+                        }
     return out;
 }
 
@@ -1287,6 +1554,12 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         const int narrow_k1 = kernel_knobs().narrow_k1;
         const bool k1_short = narrow_k1 > 0 && w.epi == EPI_STD && w.kt == 1 && ncols_max <= narrow_k1;
         if (!no_narrow && shape_ok && (nb <= 128 || k1_short)) tile = TILE_NARROW;
+        // ... and where the launch time is one wave's MFMA chain (>= 512 products per output; not the 1x1 convs, whose chain is 2.6 us of a
+        // launch that is bound by its fill), 16 x 16 tiles on v_mfma_f32_16x16x4_f32: conv_lat16_kernel
+        const int span16 = (w.kt - 1) * dil_eff;
+        if (tile == TILE_NARROW && nb <= 128 && !kernel_knobs().no_lat16 && w.wp_l16 && 16 + span16 <= 32 &&
+            ((size_t)w.nchunks + 1) * CK * 24 * 4 <= 150 * 1024)
+            tile = TILE_LAT16;
     }
     return tile;
 }
@@ -1325,6 +1598,8 @@ hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, Co
     p.scale_div = c.scale_div;
     p.ct_stride = w.ct_stride;
     p.ct_crop = c.ct_crop;
+    p.kt_rt = w.kt;
+    p.wl16 = w.wp_l16;
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
@@ -1365,6 +1640,7 @@ hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     const int tile = resolve_conv_tile(w, c);
     if (hipError_t e = make_conv_params(w, c, tile, p)) return e;
+    if (tile == TILE_LAT16) return launch_lat16(w, p, ncols_max, c.batch, s);
     const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns
     const int batch = c.batch;

@@ -206,6 +206,13 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
         packs_.push_back(std::move(ps));
     }
     out.wp = upload(packed);
+    if (!dry_run_ && conv_lat16_candidate(epi, out.kt, cin)) {  // second copy for the latency kernel (batch 1 / short inputs)
+        out.wp_l16 = upload(repack_conv_weights_l16(packed, out.mtiles, out.nchunks, out.kt));
+        if (!out.wp_l16) {
+            err = "hipMalloc failed for " + wname;
+            return false;
+        }
+    }
     out.bias = bias.empty() ? nullptr : upload(bias);
     out.bytes = (int64_t)packed.size() * 4;
     if (!out.wp) {

@@ -44,6 +44,7 @@ struct KernelKnobs {
     bool fuse32_c128 = true;     // VITS_FUSE32_C128=0: fp32 k = 3 pairs at C = 128 as two launches
     int wn16_ncw = 1;            // VITS_WN16_NCW=2: 16-bit WaveNet layer with six waves, both column tiles each
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
+    bool no_lat16 = false;       // VITS_NO_LAT16: tiny grids with long K chains on the 128 x 32 tile of conv_mfma instead of conv_lat16_kernel
     static KernelKnobs from_env() {
         KernelKnobs k;
         auto num = [](const char* name, int& v) {
@@ -72,6 +73,7 @@ struct KernelKnobs {
         if (const char* e = getenv("VITS_FUSE32_C128")) k.fuse32_c128 = atoi(e) != 0;
         num("VITS_WN16_NCW", k.wn16_ncw);
         num("VITS_FLOW_NCW", k.flow_ncw);
+        flag("VITS_NO_LAT16", k.no_lat16);
         return k;
     }
 };
@@ -145,7 +147,8 @@ enum ConvTile : int {
     TILE_32x256 = 2,
     TILE_64x64 = 3,
     TILE_32x64 = 4,
-    TILE_NARROW = 5  // 128 rows x 32 columns (256 x 32 for the gated conv): tiny grids only, see choose in launch_conv
+    TILE_NARROW = 5,  // 128 rows x 32 columns (256 x 32 for the gated conv): tiny grids only, see choose in launch_conv
+    TILE_LAT16 = 6    // 64 rows x 16 columns on v_mfma_f32_16x16x4_f32 (conv_lat16_kernel): tiny grids with long K chains
 };
 
 // Weights pre-packed at load time in exact MFMA A-fragment order (see conv_mfma.hip), resident in HBM.
@@ -161,6 +164,7 @@ struct PackedConv {
     int ct_stride = 0;  // EPI_CONVT: upsampling stride s
     int64_t bytes = 0;
     uint16_t* wp16 = nullptr;  // 16-bit A fragments of the VITS_ARITH_F16 / BF16 path (packed by Engine::set_arith)
+    float* wp_l16 = nullptr;   // the same weights as v_mfma_f32_16x16x4_f32 A fragments (repack_conv_weights_l16) for conv_lat16_kernel, or nullptr
     int64_t bytes16 = 0;
 };
 
@@ -195,6 +199,10 @@ struct ConvCall {
 // host-side packing: w is torch layout [cout][cin][k] (EPI_STD / EPI_GATE) or [cin][cout][k] (EPI_CONVT)
 std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, int epi, int ct_stride, int* rows, int* mtiles_used, int* mtiles,
                                      int* nchunks);
+// conv_lat16_kernel's A fragments from the packed array: [32-row tile][16-row half][quad = 16 input channels of one tap][lane][4] with lane l = row l & 15,
+// component s = channel 4 s + (l >> 4) of the quad: one 16-byte load per lane feeds four consecutive MFMAs. Same size as `packed`.
+bool conv_lat16_candidate(int epi, int kt, int cin);  // the layers worth a second copy of their weights (STD k <= 3 / GATE k = 5 with >= 512 products per output)
+std::vector<float> repack_conv_weights_l16(const std::vector<float>& packed, int mtiles, int nchunks, int kt);
 int choose_conv_tile(int rows, int epi, int t_hint);
 int resolve_conv_tile(const PackedConv& w, const ConvCall& c);  // the tile launch_conv will use (small-grid rules included)
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s);
