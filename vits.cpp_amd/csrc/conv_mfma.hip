@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(DB ? 320 : 256) VITS_WAVES_ATTR void conv_mfma_kern
 //   of the 32 x 32 array — half of every float4 unused — the stream was latency-bound: 768 -> 192, k = 3: 38 us against 41 for the 32 x 32
 //   tile); K order = (chunk, tap, channel), as everywhere.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-template <int EPI>
+template <int EPI, int P>  // P: LDS row pitch (floats) = 16 columns + span + shift (<= 3) rounded up: 24 (span <= 4), 40 (<= 20), 72 (<= 52); a
+                           // compile-time constant so that the B reads of a tap are ONE base register + immediate offsets
 __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
     float* xs = xs_dyn;
@@ -1052,8 +1053,6 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
 #define L16_STAMP(k)
 #endif
     L16_STAMP(0);
-    constexpr int P = 24;  // LDS row pitch (floats): 16 columns + span (<= 4) + shift (<= 3), a compile-time constant so that the B reads of a tap
-                           // are ONE base register + immediate offsets
     const int KT = p.kt_rt, dil = p.dil;
     const int cin_pad = p.nchunks * CK;
     const int tile_start = t0 - p.pad_l;
@@ -1083,22 +1082,23 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     if (p.oneshot) {  // (set by launch_lat16: rows 16-byte aligned, pitch 24)
         shift = tile_start & 3;
         const int ts = tile_start - shift;
-        const int rsub = lane / 6, c4 = lane - 6 * rsub;  // 10 rows x 6 float4 per wave pass (lanes 60-63 idle)
+        constexpr int F4 = P / 4, RPW = 64 / F4;  // float4 per row, rows per wave pass (P = 24: 6 and 10, lanes 60-63 idle)
+        const int rsub = lane / F4, c4 = lane - F4 * rsub;
         const int t4 = ts + 4 * c4;
-        const bool act = lane < 60;
+        const bool act = lane < F4 * RPW;
         const bool ld = act && t4 + 3 >= 0 && t4 < len_in;  // (t4 is a multiple of 4: t4 >= 0 or t4 <= -4)
         const float* src = xb + (ld ? t4 : 0);
         constexpr int U = 10;
-        for (int rb = wm * 10 + rsub; rb < cin_pad; rb += 40 * U) {
+        for (int rb = wm * RPW + rsub; rb < cin_pad; rb += 4 * RPW * U) {
             float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = rb + 40 * u;
+                const int r = rb + 4 * RPW * u;
                 v[u] = (ld && r < p.cin) ? *reinterpret_cast<const float4*>(src + (int64_t)r * p.x_cs) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = rb + 40 * u;
+                const int r = rb + 4 * RPW * u;
                 float4 x = v[u];
                 if (t4 + 1 >= len_in) x.y = 0.f;
                 if (t4 + 2 >= len_in) x.z = 0.f;
@@ -1113,21 +1113,22 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
             }
         }
     } else {
-        const int cc = tid & 31, r0 = tid >> 5;
+        constexpr int LPR = P <= 32 ? 32 : (P <= 64 ? 64 : 128), RPP = 256 / LPR;  // lanes per row, rows per block pass
+        const int cc = tid & (LPR - 1), r0 = tid / LPR;
         const int t = tile_start + cc;
         const bool tok = cc < P && t >= 0 && t < len_in;
         const float* src = xb + (tok ? t : 0);
         constexpr int U = 16;
-        for (int rb = r0; rb < cin_pad; rb += 8 * U) {
+        for (int rb = r0; rb < cin_pad; rb += RPP * U) {
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = rb + 8 * u;
+                const int r = rb + RPP * u;
                 v[u] = (tok && r < p.cin) ? src[(int64_t)r * p.x_cs] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = rb + 8 * u;
+                const int r = rb + RPP * u;
                 float x = v[u];
                 if (p.pre_act) x = fmaxf(x, x * p.slope);
                 if (cc < P && r < cin_pad) xs[r * P + cc] = x;
@@ -1225,31 +1226,40 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
 }
 
 // the launch: TILE_LAT16 from resolve_conv_tile
+static int lat16_pitch(int span) { return span <= 4 ? 24 : span <= 20 ? 40 : span <= 52 ? 72 : 0; }
 static hipError_t launch_lat16(const PackedConv& w, const ConvParams& p0, int ncols_max, int batch, hipStream_t s) {
     ConvParams p = p0;
     const int span = (w.kt - 1) * p.dil;
-    // 16-byte aligned rows: float4 fill from the 4-aligned time below the tile's first input (pitch 24 = 16 + span + shift <= 23 rounded up)
-    p.oneshot = span <= 4 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0;
-    p.xw = 24;
+    const int pitch = lat16_pitch(span);
+    if (!pitch || !w.wp_l16) return hipErrorInvalidValue;
+    // 16-byte aligned rows: float4 fill from the 4-aligned time below the tile's first input
+    p.oneshot = (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0;
+    p.xw = pitch;
     p.kt_rt = w.kt;
     p.wl16 = w.wp_l16;
-    const size_t lds = ((size_t)w.nchunks + 1) * CK * p.xw * sizeof(float);  // (+ one chunk of slack rows: the look-ahead of the last tap)
+    const size_t lds = ((size_t)w.nchunks + 1) * CK * pitch * sizeof(float);  // (+ one chunk of slack rows: the look-ahead of the last tap)
     dim3 grid((ncols_max + 15) / 16, (w.mtiles_used + 1) / 2, batch);
+#define VITS_L16(E, PP)                                                                                                                          \
+    do {                                                                                                                                         \
+        static BigLdsOnce big;                                                                                                                   \
+        if (lds > 64 * 1024 && big.needed()) {                                                                                                   \
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat16_kernel<E, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) \
+                return e;                                                                                                                        \
+            big.done();                                                                                                                          \
+        }                                                                                                                                        \
+        VITS_KLAUNCH((conv_lat16_kernel<E, PP>), grid, dim3(256), lds, s, p);                                                                    \
+    } while (0)
     if (w.epi == EPI_GATE) {
-        static BigLdsOnce big;
-        if (lds > 64 * 1024 && big.needed()) {
-            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat16_kernel<EPI_GATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
-            big.done();
-        }
-        VITS_KLAUNCH((conv_lat16_kernel<EPI_GATE>), grid, dim3(256), lds, s, p);
+        if (pitch != 24) return hipErrorInvalidValue;
+        VITS_L16(EPI_GATE, 24);
+    } else if (pitch == 24) {
+        VITS_L16(EPI_STD, 24);
+    } else if (pitch == 40) {
+        VITS_L16(EPI_STD, 40);
     } else {
-        static BigLdsOnce big;
-        if (lds > 64 * 1024 && big.needed()) {
-            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat16_kernel<EPI_STD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
-            big.done();
-        }
-        VITS_KLAUNCH((conv_lat16_kernel<EPI_STD>), grid, dim3(256), lds, s, p);
+        VITS_L16(EPI_STD, 72);
     }
+#undef VITS_L16
     return hipGetLastError();
 }
 #endif  // VITS_CONV_PART == 0
@@ -1357,7 +1367,7 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
 }
 
 bool conv_lat16_candidate(int epi, int kt, int cin) {
-    return ((epi == EPI_STD && kt <= 3) || (epi == EPI_GATE && kt == 5)) && (int64_t)kt * cin >= 512;
+    return (epi == EPI_STD || (epi == EPI_GATE && kt == 5)) && (int64_t)kt * cin >= 512;
 }
 
 std::vector<float> repack_conv_weights_l16(const std::vector<float>& packed, int mtiles, int nchunks, int kt) {
@@ -1554,11 +1564,16 @@ int resolve_conv_tile(const PackedConv& w, const ConvCall& c) {
         const int narrow_k1 = kernel_knobs().narrow_k1;
         const bool k1_short = narrow_k1 > 0 && w.epi == EPI_STD && w.kt == 1 && ncols_max <= narrow_k1;
         if (!no_narrow && shape_ok && (nb <= 128 || k1_short)) tile = TILE_NARROW;
-        // ... and where the launch time is one wave's MFMA chain (>= 512 products per output; not the 1x1 convs, whose chain is 2.6 us of a
-        // launch that is bound by its fill), 16 x 16 tiles on v_mfma_f32_16x16x4_f32: conv_lat16_kernel
-        const int span16 = (w.kt - 1) * dil_eff;
-        if (tile == TILE_NARROW && nb <= 128 && !kernel_knobs().no_lat16 && w.wp_l16 && 16 + span16 <= 32 &&
-            ((size_t)w.nchunks + 1) * CK * 24 * 4 <= 150 * 1024)
+        // ... and where the launch time is one wave's MFMA chain (a second copy of the weights exists for the layers with >= 512 products
+        // per output: not the 1x1 convs, whose chain is 2.6 us of a launch that is bound by its fill), 16 x 16 tiles on
+        // v_mfma_f32_16x16x4_f32 (conv_lat16_kernel): the tiny grids of the narrow tile, and any standard conv whose 32 x 32 tiles would
+        // not even fill the SIMDs once (batch 1: the C = 256 stage of the vocoder, conv_pre)
+        const int pitch16 = lat16_pitch((w.kt - 1) * dil_eff);
+        const int64_t waves32 = (int64_t)((ncols_max + 31) / 32) * w.mtiles_used * c.batch;
+        const bool tiny = tile == TILE_NARROW && nb <= 128;
+        const bool unfilled = w.epi == EPI_STD && w.kt >= 3 && dil_eff >= 1 && waves32 <= kernel_knobs().lat16_max_waves;
+        if ((tiny || unfilled) && !kernel_knobs().no_lat16 && w.wp_l16 && pitch16 && (w.epi == EPI_STD || pitch16 == 24) &&
+            ((size_t)w.nchunks + 1) * CK * pitch16 * 4 <= 150 * 1024)
             tile = TILE_LAT16;
     }
     return tile;

@@ -214,7 +214,7 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
         }
     }
     out.bias = bias.empty() ? nullptr : upload(bias);
-    out.bytes = (int64_t)packed.size() * 4;
+    out.bytes = (int64_t)packed.size() * 4 * (out.wp_l16 ? 2 : 1);
     if (!out.wp) {
         err = "hipMalloc failed for " + wname;
         return false;
