@@ -1367,7 +1367,9 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
 }
 
 bool conv_lat16_candidate(int epi, int kt, int cin) {
-    return (epi == EPI_STD || (epi == EPI_GATE && kt == 5)) && (int64_t)kt * cin >= 512;
+    // (>= 64 products per output: everything but the degenerate convs. The long chains — FFN, gated, vocoder — win by the chain (41 -> 17.7 us);
+    // the 1x1 convs, whose chain is only 2.6 us, by the fill and the finer grid: 13-16 -> 7 us at batch 1)
+    return (epi == EPI_STD || (epi == EPI_GATE && kt == 5)) && (int64_t)kt * cin >= 64;
 }
 
 std::vector<float> repack_conv_weights_l16(const std::vector<float>& packed, int mtiles, int nchunks, int kt) {

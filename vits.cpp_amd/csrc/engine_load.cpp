@@ -336,8 +336,9 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             pc.epi = EPI_STD;
             auto packed = pack_conv_weights(w.data(), 3 * H, H, 1, EPI_STD, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
             pc.wp = upload(packed);
+            if (!dry_run_ && conv_lat16_candidate(EPI_STD, 1, H)) pc.wp_l16 = upload(repack_conv_weights_l16(packed, pc.mtiles, pc.nchunks, 1));
             pc.bias = upload(bias);
-            pc.bytes = (int64_t)packed.size() * 4;
+            pc.bytes = (int64_t)packed.size() * 4 * (pc.wp_l16 ? 2 : 1);
             if (!pc.wp || !pc.bias) {
                 err = "hipMalloc failed for " + b + "attention";
                 return false;
