@@ -515,19 +515,23 @@ struct FlowCouple16Params {
 // NCW: 32-frame column tiles per wave. 1 = twelve waves (channel group, column tile); 2 = six waves that own both column tiles of their channel
 // group: every weight fragment then feeds two MFMAs per row tile, which halves the fragment traffic through the CU's vector memory path
 // (the bound of the gated conv, see wavenet16_kernel) — without the per-layer fill and epilogue that made it lose there.
-template <bool BF, int NCW>
-__global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowCouple16Params p) {
-    constexpr int H = 192, HF = 96, KT = 5, NL = 4, NG = H / 32, BM = 64, BO = 48, HALO = 8, P = (KT - 1) / 2, XS = BM + KT - 1;
+// NCT: 32-frame column tiles per BLOCK. 2 = 48 frames on 64 columns (the throughput shape). 1 = 16 frames on 32 columns, for small grids: an
+// utterance of 225 frames is FIVE blocks of the wide tile on 256 CUs (87 us per coupling layer at batch 1); fifteen narrow ones compute 1.5 x
+// the columns in a third of the time. Same chains and expressions per output: bit-identical.
+template <bool BF, int NCW, int NCT>
+__global__ __launch_bounds__(64 * 6 * NCT / NCW, 1) void flow_couple16_kernel(const FlowCouple16Params p) {
+    constexpr int H = 192, HF = 96, KT = 5, NL = 4, NG = H / 32, BM = 32 * NCT, HALO = 8, BO = BM - 2 * HALO, P = (KT - 1) / 2, XS = BM + KT - 1;
     constexpr int NGRP = H / 8;  // 16-byte channel groups of an H-channel tile
-    constexpr int NTH = 768 / NCW;
+    constexpr int NTH = 64 * NG * NCT / NCW;
+    static_assert(NCW <= NCT, "a wave owns at most the block's column tiles");
     static_assert(HALO == NL * P, "one k = 5 halo per WaveNet layer");
     extern __shared__ __attribute__((aligned(16))) wn_int4v l16[];
     wn_int4v* xs = l16;               // [NGRP][XS]  round(h), slot P + column (two zero slots on either side)
     wn_int4v* ts = l16 + NGRP * XS;   // [NGRP][BM]  acts | round(x0) (12 groups) | round(out)
-    float* ex = reinterpret_cast<float*>(l16);  // [3][2][16][2][64] fp32: the last layer's rs rows on their way to the skip waves (over xs + ts)
+    float* ex = reinterpret_cast<float*>(l16);  // [3][2][16][NCT][64] fp32: the last layer's rs rows on their way to the skip waves (over xs + ts)
     float* lb = reinterpret_cast<float*>(l16 + NGRP * XS + NGRP * BM);  // biases: pre[H] | in[NL][2H] | rs[NL][2H] | post[HF]
     constexpr int LB_IN = H, LB_RS = H + NL * 2 * H, LB_POST = H + 2 * NL * 2 * H, LB_N = LB_POST + HF;
-    static_assert(3 * 2 * 16 * 2 * 64 * 4 <= (NGRP * XS + NGRP * BM) * 16, "exchange buffer fits over the two tiles");
+    static_assert(3 * 2 * 16 * NCT * 64 * 4 <= (NGRP * XS + NGRP * BM) * 16, "exchange buffer fits over the two tiles");
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.y;
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
             for (int n = 0; n < NCW; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ex[(((gw * 2 + m) * 16 + r) * 2 + ct0 + n) * 64 + lane] = acc[m][n][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
+                    ex[(((gw * 2 + m) * 16 + r) * NCT + ct0 + n) * 64 + lane] = acc[m][n][r] + lb[LB_RS + (NL - 1) * 2 * H + rowof(2 * gw + m, r)];
     }
     if (gw < 3) conv_begin(p.w_post, gw, C_RS{}, I1{});
     __syncthreads();
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(768 / NCW, 1) void flow_couple16_kernel(const FlowC
 #pragma unroll
             for (int n = 0; n < NCW; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[m][n][r] = st[m][n][r] + ex[((((gw - 3) * 2 + m) * 16 + r) * 2 + ct0 + n) * 64 + lane];
+                for (int r = 0; r < 16; ++r) st[m][n][r] = st[m][n][r] + ex[((((gw - 3) * 2 + m) * 16 + r) * NCT + ct0 + n) * 64 + lane];
     }
     __syncthreads();  // ex read: ts may be written
     if (gw >= 3) {
@@ -902,17 +906,26 @@ hipError_t launch_flow_couple16(const PackedConv& pre, const PackedConv* in, con
     p.b_post = post.bias;
     p.lens = c.lens;
     p.tmax = c.tmax;
-    constexpr int H = 192, XS = 64 + 4, NGRP = H / 8, LB_N = H + 2 * 4 * 2 * H + 96;
-    const size_t ldsz = (size_t)(NGRP * XS + NGRP * 64) * 16 + (size_t)LB_N * 4;
+    constexpr int H = 192, NGRP = H / 8, LB_N = H + 2 * 4 * 2 * H + 96;
+    // small grids (batch 1 ... 4 at 225 frames): 16-frame blocks on one 32-column tile (see the kernel)
+    const int64_t wide_blocks = (int64_t)((c.tmax + 47) / 48) * c.batch;
+    if (wide_blocks <= kernel_knobs().flow_narrow_max) {
+        const size_t ldsz = (size_t)(NGRP * (32 + 4) + NGRP * 32) * 16 + (size_t)LB_N * 4;
+        dim3 grid((c.tmax + 15) / 16, c.batch);
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 1, 1>), grid, dim3(384), ldsz, s, p);
+        else VITS_KLAUNCH((flow_couple16_kernel<false, 1, 1>), grid, dim3(384), ldsz, s, p);
+        return hipGetLastError();
+    }
+    const size_t ldsz = (size_t)(NGRP * (64 + 4) + NGRP * 64) * 16 + (size_t)LB_N * 4;
     // six waves owning both column tiles of their channel group (VITS_FLOW_NCW=1: twelve waves, one column tile each)
     const int ncw = kernel_knobs().flow_ncw;
     dim3 grid((c.tmax + 47) / 48, c.batch);
     if (ncw == 1) {
-        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 1>), grid, dim3(768), ldsz, s, p);
-        else VITS_KLAUNCH((flow_couple16_kernel<false, 1>), grid, dim3(768), ldsz, s, p);
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 1, 2>), grid, dim3(768), ldsz, s, p);
+        else VITS_KLAUNCH((flow_couple16_kernel<false, 1, 2>), grid, dim3(768), ldsz, s, p);
     } else {
-        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 2>), grid, dim3(384), ldsz, s, p);
-        else VITS_KLAUNCH((flow_couple16_kernel<false, 2>), grid, dim3(384), ldsz, s, p);
+        if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((flow_couple16_kernel<true, 2, 2>), grid, dim3(384), ldsz, s, p);
+        else VITS_KLAUNCH((flow_couple16_kernel<false, 2, 2>), grid, dim3(384), ldsz, s, p);
     }
     return hipGetLastError();
 }
