@@ -297,6 +297,15 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     e, s_, fr = run([(base_model, ids1, noise_base, b2, cap)], n, warmup=1, pipelined=True)
     out["c2_f32"]["pipelined_throughput"] = {"value": s_ / e, "ms_per_utterance": 1000.0 * e / n,
                                              "note": "batch-1 utterances through the single-handle pipeline (two in flight): throughput, not latency"}
+    # c2 in the reference's own conv arithmetic (fp16 operands, default scope): the latency of one utterance, serial calls
+    base_model.set_arith(pkg.ARITH_F16)
+    try:
+        e, s_, fr = run([(base_model, ids1, noise_base, b, cap)], n, warmup=5)
+        out["c2_f16"] = entry(e, s_, fr, n, 128, "f16", 1, tag="c2|b1|f16")
+        out["c2_f16"]["ms_per_utterance"] = 1000.0 * e / n
+        out["c2_f16"]["schedule"] = "serial calls (latency figure: one utterance in, its PCM out)"
+    finally:
+        base_model.set_arith(pkg.ARITH_F32)
     # c3 in fp32 (pipelined beside the headline's serial figure) and in the 16-bit arithmetic modes (default scope: stage one exact,
     # durations identical to the fp32 run's)
     ids64 = pkg.synth_ids(64, 128)
@@ -529,7 +538,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the pinned-duration and host-PCM passes reported beside the headline")
-    ap.add_argument("--no-sub-results", action="store_true", help="skip the compact sub-results (c2_f32, c3_f16, c3_bf16, c5_f32, c5_bf16) and the "
+    ap.add_argument("--no-sub-results", action="store_true", help="skip the compact sub-results (c2_f32, c2_f16, c3_f16, c3_bf16, c5_f32, c5_bf16) and the "
                     "duration-boundary report that the default single-GPU run prints beside the headline")
     ap.add_argument("--no-serving", action="store_true", help="skip the two-engine serving data point (`serving_two_engines`) of the default run")
     ap.add_argument("--pcm16", action="store_true", help="multi-GPU: convert to int16 on the device and gather that (half the bytes)")

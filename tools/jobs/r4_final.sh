@@ -4,6 +4,7 @@
 V=${1:-v1}
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r4_$V; mkdir -p $O $O/profiles_out
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -1
 timeout 2400 python -m pytest tests -m gpu -q -rA > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $O/pytest.log; grep -h "config 5 model\|16-bit modes vs fp32" $O/pytest.log | head
 bash tools/jobs/profile.sh r4_${V}_prof "c3|b64|f32" > $O/prof.log 2>&1
 bash tools/jobs/profile.sh r4_${V}_prof_f16 "c3|b64|f16" --arith f16 > $O/prof_f16.log 2>&1
