@@ -78,6 +78,7 @@ struct ConvParams {
     int ct_stride, ct_crop;
     int kt_rt;  // taps (the latency kernel below takes them at run time; every other kernel has them as a template parameter)
     const float* wl16;  // conv_lat16_kernel's A fragments
+    int l16_fill4;      // conv_lat16_kernel: rows 16-byte aligned -> float4 fill
 };
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     // `shift` floats further right (launch_lat16 sizes the pitch for it). Otherwise element by element.
     L16_STAMP(1);
     int shift = 0;
-    if (p.oneshot) {  // (set by launch_lat16: rows 16-byte aligned, pitch 24)
+    if (p.l16_fill4) {  // (set by launch_lat16: rows 16-byte aligned)
         shift = tile_start & 3;
         const int ts = tile_start - shift;
         constexpr int F4 = P / 4, RPW = 64 / F4;  // float4 per row, rows per wave pass (P = 24: 6 and 10, lanes 60-63 idle)
@@ -1233,7 +1234,7 @@ static hipError_t launch_lat16(const PackedConv& w, const ConvParams& p0, int nc
     const int pitch = lat16_pitch(span);
     if (!pitch || !w.wp_l16) return hipErrorInvalidValue;
     // 16-byte aligned rows: float4 fill from the 4-aligned time below the tile's first input
-    p.oneshot = (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0;
+    p.l16_fill4 = (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0;
     p.xw = pitch;
     p.kt_rt = w.kt;
     p.wl16 = w.wp_l16;
@@ -1617,6 +1618,7 @@ hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, Co
     p.ct_crop = c.ct_crop;
     p.kt_rt = w.kt;
     p.wl16 = w.wp_l16;
+    p.l16_fill4 = 0;
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
