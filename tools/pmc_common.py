@@ -10,7 +10,7 @@ TILES = {(2, 2, 2, 2): 0, (1, 4, 2, 2): 1, (1, 4, 1, 2): 2, (1, 4, 2, 1): 3, (1,
 _CONV = re.compile(r"conv_mfma_kernel<(-?\d+), (-?\d+), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)>")
 _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>")
 _WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)(?:, \d+)?>")
-_COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)(?:, \d+)?>")
+_COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)(?:, \d+)*>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
 # rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF> (block-shape parameters between C and the dilations: any number of them)
 _RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+)(?:, \d+)*?, (\d+), (\d+), (\d+), (\w+)>")
@@ -88,3 +88,26 @@ def source_sha16():
     pkg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pkg)
     return pkg.source_sha16()
+
+
+def rebuild_by_key(kernels):
+    """by_bench_key of an artefact from its `kernels` entries (the instantiation with the most sampled launches wins a key): what the reducers
+    compute at collection time, and what `--rekey FILE...` recomputes when a kernel's template signature (and with it the regex above) changed
+    after the counters were collected."""
+    by_key = {}
+    for name, e in kernels.items():
+        key = bench_key(name)
+        if key and (key not in by_key or e.get("launches_sampled", 0) > by_key[key].get("launches_sampled", 0)):
+            by_key[key] = dict(e, kernel_name=name)
+    return by_key
+
+
+if __name__ == "__main__":
+    import json, sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--rekey":
+        for path in sys.argv[2:]:
+            d = json.load(open(path))
+            n0 = len(d.get("by_bench_key", {}))
+            d["by_bench_key"] = rebuild_by_key(d["kernels"])
+            json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+            print("rekeyed", path, n0, "->", len(d["by_bench_key"]), "keys")
