@@ -1,4 +1,4 @@
-"""Developer helper: where does a 16-bit-mode run differ from the oracle in the same arithmetic? (long utterance, per-tap statistics,
+"""Test helper (it runs the oracle, so it lives under tests/): where does a 16-bit-mode run differ from the oracle in the same arithmetic? (long utterance, per-tap statistics,
 the largest deviations, and the same comparison with the fused pair kernel / the group-layout vocoder switched off)."""
 import os, sys, subprocess, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

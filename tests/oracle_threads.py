@@ -1,4 +1,4 @@
-"""Developer helper: CPU-oracle throughput vs thread count on this host (picks the cpu_baseline thread count)."""
+"""Test helper (it runs the oracle, so it lives under tests/): CPU-oracle throughput vs thread count on this host (picks the cpu_baseline thread count)."""
 import sys, time, importlib.util, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
