@@ -154,3 +154,18 @@ def test_add_layer_norm_matches_oracle(pkg, oracle):
     x, r = rnd(rng, 2, 192, 150), rnd(rng, 2, 192, 150)
     g, b = rnd(rng, 192) + 1, rnd(rng, 192)
     assert rel_err(pkg.op_add_layer_norm(x, r, g, b), oracle.add_layer_norm(x, r, g, b)) < TOL
+
+
+def test_mfma_16x16x4_is_the_same_sequential_fmaf_chain_as_32x32x2(tmp_path):
+    """The hardware fact conv_lat16_kernel stands on (small grids): a K chain of v_mfma_f32_16x16x4_f32 is bit for bit the chain of
+    v_mfma_f32_32x32x2_f32 and the scalar fmaf chain in k order — tools/mfma_bits.hip, built and run here (1,024 outputs x 256 products);
+    the 16-bit pair (32x32x16 / 16x16x32) likewise (tools/mfma_bits16.hip)."""
+    import os, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for src, want in (("mfma_bits.hip", "32x32x2 vs 16x16x4: 0 of 1024 differ; 32x32x2 vs fmaf chain: 0; 16x16x4 vs fmaf chain: 0"),
+                      ("mfma_bits16.hip", "32x32x16 vs 16x16x32: 0 of 1024 outputs differ")):
+        exe = str(tmp_path / src.replace(".hip", ""))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tools", src), "-o", exe], check=True, capture_output=True, timeout=300)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+        assert want in out, out
