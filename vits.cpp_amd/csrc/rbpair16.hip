@@ -380,10 +380,9 @@ __global__ __launch_bounds__(ROWS ? 2 * C : 256, C >= 256 ? ((KT - 1) * DIL <= 3
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-template <int KT, int DIL, int C, bool BF>
-static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
+template <int KT, int DIL, int C, bool BF, int NR>
+static hipError_t launch_rb_nr(const RbPairParams& p, int batch, hipStream_t s) {
     constexpr bool ROWS = C >= 128;
-    constexpr int NR = ROWS ? 4 : 2;
     constexpr int BM = (ROWS ? 1 : 4) * NR * 32;
     constexpr int BO = BM - (KT - 1);
     constexpr int XWP = (BM + (KT - 1) * DIL + 7) / 8 * 8, TW = (BM + KT - 1 + 7) / 8 * 8;
@@ -397,6 +396,22 @@ static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
     dim3 grid((p.tmax + BO - 1) / BO, batch);
     VITS_KLAUNCH((rbpair16_kernel<KT, DIL, C, NR, BF, ROWS>), grid, dim3(ROWS ? 2 * C : 256), lds, s, p);
     return hipGetLastError();
+}
+#ifndef VITS_RB16_NARROW_NR
+#define VITS_RB16_NARROW_NR 2
+#endif
+template <int KT, int DIL, int C, bool BF>
+static hipError_t launch_rb(const RbPairParams& p, int batch, hipStream_t s) {
+    if constexpr (C >= 128) {
+        // small grids (batch 1 ... 4): the row-split blocks own 128 columns (NR = 4 tiles per wave), i.e. 16 blocks for the 1,808 frames of an
+        // utterance at C = 256 on 256 CUs; blocks of VITS_RB16_NARROW_NR tiles are that many times shorter chains on that many more CUs
+        // (the halo costs more: they lose as soon as the chip is full). Same chains per output: bit-identical.
+        constexpr int BO4 = 4 * 32 - (KT - 1);
+        if ((int64_t)((p.tmax + BO4 - 1) / BO4) * batch <= kernel_knobs().rb16_narrow_max) return launch_rb_nr<KT, DIL, C, BF, VITS_RB16_NARROW_NR>(p, batch, s);
+        return launch_rb_nr<KT, DIL, C, BF, 4>(p, batch, s);
+    } else {
+        return launch_rb_nr<KT, DIL, C, BF, 2>(p, batch, s);
+    }
 }
 
 template <int KT, int C, bool BF>
