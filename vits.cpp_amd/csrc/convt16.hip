@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256, 2) void convt16_lines_kernel(const ConvT16Para
     const int nunits = ncb * nhalf * NCP;
     const int lanev = lane * 16;
 
-    for (int unit = wid; unit < nunits; unit += 4) {
+    // (gridDim.z > 1, small grids: the units of a tile of positions are dealt out over that many blocks — at batch 1 the first upsampler is
+    // four tiles of sixteen units each on 256 CUs; every block stages the small input tile itself)
+    for (int unit = wid + 4 * (int)blockIdx.z; unit < nunits; unit += 4 * (int)gridDim.z) {
         const int cp = unit % NCP, rest = unit / NCP;
         const int half = rest % nhalf, cb = rest / nhalf;
         floatx16 acc[PH][NR];
@@ -529,7 +531,11 @@ hipError_t launch_convt16_stream(const PackedConv& w, const Conv16Call& c, int a
                 if (ea != hipSuccess) return ea;
                 big_lds_set.done();
             }
-            dim3 grid((ncols_max + BN - 1) / BN, c.batch);
+            const int64_t tiles = (int64_t)((ncols_max + BN - 1) / BN) * c.batch;
+            const int nunits = (p.cout >> 5) * (p.s / 4) * (BN / 64);
+            int zsplit = 1;
+            if (tiles <= kernel_knobs().convt16_split_max) zsplit = nunits >= 16 ? 4 : (nunits >= 8 ? 2 : 1);
+            dim3 grid((ncols_max + BN - 1) / BN, c.batch, zsplit);
             VITS_KLAUNCH((convt16_lines_kernel<BN, BFv>), grid, dim3(256), lds, s, p);
             return hipGetLastError();
         };
