@@ -208,7 +208,7 @@ def test_pipeline_survives_failed_submits_and_an_early_close(pkg, full_bytes):
 def test_randomised_identities_hold():
     """tests/fuzz_identity.py with a small budget: random batches / lengths / modes / arithmetic switches on one handle / window sizes /
     emulated tables — a row alone == the row in its batch, windowed == whole, two pipelined batches == process_batch, 16-bit durations ==
-    fp32 durations (all bit for bit), and the small architecture against the oracle in the same arithmetic. (By hand: 2,400 trials before and 2,400 after the latency kernels, three
+    fp32 durations (all bit for bit), and the small architecture against the oracle in the same arithmetic. (By hand: 2,400 trials before the small-grid kernels, 2,400 after the first of them and 2,400 on the final build, three
     seeds, no identity ever failed; the oracle comparison met two isolated fp16 rounding flips, 3 of 1,984 samples.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
