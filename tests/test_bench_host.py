@@ -67,3 +67,46 @@ def test_kernel_names_map_to_the_keys_the_engine_prints():
     for name, key in cases.items():
         assert pmc_common.bench_key(name) == key, name
     assert pmc_common.bench_key("vits::add_layer_norm_kernel(float const*, long)") is None
+
+
+def test_final_line_is_small_and_parses(tmp_path, monkeypatch, capsys):
+    """The driver parses the LAST stdout line of bench.py and keeps a bounded tail (round 4: a 24 KB line came back as `parsed: null`).
+    compact_line() of a worst-case result — the round-4 record with every string padded and 64 sub-results' worth of prose — stays under
+    4 KB, is one line of valid JSON, and carries the contract's keys with `roofline` and `cpu_baseline`; the full record goes to a side file."""
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_under_test2")
+    with open(os.path.join(ROOT, "tests", "golden", "bench_record_r4.json")) as fh:
+        res = json.load(fh)
+    assert len(json.dumps(res)) > 20000  # the round-4 shape
+    pad = "x" * 4000
+    res["config"]["workload"] += pad
+    res["metric"] += pad
+    res["roofline"]["kernel"] += pad
+    res["roofline"]["traffic_unit"] = pad
+    res["cpu_baseline"]["sample"] += pad
+    res["top_kernels"] = res["top_kernels"] * 8
+    for name, d in res["sub_results"].items():
+        if isinstance(d, dict):
+            d["schedule"] = pad
+            d["hbm_source"] = "profiles/round5_some_quite_long_artefact_name_pmc_traffic.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "gpurun_out").mkdir()
+    rel = bench.write_detail(res)
+    assert rel == "bench_detail.json" and json.load(open(tmp_path / rel))["top_kernels"]
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))["metric"] == res["metric"]
+    line = bench.compact_line(res, rel)
+    print("noise before")
+    print(line)
+    last = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(last.encode()) < 4096 and "\n" not in line
+    got = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == float("%.6g" % res["value"]) and got["config"]["source_sha16"] == res["config"]["source_sha16"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(got["roofline"])
+    assert abs(got["roofline"]["frac"] - got["roofline"]["achieved"] / got["roofline"]["peak"]) < 1e-5
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(got["cpu_baseline"])
+    assert set(got["sub_results"]) == {"c2_f32", "c2_f16", "c3_f32", "c3_f16", "c3_bf16", "c5_f32", "c5_bf16"}
+    assert all(set(e) >= {"value", "ms_per_step", "frac_of_binding_roof", "hbm_source"} for e in got["sub_results"].values())
+    # no prose survives in the sub-results
+    assert all(not isinstance(v, str) or len(v) < 100 for e in got["sub_results"].values() for v in e.values())
