@@ -2,6 +2,8 @@
 sizes checks the properties the library promises, bit for bit —
   * a row of a ragged batch == the same utterance alone (noise stream keyed by seed + row),
   * windowed vocoder == whole vocoder, pipelined submit / wait == process_batch, a second handle == the first,
+  * vits_model_process_batch split in two pipelined parts inside the call (the main handle is loaded with VITS_SPLIT_MIN_BATCH=2 and an
+    uneven VITS_SPLIT_FIRST_PCT) == the unsplit call of a handle loaded with VITS_SPLIT_MIN_BATCH=0,
   * 16-bit modes (default scope): durations and frame counts == the fp32 run,
 and, for the small architecture, float parity with the oracle in the same arithmetic (waveform <= tol x RMS, durations exact).
 usage: python tests/fuzz_identity.py [--trials N] [--seed S] [--no-oracle]"""
@@ -31,7 +33,13 @@ def model(arch, arith, ref=False):
     second one that stays in fp32 (the reference of the 16-bit duration check)."""
     key = (arch, ref)
     if key not in models:
-        models[key] = [pkg.Model(pkg.synth_model_bytes(0x5EED, arch)), "f32", False]
+        # (knobs are read when a model is loaded) main handle: every batch of two or more is split 37 : 63; ref / "unsplit" handles: never
+        os.environ["VITS_SPLIT_MIN_BATCH"] = "0" if ref else "2"
+        os.environ["VITS_SPLIT_FIRST_PCT"] = "37"
+        try:
+            models[key] = [pkg.Model(pkg.synth_model_bytes(0x5EED, arch)), "f32", False]
+        finally:
+            del os.environ["VITS_SPLIT_MIN_BATCH"], os.environ["VITS_SPLIT_FIRST_PCT"]
     e = models[key]
     if e[1] != arith:
         e[0].set_arith(ARITH[arith])
@@ -40,7 +48,7 @@ def model(arch, arith, ref=False):
 
 
 def tables(arch, on):
-    for ref in (False, True):
+    for ref in (False, True, "unsplit"):
         e = models.get((arch, ref))
         if e and e[2] != on:
             e[0].set_ggml_tables(on)
@@ -56,7 +64,7 @@ def same(a, b, what, ctx):
 
 
 t0 = time.time()
-counts = {"trials": 0, "single": 0, "windowed": 0, "pipelined": 0, "dur16": 0, "oracle": 0}
+counts = {"trials": 0, "single": 0, "windowed": 0, "pipelined": 0, "split": 0, "dur16": 0, "oracle": 0}
 worst = 0.0
 for trial in range(args.trials):
     arch = pkg.SYNTH_TINY if rng.random() < 0.4 else pkg.SYNTH_FULL
@@ -75,6 +83,7 @@ for trial in range(args.trials):
     ctx = dict(trial=trial, arch=arch, arith=arith, mode=mode, B=B, L=L, lens=lens.tolist(), seed=seed, fixed=fixed, chunk=chunk)
     m = model(arch, arith)
     model(arch, "f32", ref=True)
+    unsplit = model(arch, arith, ref="unsplit")
     ggml = bool(rng.random() < 0.2)
     tables(arch, ggml)
     ctx["ggml_tables"] = ggml
@@ -87,6 +96,10 @@ for trial in range(args.trials):
         one = m.process_batch(ids[b:b + 1, :lens[b]], mode=mode, noise_seed=seed + b, fixed_duration=fixed)
         same(([A[0][b]], A[1][b:b + 1], A[2][b:b + 1]), one, "row alone", ctx)
         counts["single"] += 1
+    # the call split in two pipelined parts (this handle, B >= 2) == the unsplit call
+    if B >= 2:
+        same(A, unsplit.process_batch(ids, **kw), "split in two", ctx)
+        counts["split"] += 1
     # windowed vocoder
     same(A, m.process_batch(ids, vocoder_chunk_frames=chunk, **kw), "windowed", ctx)
     counts["windowed"] += 1

@@ -214,3 +214,64 @@ def test_randomised_identities_hold():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_identity.py"), "--trials", "120", "--seed", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_free_model_is_refused_while_a_call_is_inside(pkg, full_bytes):
+    """vits_free_model on a handle a call is in progress on (here: from that call's own streaming callback) frees nothing and says so —
+    the reference deletes the model under the running call (src/vits.cpp:1217-1219). The call completes with the right PCM; the handle
+    is freed normally afterwards."""
+    m = pkg.Model(full_bytes)
+    ids, lens = ragged_ids(pkg, [40, 9])
+    want = m.process_batch(ids, id_lengths=lens, noise_seed=3)
+    said = []
+
+    def sink(utt, offset, pcm):
+        pkg.lib().vits_free_model(m._h)
+        said.append(pkg.last_error())
+        return False
+
+    got = m.process_batch(ids, id_lengths=lens, noise_seed=3, vocoder_chunk_frames=32, on_chunk=sink)
+    assert said and all("model busy" in s and "not freed" in s for s in said), said[:2]
+    for a, b in zip(want[0], got[0]):
+        assert np.array_equal(a, b)
+    m.close()
+
+
+@pytest.mark.parametrize("arith", ["f32", "f16"])
+def test_large_batches_are_split_inside_the_call_and_stay_bit_identical(pkg, full_bytes, arith):
+    """vits_model_process_batch with B >= 32 (VITS_SPLIT_MIN_BATCH) runs as two pipelined parts inside the call — the drop-in callers' share
+    of the pipeline. Same PCM / lengths / frames as a handle that never splits, with ragged lengths (the parts have different strides),
+    caller-chosen noise_seed_offsets, and a host copy; a B = 31 batch is not split."""
+    os.environ["VITS_SPLIT_MIN_BATCH"] = "0"
+    try:
+        plain = pkg.Model(full_bytes)
+    finally:
+        del os.environ["VITS_SPLIT_MIN_BATCH"]
+    m = pkg.Model(full_bytes)
+    try:
+        for h in (m, plain):
+            h.set_arith(pkg.ARITH_F16 if arith == "f16" else pkg.ARITH_F32)
+        rng = np.random.default_rng(5)
+        lens = rng.integers(1, 49, size=40).astype(np.int32)
+        lens[3], lens[37] = 48, 2
+        ids, lens = ragged_ids(pkg, lens.tolist(), seed=9)
+        for kw in (dict(), dict(noise_seed_offsets=rng.permutation(40).astype(np.int32)), dict(mode=pkg.MODE_HF, fixed_duration=2)):
+            want = plain.process_batch(ids, id_lengths=lens, noise_seed=77, **kw)
+            got = m.process_batch(ids, id_lengths=lens, noise_seed=77, **kw)
+            assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+            for a, b in zip(want[0], got[0]):
+                assert np.array_equal(a, b)
+            assert m.pending == 0
+        # an error inside the second part (token id out of range) leaves nothing in flight
+        bad = ids.copy()
+        bad[39, 0] = 10 ** 6
+        with pytest.raises(pkg.VitsError, match="token id"):
+            m.process_batch(bad, id_lengths=lens)
+        assert m.pending == 0
+        got = m.process_batch(ids, id_lengths=lens, noise_seed=77)
+        want = plain.process_batch(ids, id_lengths=lens, noise_seed=77)
+        for a, b in zip(want[0], got[0]):
+            assert np.array_equal(a, b)
+    finally:
+        m.close()
+        plain.close()

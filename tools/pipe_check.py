@@ -30,5 +30,25 @@ for arith in (pkg.ARITH_F32, pkg.ARITH_F16):
             host = bufs[s].cpu().numpy()
             for b in range(4):
                 assert np.array_equal(host[b, : lw[b]], pw[b]), (arith, kw, s, b)
+# An opts.async call (returns with its flow / vocoder still queued on the main stream) followed by a pipelined submit on the same handle:
+# stage one of the submit runs on the front-end stream into the SAME stage-one arena (slot 0) the async batch is still reading; the engine
+# orders it behind the async tail. Different ids in the two batches, so an overwritten arena would change the async batch's PCM.
+m.set_arith(pkg.ARITH_F32)
+big, other = pkg.synth_ids(24, 128), pkg.synth_ids(24, 128, ids_seed=777)
+cap = 256 * 2 * 128 + 294
+kw = dict(fixed_duration=2, out_device_stride=cap, skip_host_copy=True)
+ba, bb = (torch.zeros((24, cap), dtype=torch.float32, device="cuda") for _ in range(2))
+want_a = m.process_batch(big, noise_seed=11, fixed_duration=2)
+want_b = m.process_batch(other, noise_seed=12, fixed_duration=2)
+for _ in range(3):
+    ba.zero_(); bb.zero_(); torch.cuda.synchronize()
+    m.process_batch(big, noise_seed=11, out_device=ba.data_ptr(), async_=True, keep_pcm=False, **kw)
+    m.submit_batch(other, noise_seed=12, out_device=bb.data_ptr(), **kw)
+    m.wait()
+    m.sync()
+    ha, hb = ba.cpu().numpy(), bb.cpu().numpy()
+    for b in range(24):
+        assert np.array_equal(ha[b, : want_a[1][b]], want_a[0][b]), ("async batch corrupted by the following submit", b)
+        assert np.array_equal(hb[b, : want_b[1][b]], want_b[0][b]), ("submit after async", b)
 m.close()
 print("pipe_check ok")

@@ -80,7 +80,15 @@ VITS_API vits_model* vits_model_load_from_file(const char* path) {
 }
 
 // reference: src/vits.cpp:1217-1219
+// A handle another thread is inside (or that a callback is running on) is NOT freed: the call would go on using the engine it
+// runs on. The flag is taken and never given back — the handle is dead after this call either way.
 VITS_API void vits_free_model(vits_model* model) {
+    if (!model) return;
+    bool expected = false;
+    if (!model->eng.busy.compare_exchange_strong(expected, true, std::memory_order_acquire)) {
+        set_err("vits_free_model: model busy (a call is in progress on this handle); not freed — call again when it has returned");
+        return;
+    }
     try {
         delete model;
     } catch (...) {
@@ -220,7 +228,13 @@ VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, con
     o.noise_kind = VITS_NOISE_COUNTER;
     if (opts) std::memcpy(&o, opts, std::min<size_t>(sizeof(o), opts->struct_size ? opts->struct_size : sizeof(o)));
     std::string err;
-    const int rc = model->eng.process_batch(ids, id_lengths, batch, id_stride, o, out, err);
+    int rc;
+    try {
+        rc = model->eng.process_batch(ids, id_lengths, batch, id_stride, o, out, err);
+    } catch (...) {
+        if (out) vits_free_batch_result(out);  // (std::bad_alloc on the PCM buffer: nothing half-filled reaches the caller)
+        throw;
+    }
     if (rc != 0) {
         set_err(err);
         if (out) vits_free_batch_result(out);
@@ -258,7 +272,14 @@ VITS_API int vits_model_wait(vits_model* model, vits_batch_result* out) {
     }
     VITS_ENTER(model, -1)
     std::string err;
-    const int rc = model->eng.wait_batch(out, err);
+    int rc;
+    try {
+        rc = model->eng.wait_batch(out, err);
+    } catch (...) {
+        // (std::bad_alloc on the PCM buffer: the arrays already allocated go back, *out is left zeroed, the batch stays waitable)
+        if (out) vits_free_batch_result(out);
+        throw;
+    }
     if (rc != 0) {
         set_err(err);
         if (out) vits_free_batch_result(out);

@@ -96,6 +96,7 @@ hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipSt
 int Engine::sync(std::string& err) {
     if (front_) HIP_OK(hipStreamSynchronize(front_));
     HIP_OK(hipStreamSynchronize(stream));
+    async_tail_ = false;
     return 0;
 }
 
@@ -105,8 +106,78 @@ int Engine::process_batch(const int32_t* ids, const int32_t* id_lens, int B, int
         err = "batches in flight: call vits_model_wait for every submitted batch first";
         return -1;
     }
+    // The drop-in callers' share of the pipeline: a large batch is split in two inside the call — stage one of the
+    // second part runs on the front-end stream under the flow / vocoder of the first, exactly as two vits_model_submit_batch calls would.
+    // Every kernel is batch-invariant, so PCM, lengths and frames are those of the unsplit call bit for bit (GPU test, fuzz_identity.py).
+    const int smin = knobs.split_min_batch;
+    if (smin > 0 && B >= smin && B >= 2 && front_ && !prof.on && !knobs.no_pipeline && o.noise_kind == VITS_NOISE_COUNTER && !o.collect_taps && !o.on_chunk &&
+        !o.frames_only && !o.async && o.vocoder_chunk_frames <= 0)
+        return process_split(ids, id_lens, B, id_stride, o, out, err);
     a1_slot_ = 0;
     return process_impl(ids, id_lens, B, id_stride, o, out, err, nullptr);
+}
+
+int Engine::process_split(const int32_t* ids, const int32_t* id_lens, int B, int id_stride, const vits_process_opts& o, vits_batch_result* out,
+                          std::string& err) {
+    // first part: knobs.split_first_pct per cent of the utterances (its stage one is the only exposed one)
+    const int B1 = std::min(B - 1, std::max(1, (int)(((int64_t)B * knobs.split_first_pct + 50) / 100)));
+    const int nb[2] = {B1, B - B1}, b0[2] = {0, B1};
+    std::vector<int32_t> offs(B);
+    for (int b = 0; b < B; ++b) offs[b] = o.noise_seed_offsets ? o.noise_seed_offsets[b] : b;  // (a part keeps its utterances' global noise streams)
+    int queued = 0;
+    for (int h = 0; h < 2; ++h) {
+        vits_process_opts oh = o;
+        oh.noise_seed_offsets = offs.data() + b0[h];
+        if (o.out_device) oh.out_device = (float*)o.out_device + (int64_t)b0[h] * o.out_device_stride;
+        if (submit_batch(ids + (size_t)b0[h] * id_stride, id_lens ? id_lens + b0[h] : nullptr, nb[h], id_stride, oh, err)) break;
+        ++queued;
+    }
+    if (queued < 2) {
+        std::string ignored;
+        while (pending()) wait_batch(nullptr, ignored);
+        return -1;
+    }
+    // hand over: the parts' results side by side, rows at the stride of the longer part
+    Pending* part[2] = {&pend_[wait_seq_ & 1], &pend_[(wait_seq_ + 1) & 1]};
+    int rc = 0;
+    for (int h = 0; h < 2 && !rc; ++h)
+        if (hipEventSynchronize(part[h]->done) != hipSuccess) {
+            err = "hipEventSynchronize failed";
+            rc = -1;
+        }
+    // (the two slots are released whatever happens below: an allocation failure must not leave the handle with batches in flight)
+    struct Release {
+        Engine& e;
+        Pending** part;
+        ~Release() {
+            for (int h = 0; h < 2; ++h) {
+                part[h]->active = false;
+                ++e.wait_seq_;
+            }
+        }
+    } release{*this, part};
+    if (!rc && out) {
+        const size_t stride = std::max(part[0]->stride, part[1]->stride);
+        out->batch = (size_t)B;
+        out->stride = stride;
+        out->lengths = new int64_t[B];
+        out->frames = new int64_t[B];
+        out->data = nullptr;
+        if (!o.skip_host_copy) out->data = new float[(size_t)B * stride];
+        for (int h = 0; h < 2; ++h) {
+            const Pending& p = *part[h];
+            std::copy(p.lengths.begin(), p.lengths.end(), out->lengths + b0[h]);
+            std::copy(p.frames.begin(), p.frames.end(), out->frames + b0[h]);
+            if (out->data)
+                for (int b = 0; b < nb[h]; ++b) {
+                    float* dst = out->data + (size_t)(b0[h] + b) * stride;
+                    std::memcpy(dst, p.host + (size_t)b * p.stride, sizeof(float) * p.stride);
+                    // (columns past a row's own length are unspecified in the unsplit result too; keep them defined)
+                    if (p.stride < stride) std::memset(dst + p.stride, 0, sizeof(float) * (stride - p.stride));
+                }
+        }
+    }
+    return rc;
 }
 
 // ---- pipelined batches (vits.h: vits_model_submit_batch / vits_model_wait) --------------------------------------------------
@@ -228,6 +299,13 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
     const bool overlap = pend && front_ && !prof.on;
     StreamSwap s1_stream(stream, overlap ? front_ : stream);
     hipStream_t const main_stream = s1_stream.saved;
+    if (overlap && async_tail_) {
+        // an earlier opts.async call returned without synchronising: its flow / vocoder may still be reading stage-one arena 0 on the
+        // main stream, and nothing else orders the front-end stream behind it: stage one of this batch waits for that tail
+        if (!ev_async_) HIP_OK(hipEventCreateWithFlags(&ev_async_, hipEventDisableTiming));
+        HIP_OK(hipEventRecord(ev_async_, main_stream));
+        HIP_OK(hipStreamWaitEvent(front_, ev_async_, 0));
+    }
     if (layout_stage_one(c)) return -1;
     if (run_text_encoder(c)) return -1;
     if (run_duration_predictor(c)) return -1;
@@ -501,6 +579,7 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
             prof.fence();
         }
     }
+    async_tail_ = want_async;
     if (!want_async) {
         HIP_OK(hipStreamSynchronize(stream));
         prof.fence();

@@ -128,6 +128,8 @@ struct Knobs {
     bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
     int front_prio = 1;          // VITS_FRONT_PRIO=0: the front-end stream of pipelined batches at normal instead of high priority
     bool keep_stage_sum32 = false;  // VITS_KEEP_STAGE_SUM32: 16-bit vocoder: also store the fp32 resblock sum of a stage's last resblock (nobody reads it)
+    int split_min_batch = 32;    // VITS_SPLIT_MIN_BATCH: vits_model_process_batch splits batches of at least this many utterances in two pipelined parts (0: never)
+    int split_first_pct = 50;    // VITS_SPLIT_FIRST_PCT: share of the utterances in the first part (its stage one is the exposed one)
     bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
     KernelKnobs kernel;          // the launch functions' own tuning knobs (kernels.h), installed per call by KernelKnobsScope
     void read();
@@ -228,6 +230,9 @@ class Engine {
     } pend_[2];
     std::atomic<uint64_t> submit_seq_{0}, wait_seq_{0};  // batch n lives in pend_[n & 1]; written under the busy flag, read by vits_model_pending
     hipStream_t front_ = nullptr;             // stage one of pipelined batches (created on first use)
+    bool async_tail_ = false;                 // the last process_batch returned with device work still queued (opts.async)
+    hipEvent_t ev_async_ = nullptr;           // orders the front-end stream behind that tail
+    int process_split(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out, std::string& err);
     int process_impl(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out, std::string& err,
                      Pending* pend);
     // The three resblocks of a vocoder stage (kernel sizes 3/7/11) are independent chains of six convolutions; they run on

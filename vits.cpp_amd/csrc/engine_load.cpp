@@ -27,6 +27,7 @@ Engine::~Engine() {
         if (hs.p) hipHostFree(hs.p);
         if (hs.ev) hipEventDestroy(hs.ev);
     }
+    if (ev_async_) hipEventDestroy(ev_async_);
     if (ev_fork_) hipEventDestroy(ev_fork_);
     for (hipEvent_t e : ev_done_)
         if (e) hipEventDestroy(e);
@@ -214,7 +215,7 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
         }
     }
     out.bias = bias.empty() ? nullptr : upload(bias);
-    out.bytes = (int64_t)packed.size() * 4 * (out.wp_l16 ? 2 : 1);
+    out.bytes = (int64_t)packed.size() * 4;  // what ONE launch reads (a launch takes wp or wp_l16, never both; weight_bytes counts both copies)
     if (!out.wp) {
         err = "hipMalloc failed for " + wname;
         return false;

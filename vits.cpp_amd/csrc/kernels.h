@@ -209,7 +209,7 @@ std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, i
                                      int* nchunks);
 // conv_lat16_kernel's A fragments from the packed array: [32-row tile][16-row half][quad = 16 input channels of one tap][lane][4] with lane l = row l & 15,
 // component s = channel 4 s + (l >> 4) of the quad: one 16-byte load per lane feeds four consecutive MFMAs. Same size as `packed`.
-bool conv_lat16_candidate(int epi, int kt, int cin);  // the layers worth a second copy of their weights (STD k <= 3 / GATE k = 5 with >= 512 products per output)
+bool conv_lat16_candidate(int epi, int kt, int cin);  // the layers that get a second copy of their fp32 weights for the latency kernel: every STD conv and the 5-tap GATE convs with >= 64 products per output
 std::vector<float> repack_conv_weights_l16(const std::vector<float>& packed, int mtiles, int nchunks, int kt);
 int choose_conv_tile(int rows, int epi, int t_hint);
 int resolve_conv_tile(const PackedConv& w, const ConvCall& c);  // the tile launch_conv will use (small-grid rules included)
