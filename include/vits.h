@@ -305,6 +305,39 @@ VITS_API int vits_pcm16_from_float_device(const float* src, int64_t src_stride, 
 /* Writes a canonical 44-byte-header RIFF/WAVE file exactly like test/main.cpp:36-60. Returns 0 on success. */
 VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int32_t sample_rate);
 
+/* ---- multi-GPU: the path's one exchange for C / C++ / Swift hosts -------------------------------------------------------
+ * The reference synthesises one utterance per call (vits.cpp:184,303; callers test/main.cpp:68-78), so a batch shards by utterance:
+ * ONE PROCESS PER GPU, each with its own model handle (vits_set_device(local_rank), weights replicated), rank r synthesising its own
+ * rows — no data-path collective until the end, where every rank wants the whole batch's PCM. These three calls are that end: a
+ * ragged all-gather over RCCL (xGMI inside a node) — the per-utterance lengths first (fixed size), then the rows padded to the longest
+ * utterance of any rank. It is what vits.cpp_amd/multi_gpu.py does through torch.distributed, without Python. RCCL is loaded with
+ * dlopen on first use (VITS_RCCL_LIB overrides the library name): single-GPU users need nothing, and world == 1 never touches it.
+ *   rank 0:     char id[VITS_GATHER_ID_BYTES]; vits_pcm_gather_unique_id(id);  -> hand the 128 bytes to the other ranks (file, socket, MPI ...)
+ *   every rank: g = vits_pcm_gather_init(id, sizeof id, rank, world, rows, row_capacity, 4);           (collective: all ranks call it)
+ *   per batch:  vits_model_process_batch(..., opts.out_device = pcm, opts.skip_host_copy = 1, &r);
+ *               vits_pcm_gather(g, pcm, stride, r.lengths, NULL, &all);                                 (collective)
+ *               -> all.data: DEVICE [world * rows][all.stride], rank blocks in rank order; all.lengths: host [world * rows]
+ *   end:        vits_pcm_gather_destroy(g);
+ * rows is the same on every rank (pad a short shard with zero-length rows); row_capacity >= the longest utterance anywhere, in elements.
+ * elem_bytes 4 = fp32 PCM, 2 = PCM16 (vits_pcm16_from_float_device first: half the bytes on the links). `hip_stream` = the stream the PCM was
+ * produced on (the exchange is ordered behind it without a host wait), NULL when the producer has been synchronised — vits_model_process_batch
+ * without opts.async has. The call returns when the gathered block is complete; it stays valid until the next call on the same object.
+ * One call at a time per object. Return 0 / non-NULL on success, else -1 / NULL with vits_last_error(). */
+#define VITS_GATHER_ID_BYTES 128
+typedef struct vits_gather_ctx vits_gather_ctx;
+typedef struct vits_gather_result {
+    const void* data;       /* device [rows_total][stride] elements, owned by the gather object */
+    int64_t stride;         /* elements between rows = the longest utterance of any rank */
+    const int64_t* lengths; /* host [rows_total]: elements per utterance, rank blocks in rank order */
+    int32_t rows_total;     /* world * rows */
+} vits_gather_result;
+VITS_API int vits_pcm_gather_unique_id(char* id_out /* [VITS_GATHER_ID_BYTES] */);
+VITS_API vits_gather_ctx* vits_pcm_gather_init(const char* id, size_t id_bytes, int32_t rank, int32_t world, int32_t rows, int64_t row_capacity,
+                                               int32_t elem_bytes);
+VITS_API int vits_pcm_gather(vits_gather_ctx* g, const void* pcm_device, int64_t pcm_stride, const int64_t* lengths_host, void* hip_stream,
+                             vits_gather_result* out);
+VITS_API void vits_pcm_gather_destroy(vits_gather_ctx* g);
+
 /* Select the HIP device used by subsequent loads on this thread (one process per GPU: pass LOCAL_RANK). */
 VITS_API int vits_set_device(int32_t device);
 

@@ -109,7 +109,22 @@ int main(void) {
     vits_model* m = vits_model_load_from_file("/nonexistent/model.ggml");
     if (m) { vits_result r = vits_model_process(m, "hello"); vits_free_result(r); vits_free_model(m); return 2; }
     printf("%s\n", vits_last_error());
-    return strstr(vits_last_error(), "failed to open file") ? 0 : 3;
+    if (!strstr(vits_last_error(), "failed to open file")) return 3;
+    /* the multi-GPU gather from C: bad arguments are refused with a message; a one-rank object needs a device (none here: NULL, no crash) */
+    {
+        vits_gather_result all;
+        char id[VITS_GATHER_ID_BYTES];
+        vits_gather_ctx* g;
+        memset(id, 0, sizeof id);
+        if (vits_pcm_gather_init(id, sizeof id, 2, 2, 4, 100, 4) != NULL) return 4;  /* rank >= world */
+        if (!strstr(vits_last_error(), "rank")) return 5;
+        if (vits_pcm_gather(NULL, NULL, 0, NULL, NULL, &all) != -1) return 6;
+        g = vits_pcm_gather_init(NULL, 0, 0, 1, 4, 100, 4);
+        if (g) vits_pcm_gather_destroy(g);  /* (a GPU box: fine) */
+        else printf("%s\n", vits_last_error());
+        vits_pcm_gather_destroy(NULL);
+    }
+    return 0;
 }
 ''')
     exe = tmp_path / "caller"

@@ -228,3 +228,14 @@ def test_tuning_knobs_do_not_change_a_single_bit():
                   {"VITS_MIN_BLOCKS": "1", "VITS_RB_GROUP": "1", "VITS_LRELU_COPY_MINC": "1000"},
                   {"VITS_NO_ONESHOT": "1", "VITS_NO_NARROW": "1", "VITS_NO_DDS_FUSE": "1", "VITS_NO_FUSE32": "1", "VITS_NO_WN_FUSE": "1"}):
         assert run(extra) == base, extra
+
+
+def test_c_abi_pcm_gather_world_one_with_and_without_rccl():
+    """include/vits.h vits_pcm_gather_* (the exchange of multi_gpu.PcmExchange for C / C++ / Swift hosts) on the one GPU of the box: world 1
+    as a plain copy, and through a real one-rank RCCL communicator (the calls of the N > 1 path), fp32 and PCM16 rows, bit-equal to the
+    host rows of vits_model_process_batch — tools/gather_check.py in its own process (RCCL brings its own threads up)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gather_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "gather_check ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

@@ -260,3 +260,95 @@ def test_pipelined_exchange_delivers_every_step_in_order(world, total, dtype):
             for u in range(total):
                 row = _fake_pcm(u + 1000 * step, want_len[u], cap, dtype).numpy()
                 assert (out[u, : want_len[u]] == row[: want_len[u]]).all() and not out[u, want_len[u]:].any()
+
+
+# ---- the C ABI's gather (include/vits.h vits_pcm_gather_*): unique-id plumbing with RCCL stubbed out --------------------------------
+_STUB_RCCL = r'''
+/* test stub of the five RCCL entry points pcm_gather.cpp binds (rccl.h:187,220,260,339,678): records what it is called with */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+typedef struct { char internal[128]; } ncclUniqueId;
+static void logline(const char* what, const ncclUniqueId* id, int rank, int world) {
+    const char* path = getenv("STUB_RCCL_LOG");
+    if (!path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "%s %d %d ", what, rank, world);
+    if (id) for (int i = 0; i < 128; ++i) fprintf(f, "%02x", (unsigned char)id->internal[i]);
+    fprintf(f, "\n");
+    fclose(f);
+}
+int ncclGetUniqueId(ncclUniqueId* id) {
+    for (int i = 0; i < 128; ++i) id->internal[i] = (char)(i * 7 + 3 + (getpid() & 0x3f));
+    logline("id", id, -1, -1);
+    return 0;
+}
+int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank) { *comm = malloc(8); logline("init", &id, rank, nranks); return 0; }
+int ncclCommDestroy(void* comm) { free(comm); logline("destroy", NULL, -1, -1); return 0; }
+const char* ncclGetErrorString(int r) { (void)r; return "stub error"; }
+int ncclAllGather(const void* s, void* r, size_t n, int dt, void* c, void* st) { (void)s; (void)r; (void)n; (void)dt; (void)c; (void)st; return 0; }
+'''
+
+
+def _gather_id_worker(rank, world, port, stub, log, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VITS_RCCL_LIB": stub, "STUB_RCCL_LOG": log})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    pkg = load_package()
+    # rank 0 creates the id through the C ABI; the HOST APPLICATION moves the 128 bytes (here: a gloo broadcast)
+    buf = torch.zeros(pkg.GATHER_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(pkg.gather_unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(buf, 0)
+    uid = bytes(buf.tolist())
+    said = []
+    for bad in (uid[:64], None):  # a truncated / missing id is refused before RCCL sees it
+        try:
+            pkg.PcmGather(bad, rank, world, 4, 1000)
+            said.append("accepted")
+        except pkg.VitsError as e:
+            said.append(str(e))
+    try:
+        pkg.PcmGather(uid, rank, world, 4, 1000)  # joins (stub), then needs a device for its buffers: there is none here
+        said.append("accepted")
+    except pkg.VitsError as e:
+        said.append(str(e))
+    q.put((rank, uid.hex(), said))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c_abi_gather_unique_id_reaches_every_rank(tmp_path):
+    """vits_pcm_gather_unique_id / vits_pcm_gather_init under two gloo-launched CPU processes with RCCL replaced by a recording stub
+    (VITS_RCCL_LIB): rank 0's 128 bytes arrive unchanged in ncclCommInitRank on both ranks with the right (rank, world); a malformed id
+    never reaches RCCL; and with no GPU the object refuses to exist (no CPU path) after giving the communicator back."""
+    import subprocess
+    src = tmp_path / "stub_rccl.c"
+    src.write_text(_STUB_RCCL)
+    stub = str(tmp_path / "libstub_rccl.so")
+    cc = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Werror", str(src), "-o", stub], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    log = str(tmp_path / "stub.log")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_id_worker, args=(r, 2, port, stub, log, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and len(got[0][1]) == 256
+    for rank, uid, said in got:
+        assert "128 bytes" in said[0] and "128 bytes" in said[1], said
+        assert "accepted" not in said[2] and ("device" in said[2].lower() or "hip" in said[2].lower()), said
+    lines = [ln.split() for ln in open(log).read().splitlines()]
+    inits = sorted((int(ln[1]), int(ln[2]), ln[3]) for ln in lines if ln[0] == "init")
+    assert inits == [(0, 2, got[0][1]), (1, 2, got[0][1])]
+    assert sum(ln[0] == "id" for ln in lines) == 1 and sum(ln[0] == "destroy" for ln in lines) == 2

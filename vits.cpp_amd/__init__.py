@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
     "vits_model_set_arith_scope", "vits_model_get_arith_scope", "vits_model_submit_batch", "vits_model_wait", "vits_model_pending",
     "vits_model_set_ggml_tables", "vits_model_get_ggml_tables",
+    "vits_pcm_gather_unique_id", "vits_pcm_gather_init", "vits_pcm_gather", "vits_pcm_gather_destroy",
 ]
 
 
@@ -566,6 +567,60 @@ def pcm16_device(src_ptr, src_stride, dst_ptr, dst_stride, rows, cols, lengths_p
     f.restype = C.c_int
     if f(src_ptr, src_stride, dst_ptr, dst_stride, lengths_ptr, rows, cols, stream) != 0:
         raise VitsError(last_error())
+
+
+GATHER_ID_BYTES = 128
+
+
+class GatherResult(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_int64), ("lengths", C.POINTER(C.c_int64)), ("rows_total", C.c_int32)]
+
+
+def gather_unique_id():
+    """vits_pcm_gather_unique_id: the 128 bytes rank 0 creates and hands to the other ranks (the RCCL unique id)."""
+    f = lib().vits_pcm_gather_unique_id
+    f.restype, f.argtypes = C.c_int, [C.c_char_p]
+    buf = C.create_string_buffer(GATHER_ID_BYTES)
+    if f(buf) != 0:
+        raise VitsError(last_error())
+    return buf.raw
+
+
+class PcmGather:
+    """The C ABI's PCM all-gather (include/vits.h vits_pcm_gather_*: RCCL through dlopen, no torch): what a C / C++ / Swift host calls;
+    multi_gpu.PcmExchange is the torch.distributed form of the same exchange."""
+
+    def __init__(self, unique_id, rank, world, rows, row_capacity, elem_bytes=4):
+        L = lib()
+        L.vits_pcm_gather_init.restype = C.c_void_p
+        L.vits_pcm_gather_init.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]
+        L.vits_pcm_gather.restype = C.c_int
+        L.vits_pcm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(GatherResult)]
+        L.vits_pcm_gather_destroy.restype = None
+        L.vits_pcm_gather_destroy.argtypes = [C.c_void_p]
+        self._h = L.vits_pcm_gather_init(unique_id, len(unique_id) if unique_id is not None else 0, rank, world, rows, row_capacity, elem_bytes)
+        if not self._h:
+            raise VitsError(last_error())
+
+    def gather(self, pcm_ptr, pcm_stride, lengths, stream=None):
+        """pcm_ptr: integer device address of [rows][pcm_stride]; lengths: host int64 [rows]. Returns (device address of the gathered
+        [rows_total][stride] block, stride, lengths of all rows as a numpy array)."""
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        r = GatherResult()
+        if lib().vits_pcm_gather(self._h, pcm_ptr, pcm_stride, _ptr(lengths), stream, C.byref(r)) != 0:
+            raise VitsError(last_error())
+        return r.data, int(r.stride), np.ctypeslib.as_array(r.lengths, shape=(r.rows_total,)).copy()
+
+    def close(self):
+        if self._h:
+            lib().vits_pcm_gather_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def write_wav16(path, pcm, sample_rate=16000):

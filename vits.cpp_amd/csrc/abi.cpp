@@ -13,6 +13,7 @@
 #include "../../include/vits.h"
 #include "busy_guard.h"
 #include "engine.h"
+#include "pcm_gather.h"
 
 namespace vits {
 void reference_noise_seed(uint32_t seed);
@@ -720,4 +721,79 @@ VITS_API int vits_op_add_layer_norm(int32_t batch, int32_t channels, int32_t t, 
     if (hipMemcpy(y, dy.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy back failed");
     return 0;
     VITS_CATCH(-1)
+}
+
+// ---- multi-GPU PCM gather (pcm_gather.cpp) ---------------------------------------------------------------------------------------
+struct vits_gather_ctx {
+    vits::PcmGather g;
+    std::atomic<bool> busy{false};
+};
+
+VITS_API int vits_pcm_gather_unique_id(char* id_out) {
+    VITS_TRY
+    if (!id_out) {
+        set_err("null argument");
+        return -1;
+    }
+    const vits::RcclApi& api = vits::RcclApi::get();
+    if (!api.ok()) {
+        set_err(api.why);
+        return -1;
+    }
+    vits::RcclApi::UniqueId uid;
+    std::memset(&uid, 0, sizeof(uid));
+    const int r = api.GetUniqueId(&uid);
+    if (r != 0) {
+        set_err(std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+        return -1;
+    }
+    std::memcpy(id_out, uid.internal, sizeof(uid.internal));
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API vits_gather_ctx* vits_pcm_gather_init(const char* id, size_t id_bytes, int32_t rank, int32_t world, int32_t rows, int64_t row_capacity, int32_t elem_bytes) {
+    VITS_TRY
+    vits_gather_ctx* h = new vits_gather_ctx();
+    std::string err;
+    if (!h->g.init(id, id_bytes, rank, world, rows, row_capacity, elem_bytes, err)) {
+        set_err(err);
+        delete h;
+        return nullptr;
+    }
+    return h;
+    VITS_CATCH(nullptr)
+}
+
+VITS_API int vits_pcm_gather(vits_gather_ctx* g, const void* pcm_device, int64_t pcm_stride, const int64_t* lengths_host, void* hip_stream, vits_gather_result* out) {
+    VITS_TRY
+    if (out) std::memset(out, 0, sizeof(*out));
+    if (!g) {
+        set_err("null argument");
+        return -1;
+    }
+    vits::BusyGuard guard(&g->busy);
+    if (!guard.entered()) {
+        set_err("gather busy: one call at a time per gather object");
+        return -1;
+    }
+    vits::PcmGather::Result r;
+    std::string err;
+    if (g->g.gather(pcm_device, pcm_stride, lengths_host, (hipStream_t)hip_stream, &r, err) != 0) {
+        set_err(err);
+        return -1;
+    }
+    out->data = r.data;
+    out->stride = r.stride;
+    out->lengths = r.lengths;
+    out->rows_total = r.rows_total;
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API void vits_pcm_gather_destroy(vits_gather_ctx* g) {
+    try {
+        delete g;
+    } catch (...) {
+    }
 }
