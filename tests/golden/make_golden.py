@@ -20,6 +20,12 @@ checked against (scripts/verify_layers.py:25) — computes; the oracle's VO_MODE
                            App. B Q1-Q5; see `reference_mode_patches`). They pin VO_MODE_REFERENCE / VITS_MODE_REFERENCE —
                            the default mode of vits_model_process and of bench.py — independently of the oracle's own reading.
 
+  *_arith_{f16,bf16}_taps.npz  third-party pin of the 16-BIT-OPERAND arithmetic (Q7: custom-ops.h:684-690 rounds the im2col of a conv to fp16;
+                           scripts/export_vits.py:79-88 stores conv weights as fp16): the same transformers model (reference-mode patches) with
+                           forward-pre hooks that round the INPUT of every Conv1d / ConvTranspose1d of the flow and the vocoder to the
+                           16-bit type (and the weights, for bf16), products and sums in fp32 — torch's conv, not the oracle's.
+                           Pins vo_opts.arith (VO_ARITH_F16 / BF16, default scope: stage one exact) and VITS_ARITH_*.
+
 usage: python tests/golden/make_golden.py            (from the repo root, after building csrc/libvits_hip.so)
 """
 import ast
@@ -210,8 +216,36 @@ class reference_mode_patches:
         self.mv._unconstrained_rational_quadratic_spline, self.mv.VitsElementwiseAffine.forward = self.saved
 
 
+class conv_operand_rounding:
+    """Q7 in torch: every Conv1d / ConvTranspose1d under the given sub-modules sees its input rounded (nearest even) to `dtype`, and weights rounded
+    to it as well (a no-op for fp16-stored weights in fp16 mode); accumulation stays fp32. `hf_taps` rounds by hand where it calls the functional
+    form (the reference-mode transposed convs)."""
+
+    def __init__(self, modules, dtype):
+        self.modules, self.dtype, self.handles, self.saved = modules, dtype, [], []
+
+    def round(self, t):
+        return t.to(self.dtype).to(torch.float32)
+
+    def __enter__(self):
+        for root in self.modules:
+            for m in root.modules():
+                if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d)):
+                    self.handles.append(m.register_forward_pre_hook(lambda mod, args: (self.round(args[0]),) + tuple(args[1:])))
+                    self.saved.append((m, m.weight.data.clone()))
+                    m.weight.data = self.round(m.weight.data)
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        for m, w in self.saved:
+            m.weight.data = w
+        return False
+
+
 @torch.no_grad()
-def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False, stage_one_only=False):
+def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False, stage_one_only=False, rounding=None):
     """Restates VitsModel.forward (modeling_vits.py:1298-1394) step by step to expose the stage outputs, with the two
     torch.randn draws replaced by the supplied arrays. refmode: call inside `reference_mode_patches()`; additionally the
     transposed convs run without padding (Q1, src/vits.cpp:187 overwrites padding with 0), the resblock mean is a multiply by
@@ -258,7 +292,8 @@ def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False, stage_one_only
         h = torch.nn.functional.leaky_relu(h, cfg.leaky_relu_slope)
         up = dec.upsampler[i]
         if refmode:
-            h = torch.nn.functional.conv_transpose1d(h, up.weight, up.bias, stride=up.stride, padding=0)  # Q1
+            hin = rounding.round(h) if rounding is not None else h  # (functional call: the module's pre-hook does not run; its weight is already rounded)
+            h = torch.nn.functional.conv_transpose1d(hin, up.weight, up.bias, stride=up.stride, padding=0)  # Q1
         else:
             h = up(h)
         res = dec.resblocks[i * dec.num_kernels](h)
@@ -277,6 +312,53 @@ def hf_taps(model, ids, noise_dur, noise_prior_fn, refmode=False, stage_one_only
         enc_out=f(hidden), prior_mean=f(prior_means.transpose(1, 2)), prior_logvar=f(prior_logvar.transpose(1, 2)),
         log_duration=f(log_duration), durations=f(duration), z_p=f(z_p), z_flow=f(spec), pre_tanh=f(pre), waveform=f(wave),
     )
+
+
+def arith16_taps_for(parsed, T, seed, dtype, refmode=True):
+    """Same inputs as taps_for(parsed, T, seed, refmode); the flow and the vocoder in 16-bit-operand arithmetic (default scope: stage one exact fp32)."""
+    model = hf_model_from_file(parsed)
+    rng = np.random.default_rng(seed)
+    ids = make_ids(T, model.config.vocab_size, seed)
+    nd = rng.standard_normal((2, T)).astype(np.float32)
+    F = model.config.flow_size
+    import contextlib
+    with (reference_mode_patches() if refmode else contextlib.nullcontext()):
+        with conv_operand_rounding([model.flow, model.decoder], dtype) as cr:
+            return hf_taps(model, ids, nd, lambda L: rng.standard_normal((F, L)).astype(np.float32), refmode=refmode, rounding=cr)
+
+
+def arith16_op_fixtures():
+    """Operator-level pins of the 16-bit-operand arithmetic, by torch: Conv1d / ConvTranspose1d with BOTH operands rounded to fp16 / bf16 and fp32
+    accumulation (Q7: the im2col of custom-ops.h:684-690 is fp16, the exported weights are fp16, ggml accumulates in fp32), input LeakyReLU before
+    the rounding where the path fuses it (vits.cpp:554,613). Small shapes: the whole file is a few hundred KB."""
+    rng = np.random.default_rng(2024)
+    out, n = {}, 0
+    F = torch.nn.functional
+    conv_cases = [(24, 40, 1, 1, 40, 1.0), (32, 32, 3, 1, 48, 0.1), (32, 32, 3, 5, 48, 0.1), (16, 24, 5, 1, 40, 1.0), (32, 32, 7, 3, 64, 0.1), (32, 32, 11, 5, 96, 0.1),
+                  (192, 29, 1, 1, 17, 1.0)]
+    for dt_name, dtype, arith in (("f16", torch.float16, 2), ("bf16", torch.bfloat16, 1)):
+        rd = lambda t: t.to(dtype).to(torch.float32)
+        for cin, cout, k, dil, T, slope in conv_cases:
+            x = rng.standard_normal((1, cin, T)).astype(np.float32)
+            w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+            xt = torch.from_numpy(x)
+            if slope != 1.0:
+                xt = F.leaky_relu(xt, slope)
+            y = F.conv1d(rd(xt), rd(torch.from_numpy(w)), torch.from_numpy(b), dilation=dil, padding=(k - 1) * dil // 2)
+            out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "y_%d" % n: y.numpy(), "meta_%d" % n: np.array([0, dil, 0, round(slope * 1e6), arith], np.int64)})
+            n += 1
+        for cin, cout, k, s, T in ((32, 16, 16, 8, 12), (32, 16, 4, 2, 40)):
+            for crop in (0, (k - s) // 2):
+                x = rng.standard_normal((1, cin, T)).astype(np.float32)
+                w = (rng.standard_normal((cin, cout, k)) / np.sqrt(cin * 2)).astype(np.float32)
+                b = rng.standard_normal(cout).astype(np.float32)
+                y = F.conv_transpose1d(rd(F.leaky_relu(torch.from_numpy(x), 0.1)), rd(torch.from_numpy(w)), torch.from_numpy(b), stride=s, padding=crop)
+                out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "y_%d" % n: y.numpy(), "meta_%d" % n: np.array([1, s, crop, 100000, arith], np.int64)})
+                n += 1
+    out["n_cases"] = np.array([n], np.int64)
+    np.savez_compressed(os.path.join(HERE, "arith16_ops.npz"), **out)
+    print("arith16_ops.npz:", n, "cases,", os.path.getsize(os.path.join(HERE, "arith16_ops.npz")), "bytes")
 
 
 def make_ids(T, vocab, seed):
@@ -445,6 +527,17 @@ def main():
     for T, seed in ((8, 31), (32, 32)):
         np.savez_compressed(os.path.join(HERE, "full_synth_T%d_taps.npz" % T), **taps_for(parse_model_file(data), T, seed))
         np.savez_compressed(os.path.join(HERE, "full_synth_T%d_refmode_taps.npz" % T), **taps_for(parse_model_file(data), T, seed, refmode=True))
+    # (C3) the 16-bit-operand arithmetic modes (Q7), reference mode, tiny + full architecture, same inputs as (B) / (C)
+    tiny = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)
+    for name, dtype in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        a = arith16_taps_for(parse_model_file(tiny), 20, 12, dtype)
+        np.savez_compressed(os.path.join(HERE, "tiny_synth_arith_%s_taps.npz" % name), **a)
+        b16 = arith16_taps_for(parse_model_file(data), 16, 13, dtype)
+        np.savez_compressed(os.path.join(HERE, "full_synth_arith_%s_taps.npz" % name), **b16)
+        d = b16["waveform"].astype(np.float64) - rtaps["waveform"]
+        print("arith", name, "full: waveform vs the fp32 reference-mode fixture: max %.2e rms %.2e of RMS" % (
+            np.abs(d).max() / np.sqrt((rtaps["waveform"].astype(np.float64) ** 2).mean()), np.sqrt((d ** 2).mean()) / np.sqrt((rtaps["waveform"].astype(np.float64) ** 2).mean())))
+    arith16_op_fixtures()
     # (D) Q6: latents outside the spline interval (duration noise x 4: |0.8 * 4 * n| > 5 for one draw in eight), stage one only
     q = q6_taps_for(parse_model_file(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY)), 24, 21, 4.0)
     np.savez(os.path.join(HERE, "tiny_synth_q6_refmode_taps.npz"), **q)

@@ -351,3 +351,71 @@ def test_emulated_ggml_tables_option(pkg, oracle):
         d = np.abs(a[0] - b[0]).max()
         assert 1e-5 < d < 5e-2 and np.isfinite(b[0]).all()
         assert (a[1] != b[1]).mean() < 0.05
+
+
+@pytest.mark.parametrize("arch", ["tiny", "full"])
+@pytest.mark.parametrize("name,tol", [("f16", 5e-3), ("bf16", 8e-2)])
+def test_oracle_16bit_arithmetic_reproduces_the_torch_operand_rounding_fixtures(pkg, oracle, arch, name, tol):
+    """Third-party pin of vo_opts.arith ("the 16-bit-mode oracle has no third-party pin at all"): the fixtures are
+    transformers.VitsModel (reference-mode patches) with forward-pre hooks that round the input — and, for bf16, the weights — of every
+    Conv1d / ConvTranspose1d of the flow and the vocoder to the 16-bit type, fp32 products and sums by torch's own conv
+    (tests/golden/make_golden.py `conv_operand_rounding`; Q7: /root/reference/src/include/custom-ops.h:684-690 + scripts/export_vits.py:79-88).
+    Stage one is exact fp32 under the default scope: its taps and the integer durations meet the fp32 bounds.
+    Downstream, 16-bit-operand arithmetic is CHAOTIC at the size of its own rounding step: two correct implementations differ by fp32 summation
+    order, an activation within 1e-7 of a rounding boundary then rounds the other way (1e-3 relative for fp16, 8e-3 for bf16) and the gated
+    WaveNet layers carry that on. Measured inside torch alone (fp32 against fp64 accumulation of the SAME rounded operands, full architecture):
+    z_flow differs by 5.2e-4 (fp16) / 3.3e-3 (bf16) of RMS — exactly what the oracle shows against the fixture. So the whole-model bound is the
+    one of the GPU-vs-oracle tests of these modes (tests/test_gpu_arith16.py), with the RMS deviation bounded four times tighter; the pin that
+    DISCRIMINATES is the tiny architecture (two flows of two layers: the operand rounding is matched before the noise builds up — bf16 z_flow agrees
+    to 2e-7 where the fp32 oracle is 2e-3 away) and the operator-level fixtures below."""
+    g = golden("%s_synth_arith_%s_taps.npz" % (arch, name))
+    f32 = golden("%s_synth_refmode_taps.npz" % arch)
+    m = oracle.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY if arch == "tiny" else pkg.SYNTH_FULL))
+    arith = oracle.ARITH_F16 if name == "f16" else oracle.ARITH_BF16
+    kw = dict(mode=oracle.MODE_REFERENCE, noise_kind=oracle.NOISE_EXPLICIT, noise_dur=g["noise_dur"], noise_prior=g["noise_prior"])
+    r = m.process_ids(g["ids"], arith=arith, **kw)
+    np.testing.assert_array_equal(r["durations"], g["durations"].ravel())
+    np.testing.assert_array_equal(g["durations"], f32["durations"])  # the arithmetic mode does not move the durations (default scope)
+    for tap in ("enc_out", "prior_mean", "prior_logvar", "log_duration", "z_p"):
+        assert rel_err(r[tap], g[tap]) < 1e-4, tap
+
+    def dev(a, b):
+        a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+        rms = np.sqrt((b ** 2).mean())
+        return np.abs(a - b).max() / rms, np.sqrt(((a - b) ** 2).mean()) / rms
+
+    for tap in ("z_flow", "pre_tanh", "waveform"):
+        mx, rms = dev(r[tap], g[tap])
+        assert mx < tol and rms < tol / 4, (tap, mx, rms)
+    # the fixture really is in another arithmetic than fp32: it differs from the fp32 reference-mode fixture by the mode's rounding noise
+    assert dev(g["waveform"], f32["waveform"])[0] > (5e-4 if name == "f16" else 4e-3)
+    if arch == "tiny":
+        # discrimination: the oracle in fp32 arithmetic is several times further from the fixture's flow output than the oracle in the fixture's arithmetic
+        r32 = m.process_ids(g["ids"], taps=["z_flow"], **kw)
+        assert dev(r["z_flow"], g["z_flow"])[1] * 3 < dev(r32["z_flow"], g["z_flow"])[1]
+        assert dev(r["z_flow"], g["z_flow"])[1] < (1e-4 if name == "f16" else 1e-5)
+
+
+def test_oracle_16bit_conv_operators_reproduce_torch_with_rounded_operands(oracle):
+    """Operator-level third-party pin of the 16-bit-operand arithmetic: tests/golden/arith16_ops.npz holds inputs and torch outputs of
+    Conv1d (taps 1 / 3 / 5 / 7 / 11, dilations 1 / 3 / 5, fused input LeakyReLU) and ConvTranspose1d (strides 8 / 2, reference crop 0 and HF crop)
+    with BOTH operands rounded to fp16 / bf16 and fp32 accumulation (make_golden.py `arith16_op_fixtures`). One conv differs between two
+    correct implementations by fp32 summation order only: 2e-5 of RMS, the fp32 bound — far below the modes' own rounding step, which the oracle
+    WITHOUT the operand rounding (arith = fp32) must therefore miss."""
+    g = golden("arith16_ops.npz")
+    n = int(g["n_cases"][0])
+    assert n >= 8
+    for i in range(n):
+        meta = g["meta_%d" % i]  # kind (0 conv, 1 transposed), dilation | stride, crop, slope x 1e6, arith
+        kind, p1, crop, slope, arith = int(meta[0]), int(meta[1]), int(meta[2]), float(meta[3]) / 1e6, int(meta[4])
+        x, w, b, y = g["x_%d" % i], g["w_%d" % i], g["b_%d" % i], g["y_%d" % i]
+        if kind == 0:
+            extra = dict(pre_slope=slope) if slope != 1.0 else {}
+            got = oracle.conv1d(x, w, b, dilation=p1, arith=arith, **extra)
+            plain = oracle.conv1d(x, w, b, dilation=p1, arith=0, **extra)
+        else:
+            got = oracle.conv_transpose1d(x, w, b, p1, crop, pre_slope=slope, arith=arith)
+            plain = oracle.conv_transpose1d(x, w, b, p1, crop, pre_slope=slope, arith=0)
+        assert got.shape == y.shape, (i, got.shape, y.shape)
+        assert rel_err(got, y) < 2e-5, (i, meta.tolist(), rel_err(got, y))
+        assert rel_err(plain, y) > (2e-4 if arith == 2 else 1.5e-3), (i, "fp32 arithmetic is indistinguishable here", rel_err(plain, y))

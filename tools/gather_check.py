@@ -48,11 +48,11 @@ assert hip.hipDeviceSynchronize() == 0
 for forced in (False, True):
     if forced:
         os.environ["VITS_GATHER_FORCE_RCCL"] = "1"
-        uid = pkg.gather_unique_id()
-        assert len(uid) == 128 and any(uid)
-    else:
-        uid = None
+    uid = None
     for eb, src, dtype in ((4, pcm, np.float32), (2, pcm16, np.int16)):
+        if forced:
+            uid = pkg.gather_unique_id()  # (one id per communicator: RCCL's bootstrap serves an id once)
+            assert len(uid) == 128 and any(uid)
         with pkg.PcmGather(uid, 0, 1, 5, cap, eb) as g:
             for rep in range(2):  # the object is reusable
                 data, stride, all_len = g.gather(src, cap, lengths)

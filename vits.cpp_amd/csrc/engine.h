@@ -128,8 +128,11 @@ struct Knobs {
     bool prof_attach = true;     // VITS_PROF_ATTACH=0: per-kernel profiler with recorded events instead of dispatch-attached ones
     int front_prio = 1;          // VITS_FRONT_PRIO=0: the front-end stream of pipelined batches at normal instead of high priority
     bool keep_stage_sum32 = false;  // VITS_KEEP_STAGE_SUM32: 16-bit vocoder: also store the fp32 resblock sum of a stage's last resblock (nobody reads it)
-    int split_min_batch = 32;    // VITS_SPLIT_MIN_BATCH: vits_model_process_batch splits batches of at least this many utterances in two pipelined parts (0: never)
+    int split_min_batch = 128;   // VITS_SPLIT_MIN_BATCH: vits_model_process_batch splits batches of at least this many utterances in two pipelined parts (0: never).
+                                 // Measured (f16, 128 ids): B = 64 split 32 + 32 LOSES (14.98 vs 14.34 ms: two half-size vocoder passes cost more than the hidden stage one)
     int split_first_pct = 50;    // VITS_SPLIT_FIRST_PCT: share of the utterances in the first part (its stage one is the exposed one)
+    int flow_chains = 2;         // VITS_FLOW_CHAINS: 16-bit modes: the fused coupling layers of the flow as two independent chains of launches over halves of the batch (1: one chain)
+    int flow_chain_min_blocks = 256;  // VITS_FLOW_CHAIN_MIN_BLOCKS: ... when a layer has more blocks than this (one block per CU at a time: 256 = one full round)
     bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
     KernelKnobs kernel;          // the launch functions' own tuning knobs (kernels.h), installed per call by KernelKnobsScope
     void read();

@@ -161,13 +161,57 @@ int Engine::run_flow(Call& c) {
         c.sum_in = c.sum_out = sum_frames;
         return c;
     };
+    // 16-bit modes, fused coupling layers: a layer is ONE launch of sum_b ceil(frames_b / 48) blocks, one block per CU at a time (238 VGPRs x six
+    // waves) — 320 blocks at batch 64 x 225 frames = a full round on the 256 CUs and a second one on 64 of them, four times over. Utterances never
+    // interact, so the batch is dealt out over two independent chains of launches (main stream + a side stream): while one chain's layer drains its
+    // tail the other's blocks take the free CUs (4 x 320 blocks in ~5 rounds instead of 8). Same kernel, same operands per utterance: same bits.
+    int chains = 1, chain_b0[3] = {0, B, B};
+    bool all_fused = arith_now_ != VITS_ARITH_F32 && !knobs.no_flow_fuse;
+    for (int i = 0; i < hp.n_flows && all_fused; ++i)
+        all_fused = (int)flow_[i].in_layers.size() == hp.wn_layers && (int)flow_[i].res_skip.size() == hp.wn_layers &&
+                    flow_couple16_supported(H, F / 2, hp.wn_k, hp.wn_rate, hp.wn_layers, flow_[i].pre, flow_[i].in_layers.data(), flow_[i].res_skip.data(), flow_[i].post);
+    if (all_fused && !prof.on && side_[0] && B >= 2 && knobs.flow_chains > 1) {
+        int64_t blocks = 0;
+        for (int b = 0; b < B; ++b) blocks += (frames[b] + 47) / 48;
+        if (blocks > knobs.flow_chain_min_blocks && blocks > kernel_knobs().flow_narrow_max) {
+            // equal shares of the blocks (by utterance, in order)
+            int64_t run = 0;
+            int cut = 0;
+            while (cut < B - 1 && 2 * (run + (frames[cut] + 47) / 48) <= blocks) run += (frames[cut++] + 47) / 48;
+            if (cut >= 1) {
+                chains = 2;
+                chain_b0[1] = cut;
+            }
+        }
+    }
+    if (chains > 1) {
+        HIP_OK(hipEventRecord(ev_fork_, stream));
+        HIP_OK(hipStreamWaitEvent(side_[0], ev_fork_, 0));
+    }
     for (int i = hp.n_flows - 1; i > -1; --i) {
         const FlowLayerW& Lw = flow_[i];
         const bool flipped = ((hp.n_flows - i) % 2) == 1;
         TensorRef x0 = sub(zp, flipped ? F / 2 : 0), x1 = sub(zp, flipped ? 0 : F / 2);
         // 16-bit modes: the whole coupling layer as ONE kernel (flow_couple16_kernel, wavenet32.hip; bit-identical to the launches below)
-        if (arith_now_ != VITS_ARITH_F32 && !knobs.no_flow_fuse && (int)Lw.in_layers.size() == hp.wn_layers && (int)Lw.res_skip.size() == hp.wn_layers &&
-            flow_couple16_supported(H, F / 2, hp.wn_k, hp.wn_rate, hp.wn_layers, Lw.pre, Lw.in_layers.data(), Lw.res_skip.data(), Lw.post)) {
+        if (chains > 1) {
+            for (int ch = 0; ch < chains; ++ch) {
+                const int b0 = chain_b0[ch], nb = chain_b0[ch + 1] - b0;
+                FlowCouple16Call fc;
+                fc.x0 = x0;
+                fc.x0.p += (int64_t)b0 * x0.bs;
+                fc.x1 = x1;
+                fc.x1.p += (int64_t)b0 * x1.bs;
+                fc.lens = ll + b0;
+                fc.batch = nb;
+                fc.tmax = 0;
+                for (int b = b0; b < b0 + nb; ++b) fc.tmax = std::max(fc.tmax, frames[b]);
+                fc.hidden = H;
+                fc.half = F / 2;
+                HIP_OK(launch_flow_couple16(Lw.pre, Lw.in_layers.data(), Lw.res_skip.data(), Lw.post, fc, arith_now_, ch == 0 ? stream : side_[0]));
+            }
+            continue;
+        }
+        if (all_fused) {
             FlowCouple16Call fc;
             fc.x0 = x0;
             fc.x1 = x1;
@@ -253,6 +297,10 @@ int Engine::run_flow(Call& c) {
         ConvCall pc = mk2(sub(hout, H), x1);  // x1 <- x1 - (W out + b): weights negated at load (vits.cpp:506,513)
         pc.res = x1;
         HIP_OK(conv("flow_conv1x1", Lw.post, pc));
+    }
+    if (chains > 1) {
+        HIP_OK(hipEventRecord(ev_done_[0], side_[0]));
+        HIP_OK(hipStreamWaitEvent(stream, ev_done_[0], 0));
     }
     if (o.collect_taps) snapshot("z_flow", zp, F, Lmax, B, frames);
     (void)n_up;

@@ -41,6 +41,8 @@ void Knobs::read() {
     if (const char* e = std::getenv("VITS_PROF_ATTACH")) prof_attach = std::atoi(e) != 0;
     if (const char* e = std::getenv("VITS_FRONT_PRIO")) front_prio = std::atoi(e);
     no_pipeline = flag("VITS_NO_PIPELINE");
+    if (const char* e = std::getenv("VITS_FLOW_CHAINS")) flow_chains = std::atoi(e);
+    if (const char* e = std::getenv("VITS_FLOW_CHAIN_MIN_BLOCKS")) flow_chain_min_blocks = std::atoi(e);
     if (const char* e = std::getenv("VITS_SPLIT_MIN_BATCH")) split_min_batch = std::atoi(e);
     if (const char* e = std::getenv("VITS_SPLIT_FIRST_PCT")) split_first_pct = std::min(95, std::max(5, std::atoi(e)));
     keep_stage_sum32 = flag("VITS_KEEP_STAGE_SUM32");
