@@ -527,3 +527,57 @@ def test_kernel_tuning_knobs_belong_to_the_handle_that_read_them(pkg, full_bytes
     finally:
         a.close()
         b.close()
+
+
+def test_16bit_conv_kernels_reproduce_torch_with_rounded_operands(pkg):
+    """The HIP kernels of the 16-bit modes against a THIRD party (not the oracle): tests/golden/arith16_ops.npz = torch's Conv1d / ConvTranspose1d with both
+    operands rounded to fp16 / bf16 and fp32 accumulation (make_golden.py `arith16_op_fixtures`; Q7: custom-ops.h:684-690). One conv differs from another
+    correct implementation by fp32 summation order only — the fp32 bound of 2e-5 of RMS — and the fp32 kernels must miss the fixture by the rounding step."""
+    from conftest import golden
+    g = golden("arith16_ops.npz")
+    for i in range(int(g["n_cases"][0])):
+        meta = g["meta_%d" % i]
+        kind, p1, crop, slope, arith = int(meta[0]), int(meta[1]), int(meta[2]), float(meta[3]) / 1e6, int(meta[4])
+        x, w, b, y = g["x_%d" % i], g["w_%d" % i], g["b_%d" % i], g["y_%d" % i]
+        outs = {}
+        for a in (arith, pkg.ARITH_F32):
+            pkg.op_set_arith(a)
+            if kind == 0:
+                outs[a] = pkg.op_conv1d(x, w, b, dilation=p1, **(dict(pre_slope=slope) if slope != 1.0 else {}))
+            else:
+                outs[a] = pkg.op_conv_transpose1d(x, w, b, p1, crop, pre_slope=slope)
+        assert rel_err(outs[arith], y) < 2e-5, (i, meta.tolist())
+        assert rel_err(outs[pkg.ARITH_F32], y) > (2e-4 if arith == 2 else 1.5e-3), (i, meta.tolist())
+
+
+@pytest.mark.parametrize("arch", ["tiny", "full"])
+@pytest.mark.parametrize("name,arith,tol", ARITHS)
+def test_full_path_16bit_reproduces_the_torch_operand_rounding_fixtures(pkg, arch, name, arith, tol):
+    """Whole path in a 16-bit mode against transformers.VitsModel with torch hooks that round every conv operand of the flow and the vocoder
+    (tests/golden/*_arith_*_taps.npz; see tests/test_oracle.py for what these fixtures can and cannot discriminate): stage-one taps at the fp32 bound,
+    durations exact, downstream taps at the modes' rounding noise with the RMS deviation four times tighter; on the tiny architecture the flow
+    output agrees far below the distance of the fp32 path."""
+    from conftest import golden
+    g = golden("%s_synth_arith_%s_taps.npz" % (arch, name))
+    data = pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY if arch == "tiny" else pkg.SYNTH_FULL)
+    kw = dict(mode=pkg.MODE_REFERENCE, noise_kind=pkg.NOISE_EXPLICIT, noise_dur=g["noise_dur"], noise_prior=g["noise_prior"], collect_taps=True)
+
+    def dev(a, b):
+        a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+        rms = np.sqrt((b ** 2).mean())
+        return np.abs(a - b).max() / rms, np.sqrt(((a - b) ** 2).mean()) / rms
+
+    with pkg.Model(data) as m:
+        m.process_batch(g["ids"], **kw)
+        z32 = m.tap("z_flow")
+        m.set_arith(arith)
+        pcm, lengths, frames = m.process_batch(g["ids"], **kw)
+        np.testing.assert_array_equal(m.tap("durations"), g["durations"].ravel())
+        assert lengths[0] == g["waveform"].size
+        for tap in ("enc_out", "prior_mean", "log_duration", "z_p"):
+            assert rel_err(m.tap(tap), g[tap]) < 1e-4, tap
+        for tap in ("z_flow", "pre_tanh", "waveform"):
+            mx, rms = dev(m.tap(tap), g[tap])
+            assert mx < tol and rms < tol / 4, (tap, mx, rms)
+        if arch == "tiny":
+            assert dev(m.tap("z_flow"), g["z_flow"])[1] * 3 < dev(z32, g["z_flow"])[1]
