@@ -492,8 +492,10 @@ def compact_line(res, detail_path=None):
     Everything the run measured beyond that (top_kernels, roofline_default_schedule, notes, serving_two_engines, duration_boundary_margin)
     is in bench_detail.json. Pure function of the full result dict (tests/test_bench_host.py builds a worst case and checks the size)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "ranks_seen", "rtf", "algorithmic_tflops", "speedup_vs_cpu_baseline", "value_without_kernel_events", "ms_per_step_without_kernel_events")
+            "ranks_seen", "rccl_world_size", "devices_seen", "rtf", "algorithmic_tflops", "speedup_vs_cpu_baseline", "value_without_kernel_events", "ms_per_step_without_kernel_events")
     out = {k: _sig(res[k]) for k in keep if k in res}
+    if isinstance(out.get("devices_seen"), list):
+        out["devices_seen"] = out["devices_seen"][:16]
     out["metric"] = str(out.get("metric", ""))[:120]
     cfg = res.get("config", {})
     out["config"] = {k: (_sig(cfg[k]) if not isinstance(cfg[k], str) else cfg[k][:200]) for k in

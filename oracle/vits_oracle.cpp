@@ -9,6 +9,7 @@
  * ne order [time, channels, 1]. Arithmetic is straight fp32 loops (the compiler may contract a*b+c to fma).
  */
 #include "vits_oracle.h"
+#include "vits_oracle_exact.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1171,6 +1172,28 @@ VO_API int64_t vo_config(const vo_model* m, const char* key, char* dst, size_t c
     return (int64_t)it->second.size();
 }
 
+// ggml_tables == 1: stage one in the exact order of include/vits_exact_math.h (vits_oracle_exact.cpp), shared with the product's device code so that
+// the durations of that mode are bit-identical on both sides; == 2: the loops of THIS file with the table lookups (the independent restatement the
+// exact one is compared against at tolerance). Requires fp32 stage-one arithmetic (default scope).
+static bool exact_stage_one_wanted(const vo_opts* opts) { return opts && opts->ggml_tables == 1; }
+static void run_exact_stage_one(const vo_model& m, const vo_opts* opts, const int32_t* ids, int T, const float* noise, int threads, vo_exact::StageOne& out) {
+    if (g_arith) throw std::runtime_error("ggml_tables = 1 (exact order) needs fp32 stage-one arithmetic: use VO_SCOPE_FLOW_VOCODER");
+    vo_exact::ModelView v;
+    v.T = [&m](const std::string& name) {
+        const Tensor& t = m.T(name);
+        vo_exact::TensorRef r;
+        r.d = t.d.data();
+        r.rank = t.rank;
+        for (int i = 0; i < 4; ++i) r.ne[i] = t.ne[i];
+        return r;
+    };
+    v.hidden = m.hidden, v.layers = m.layers, v.heads = m.heads, v.window = m.window, v.ffn_k = m.ffn_k, v.flow_size = m.flow_size;
+    v.dp_k = m.dp_k, v.dds_layers = m.dds_layers, v.dp_bins = m.dp_bins, v.dp_flows = m.dp_flows;
+    v.ln_eps = m.ln_eps, v.dp_tail = m.dp_tail, v.noise_scale_dur = m.noise_scale_dur, v.speaking_rate = m.speaking_rate;
+    vo_exact::stage_one(v, (opts ? opts->mode : VO_MODE_REFERENCE) == VO_MODE_REFERENCE, ids, T, noise, threads, out);
+    g_outside_latents = out.outside_latents;
+}
+
 VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const vo_opts* opts) {
     try {
         const vo_model& m = *mp;
@@ -1185,7 +1208,8 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         auto run = std::make_unique<vo_run>();
         Act enc, m_p, logs_p;
-        {
+        const bool exact = exact_stage_one_wanted(opts);
+        if (!exact) {
             StageTimer t("text_encoder");
             text_encoder(c, ids, T, enc, m_p, logs_p);
         }
@@ -1198,7 +1222,17 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
         else
             ref_noise_fill(nd.d.data(), (size_t)2 * T);
         Act logw;
-        {
+        vo_exact::StageOne ex;
+        if (exact) {
+            StageTimer t("stage_one_exact");
+            run_exact_stage_one(m, opts, ids, T, nd.d.data(), c.threads, ex);
+            const int F = m.flow_size;
+            enc = Act(m.hidden, T), m_p = Act(F, T), logs_p = Act(F, T), logw = Act(1, T);
+            enc.d = ex.enc;
+            std::memcpy(m_p.d.data(), ex.stats.data(), sizeof(float) * (size_t)F * T);
+            std::memcpy(logs_p.d.data(), ex.stats.data() + (size_t)F * T, sizeof(float) * (size_t)F * T);
+            logw.d = ex.logw;
+        } else {
             StageTimer t("duration_predictor");
             logw = duration_predictor(c, enc, nd.d.data());
         }
@@ -1207,7 +1241,7 @@ VO_API vo_run* vo_process_ids(vo_model* mp, const int32_t* ids, int32_t T, const
         const float length_scale = (float)(1.0 / m.speaking_rate);
         double total = 0;
         for (int t = 0; t < T; ++t) {
-            float d = std::ceil(std::exp(logw.d[t]) * length_scale);
+            float d = exact ? ex.dur[t] : std::ceil(std::exp(logw.d[t]) * length_scale);
             if (opts && opts->fixed_duration > 0) d = (float)opts->fixed_duration;
             dur.d[t] = d;
             total += d;
@@ -1286,7 +1320,8 @@ VO_API int vo_log_durations(vo_model* mp, const int32_t* ids, int32_t T, const v
         } arith_reset;
         Ctx c{m, opts ? opts->mode : VO_MODE_REFERENCE, (opts && opts->threads > 0) ? opts->threads : default_threads(), ""};
         Act enc, m_p, logs_p;
-        text_encoder(c, ids, T, enc, m_p, logs_p);
+        const bool exact = exact_stage_one_wanted(opts);
+        if (!exact) text_encoder(c, ids, T, enc, m_p, logs_p);
         Act nd(2, T);
         const int nk = opts ? opts->noise_kind : VO_NOISE_REFERENCE;
         if (nk == VO_NOISE_EXPLICIT) std::memcpy(nd.d.data(), opts->noise_dur, sizeof(float) * 2 * T);
@@ -1294,6 +1329,15 @@ VO_API int vo_log_durations(vo_model* mp, const int32_t* ids, int32_t T, const v
             for (int i = 0; i < 2 * T; ++i) nd.d[i] = vits_counter_normal(opts->noise_seed, VITS_STREAM_NOISE_DUR, (uint64_t)i);
         else
             ref_noise_fill(nd.d.data(), (size_t)2 * T);
+        if (exact) {
+            vo_exact::StageOne ex;
+            run_exact_stage_one(m, opts, ids, T, nd.d.data(), c.threads, ex);
+            for (int t = 0; t < T; ++t) {
+                if (logw_out) logw_out[t] = ex.logw[t];
+                if (dur_out) dur_out[t] = ex.dur[t];
+            }
+            return 0;
+        }
         Act logw = duration_predictor(c, enc, nd.d.data());
         const float length_scale = (float)(1.0 / m.speaking_rate);
         for (int t = 0; t < T; ++t) {

@@ -345,6 +345,11 @@ class Model:
         return bool(lib().vits_model_get_ggml_tables(self._h))
 
     @property
+    def ggml_tables_mode(self):
+        """0 off, 1 tables + stage one in the exact order shared with the oracle, 2 tables inside the throughput kernels"""
+        return int(lib().vits_model_get_ggml_tables(self._h))
+
+    @property
     def arith_scope(self):
         return lib().vits_model_get_arith_scope(self._h)
 

@@ -205,14 +205,14 @@ VITS_API int vits_model_set_ggml_tables(vits_model* model, int on) {
         return -1;
     }
     std::string err;
-    if (model->eng.set_ggml_tables(on != 0, err) != 0) {
+    if (model->eng.set_ggml_tables(on, err) != 0) {
         set_err(err);
         return -1;
     }
     return 0;
     VITS_CATCH(-1)
 }
-VITS_API int vits_model_get_ggml_tables(const vits_model* model) { return model ? (model->eng.ggml_tables ? 1 : 0) : -1; }
+VITS_API int vits_model_get_ggml_tables(const vits_model* model) { return model ? model->eng.ggml_tables : -1; }
 
 VITS_API int vits_model_process_batch(vits_model* model, const int32_t* ids, const int32_t* id_lengths, int32_t batch, int32_t id_stride,
                                       const vits_process_opts* opts, vits_batch_result* out) {

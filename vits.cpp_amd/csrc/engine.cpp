@@ -307,8 +307,13 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         HIP_OK(hipStreamWaitEvent(front_, ev_async_, 0));
     }
     if (layout_stage_one(c)) return -1;
-    if (run_text_encoder(c)) return -1;
-    if (run_duration_predictor(c)) return -1;
+    if (ggml_tables == 1) {
+        // emulated-ggml mode: stage one in the exact order shared with the oracle (engine_stage1_exact.cpp)
+        if (run_stage_one_exact(c)) return -1;
+    } else {
+        if (run_text_encoder(c)) return -1;
+        if (run_duration_predictor(c)) return -1;
+    }
     arith_now_ = arith;
 
     // ---- the one data-dependent shape (vits.cpp:1133): frames per utterance ---------------------------------

@@ -160,8 +160,10 @@ class Engine {
     int set_arith(int arith, std::string& err);  // VITS_ARITH_*: packs the 16-bit weight fragments on first use
     // EMULATED ggml fp16 lookup tables for ggml_gelu / ggml_soft_max (Q8; inferred from upstream ggml, the fork is absent): builds the two
     // tables on the host as ggml_init does and uploads them on first use
-    int set_ggml_tables(bool on, std::string& err);
-    bool ggml_tables = false;
+    // mode 1: stage one additionally runs in the exact order of include/vits_exact_math.h (exact_stage1.hip), shared with the oracle: durations are
+    // bit-identical to the oracle's. mode 2: the tables inside the throughput kernels (their own summation order: statistical agreement only).
+    int set_ggml_tables(int mode, std::string& err);
+    int ggml_tables = 0;
     int arith = VITS_ARITH_F32;
     // which convolutions a 16-bit arithmetic mode applies to (include/vits.h VITS_ARITH_SCOPE_*)
     int arith_scope = VITS_ARITH_SCOPE_FLOW_VOCODER;
@@ -248,6 +250,15 @@ class Engine {
     // arithmetic of the convolutions being queued right now: `arith`, or fp32 while stage one runs under
     // VITS_ARITH_SCOPE_FLOW_VOCODER (every conv wrapper and fused kernel reads this one, never `arith` itself)
     int arith_now_ = VITS_ARITH_F32;
+    // emulated-ggml mode 1: the stage-one tensors as the file holds them (host, storage type) and their fp32 device copies (first use)
+    std::vector<TensorEntry> exact_src_;
+    struct ExactTensor {
+        const float* d = nullptr;
+        int rank = 0;
+        int64_t ne[4] = {1, 1, 1, 1};
+    };
+    std::map<std::string, ExactTensor> exact_w_;
+    int run_stage_one_exact(Call& c);
     GgmlTables ggml_tabs_;              // what the stage-one kernels receive: null pointers unless ggml_tables
     uint16_t* ggml_tab_dev_ = nullptr;  // [2][65536]: gelu, exp
     struct HStage {  // pinned staging of the per-call host header (ids, lengths, stage tables)

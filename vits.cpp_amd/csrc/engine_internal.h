@@ -102,6 +102,7 @@ struct Call {
     struct S1 {
         int *ids, *lens, *cum, *frames, *stage_lens, *stage_mul, *stage_add, *seed_off;
         float *x, *qkv, *att, *tmp, *ffn, *stats, *dpx, *dpy, *dpp, *cond, *z, *u, *dur;
+        float *ex_scores, *ex_tok;  // emulated-ggml mode 1 only
         uint16_t* x16;
     } s1{};
     std::vector<int> smul, sadd;  // vocoder stage lengths as affine functions of the frame count: len_i = L * smul[i] + sadd[i]

@@ -1,5 +1,6 @@
 // engine_load.cpp — weights: shape-checked upload, MFMA-fragment packing (fp32 at load, 16-bit on vits_model_set_arith), taps.
 #include "engine_internal.h"
+#include "../../include/vits_exact_math.h"
 
 namespace vits {
 
@@ -38,14 +39,15 @@ Engine::~Engine() {
 
 // ggml_init builds table_gelu_f16 / table_exp_f16 on the host by evaluating ggml_gelu_f32 / expf on every fp16 value (upstream ggml.c of the
 // reference's era; GGML_GELU_FP16 is on by default) — the same here, with this host's C library, then the 2 x 128 KB go to the device.
-int Engine::set_ggml_tables(bool on, std::string& err) {
-    if (on && !ggml_tab_dev_) {
+int Engine::set_ggml_tables(int mode, std::string& err) {
+    if (mode < 0 || mode > 2) {
+        err = "vits_model_set_ggml_tables: 0 (off), 1 (tables, stage one in the exact shared order) or 2 (tables inside the throughput kernels)";
+        return -1;
+    }
+    if (mode && !ggml_tab_dev_) {
+        // built on the HOST with the C library's tanhf / expf, as ggml_init does — by the function the oracle builds its copy with
         std::vector<uint16_t> tab(2 * 65536);
-        for (uint32_t i = 0; i < 65536; ++i) {
-            const float x = f16_to_f32((uint16_t)i);
-            tab[i] = f32_to_f16(0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x))));
-            tab[65536 + i] = f32_to_f16(expf(x));
-        }
+        vx_build_ggml_tables(tab.data(), tab.data() + 65536);
         uint16_t* d = nullptr;
         if (hipMalloc((void**)&d, tab.size() * sizeof(uint16_t)) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
             if (d) hipFree(d);
@@ -55,9 +57,28 @@ int Engine::set_ggml_tables(bool on, std::string& err) {
         ggml_tab_dev_ = d;
         owned_.push_back(d);
     }
-    ggml_tables = on;
+    if (mode == 1 && exact_w_.empty()) {
+        // the stage-one tensors in torch layout, fp32 on the device (uploaded once per handle)
+        for (const TensorEntry& t : exact_src_) {
+            float* d = upload(t.to_f32());
+            if (!d) {
+                err = "hipMalloc failed for the exact-order copy of " + t.name;
+                return -1;
+            }
+            ExactTensor e;
+            e.d = d;
+            e.rank = (int)t.rank;
+            for (int k = 0; k < 4; ++k) e.ne[k] = t.ne[k];
+            exact_w_[t.name] = e;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) {
+            err = "device error while uploading the exact-order weights";
+            return -1;
+        }
+    }
+    ggml_tables = mode;
     ggml_tabs_ = GgmlTables();
-    if (on) {
+    if (mode) {
         ggml_tabs_.gelu = ggml_tab_dev_;
         ggml_tabs_.exp = ggml_tab_dev_ + 65536;
     }
@@ -467,6 +488,16 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
     if (!dry_run_ && hipDeviceSynchronize() != hipSuccess) {
         err = "device error while uploading weights";
         return false;
+    }
+    if (!dry_run_) {
+        // The emulated-ggml mode (vits_model_set_ggml_tables(model, 1)) runs stage one in the exact order of include/vits_exact_math.h on the tensors AS
+        // THE FILE HOLDS THEM (torch layout, no packing, no folds): keep the text encoder's and the duration predictor's, in their storage type
+        // (~20 MB of host memory for the MMS-TTS architecture), and upload them when the mode is first switched on.
+        for (const TensorEntry& t : f.tensors) {
+            const bool s1 = t.name.rfind("text_encoder.", 0) == 0 || t.name.rfind("duration_predictor.", 0) == 0;
+            if (!s1 || t.name.find(".post_") != std::string::npos || t.name.rfind("duration_predictor.flows.1.", 0) == 0) continue;
+            exact_src_.push_back(t);
+        }
     }
     return true;
 }

@@ -77,6 +77,10 @@ int Engine::layout_stage_one(Call& c) {
         s1.cond = a.alloc<float>((size_t)B * H * ts);
         s1.z = a.alloc<float>((size_t)B * 2 * ts);
         s1.u = a.alloc<float>((size_t)B * 32 * ts);
+        if (ggml_tables == 1) {  // exact-order stage one: a score row per (utterance, head, query), three token rows per utterance for the spline step
+            s1.ex_scores = a.alloc<float>((size_t)B * hp.heads * c.Tmax * ts);
+            s1.ex_tok = a.alloc<float>((size_t)3 * B * ts);
+        }
         // 16-bit arithmetic modes: scratch for the rounded copy of a conv input (largest c_in of stage one)
         x16_elems1 = arith_now_ != VITS_ARITH_F32 ? (size_t)B * round_up(std::max({hp.ffn_dim, 2 * F, H}), 8) * round_up(ts, 8) : 0;
         s1.x16 = x16_elems1 ? a.alloc<uint16_t>(x16_elems1) : nullptr;

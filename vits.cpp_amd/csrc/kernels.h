@@ -372,9 +372,22 @@ hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int 
                          hipStream_t s, GgmlTables tabs = GgmlTables());
 hipError_t launch_affine(TensorRef z, int c_first, const float* translate, const float* log_scale, int sign, const int* lens, int batch, int tmax,
                          hipStream_t s);
+// ---- exact-order stage one of the emulated-ggml mode (exact_stage1.hip; element functions: include/vits_exact_math.h) -----------------------
+hipError_t launch_exact_conv(TensorRef x, const float* w, const float* bias, TensorRef y, TensorRef res, const int* lens, int batch, int cin, int cout, int K, int dil, int pad_l,
+                             int tmax, bool relu, const float* post_scale, hipStream_t s);
+hipError_t launch_exact_depthwise(TensorRef x, const float* w, const float* bias, TensorRef y, const int* lens, int batch, int channels, int K, int dil, int pad, int tmax,
+                                  hipStream_t s);
+hipError_t launch_exact_add(TensorRef x, TensorRef g, const int* lens, int batch, int channels, int tmax, hipStream_t s);
+hipError_t launch_exact_layer_norm(TensorRef x, const float* gamma, const float* beta, const int* lens, int batch, int channels, int tmax, float eps, const uint16_t* gelu_tab,
+                                   hipStream_t s);
+hipError_t launch_exact_attention(TensorRef q, TensorRef k, TensorRef v, const float* ek, const float* ev, TensorRef out, float* scratch, int srow, const int* lens, int batch,
+                                  int heads, int hd, int tmax, int window, const uint16_t* exp_tab, hipStream_t s);
+hipError_t launch_exact_affine(TensorRef z, int c_first, float t0, float t1, float e0, float e1, const int* lens, int batch, int tmax, hipStream_t s);
+hipError_t launch_exact_spline(TensorRef z, int row, TensorRef u, float* res, float* inside, float* tmp, int stride, const int* lens, int batch, int tmax, int nb, float B,
+                               float inv_sqrt, float constant, bool refmode, const uint16_t* exp_tab, hipStream_t s);
 hipError_t launch_noise_dur(TensorRef z, const int* lens, int batch, int tmax, uint64_t seed, const int* seed_off, float scale, hipStream_t s);
 hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
-                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s);
+                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s, bool exact = false);
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
                      uint64_t seed, const int* seed_off, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);

@@ -7,6 +7,7 @@
 
 #include "../../include/vits.h"
 #include "../../include/vits_synth_noise.h"
+#include "../../include/vits_exact_math.h"
 #include "kernels.h"
 
 namespace vits {
@@ -1466,7 +1467,7 @@ hipError_t launch_scale_rows(TensorRef x, int channels, float scale, int batch, 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64_t l_bs, int l_cs, int c, const int* lens, int tmax, float length_scale,
                                                         int fixed, float* dur, int* cum, int* frames, int* stage_lens, int n_stage, const int* stage_mul,
-                                                        const int* stage_add, int batch) {
+                                                        const int* stage_add, int batch, int exact) {
     __shared__ int part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = lens ? lens[b] : tmax;
@@ -1474,7 +1475,9 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64
     const int beg = tid * per, end = min(beg + per, len);
     int s = 0;
     for (int t = beg; t < end; ++t) {
-        float d = ceilf(expf(logw[(int64_t)b * l_bs + (int64_t)c * l_cs + t]) * length_scale);
+        const float lw = logw[(int64_t)b * l_bs + (int64_t)c * l_cs + t];
+        // exact: the emulated-ggml mode — exp as the fixed polynomial both sides share (include/vits_exact_math.h) instead of the device library's
+        float d = exact ? vx_duration(lw, length_scale) : ceilf(expf(lw) * length_scale);
         if (fixed > 0) d = (float)fixed;
         dur[(int64_t)b * tmax + t] = d;
         s += (int)d;
@@ -1505,9 +1508,9 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64
 }
 
 hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
-                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s) {
+                            int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s, bool exact) {
     VITS_KLAUNCH(durations_kernel, dim3(batch), dim3(256), 0, s, logw.p, logw.bs, logw.cs, c, lens, tmax, length_scale, fixed, dur, cum, frames, stage_lens,
-                       n_stage, stage_mul, stage_add, batch);
+                       n_stage, stage_mul, stage_add, batch, exact ? 1 : 0);
     return hipGetLastError();
 }
 
