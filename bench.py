@@ -123,9 +123,10 @@ def duration_boundary_margin(pkg, model, model_bytes, ids, noise_base, mode, mod
         misaligns (vits.cpp:832-849; reproduced literally in reference mode since round 4). 0 means Q6 plays no part in this batch;
       * Q8, MEASURED instead of bounded: the same stage one with EMULATED ggml lookup tables (tanh-GELU and the soft-max exponential
         through fp16 tables, double sum — inferred from upstream ggml, the reference's fork is absent): how many of the durations change
-        against the erf-GELU / fp32-soft-max reading, in the oracle and on the GPU (vits_model_set_ggml_tables), and how many the GPU
-        and the oracle disagree on in that arithmetic (a table input within ~1e-7 of an fp16 rounding boundary takes the neighbouring
-        entry on one side: the two are not bit-identical there, by construction)."""
+        against the erf-GELU / fp32-soft-max reading. In that mode both sides compute stage one in ONE shared order of operations
+        (include/vits_exact_math.h; vits_model_set_ggml_tables(model, 1) / vo_opts.ggml_tables = 1), so GPU and oracle must agree on EVERY
+        duration and every log-duration bit (`gpu_vs_oracle_durations_differ` = 0, `max_abs_log_duration_gpu_minus_oracle` = 0; round 4, with
+        the tables inside the throughput kernels: 5 of 8,192)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     om = O.Model(model_bytes)
@@ -161,8 +162,9 @@ def duration_boundary_margin(pkg, model, model_bytes, ids, noise_base, mode, mod
         tab["max_abs_log_duration_gpu_minus_oracle"] = max(tab["max_abs_log_duration_gpu_minus_oracle"], float(np.abs(gt_logw[u] - logw_t).max()))
     rel = np.concatenate(rel)
     tab["note"] = ("EMULATED ggml arithmetic, inferred from upstream ggerganov/ggml (ggml_vec_gelu_f32 with GGML_GELU_FP16, ggml_compute_forward_soft_max_f32 "
-                   "with table_exp_f16 and a double sum); the maxilevi/ggml fork the reference builds against is absent. Counts are ids of the benchmark batch "
-                   "whose duration differs between the two readings")
+                   "with table_exp_f16 and a double sum); the maxilevi/ggml fork the reference builds against is absent. Stage one of this mode runs in the exact "
+                   "order of include/vits_exact_math.h on both sides: gpu_vs_oracle_durations_differ must be 0. *_changed: ids of the benchmark batch whose "
+                   "duration differs from the table-free arithmetic")
     return {"ids": int(total), "within_1e-3_of_a_ceil_boundary": int((rel < 1e-3).sum()), "within_1e-2_of_a_ceil_boundary": int((rel < 1e-2).sum()),
             "within_1e-4_of_a_ceil_boundary": int((rel < 1e-4).sum()), "smallest_relative_margin": float(rel.min()),
             "gpu_durations_equal_to_oracle": int(equal), "max_abs_log_duration_gpu_minus_oracle": maxdev,

@@ -113,10 +113,18 @@ VITS_API int vits_model_get_arith_scope(const vits_model* model);
  * `ggml_soft_max` (vits.cpp:329,719,735) most probably compute there, not a pinned restatement:
  *   ggml_gelu:     y = fp16->fp32( table_gelu_f16[ fp32->fp16(x) ] ), the table holding fp16( 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2))) );
  *   ggml_soft_max: e_i = fp16->fp32( table_exp_f16[ fp32->fp16(x_i - max) ] ), the sum in double, p_i = e_i * (float)(1 / sum).
- * on = 1 routes the GELU of the duration predictor's DDS layers and the soft-max of the text encoder's attention and of the spline bins
- * through device copies of those tables (built on the host with the C library, as ggml_init does). Default 0: erf-GELU (what
- * transformers.VitsModel computes) and fp32 soft-max — the mode every parity fixture is in. Durations carry the tables' 5e-4 relative
- * rounding noise when on (bench.py reports how many of the benchmark batch's 8,192 durations move). Set between calls. */
+ * The GELU of the duration predictor's DDS layers and the soft-max of the text encoder's attention and of the spline bins go through those tables
+ * (built on the host with the C library, as ggml_init does). Default 0: erf-GELU (what transformers.VitsModel computes) and fp32 soft-max — the
+ * mode every parity fixture is in. Set between calls.
+ *   on = 1: a table turns a last-bit difference of its argument into a 5e-4 step of its value, so in this mode STAGE ONE (text encoder + duration
+ *           predictor, ~1 % of the work) runs in ONE fixed order of operations — include/vits_exact_math.h: one device thread per output element,
+ *           sequential sums, fp contraction off, polynomial exp / log instead of the device library's — which the oracle shares
+ *           (vo_opts.ggml_tables = 1): log-durations, durations, frame and sample counts are BIT-IDENTICAL to the oracle's (GPU test). A
+ *           measurement instrument (how far do ggml's tables move the durations: ~0.1 % of the ids), not a serving configuration: stage one takes
+ *           several times longer than the throughput kernels; everything behind the durations is the default path. Needs fp32 stage-one
+ *           arithmetic (VITS_ARITH_SCOPE_FLOW_VOCODER, the default).
+ *   on = 2: the same tables inside the THROUGHPUT kernels (MFMA summation order, the device library's exp / log): agrees with the oracle's loops
+ *           (vo_opts.ggml_tables = 2) statistically only — a few durations per ten thousand ids differ. Kept for that comparison. */
 VITS_API int vits_model_set_ggml_tables(vits_model* model, int on);
 VITS_API int vits_model_get_ggml_tables(const vits_model* model);
 

@@ -58,9 +58,13 @@ typedef struct vo_opts {
     int32_t threads;            /* <=0: max(hardware_concurrency, 6) like src/include/common.h:19-21 */
     int32_t arith;              /* VO_ARITH_*: operand rounding of every Conv1d / ConvTranspose1d (not of the Linear layers) */
     int32_t arith_scope;        /* VO_SCOPE_*: which convs `arith` applies to */
-    int32_t ggml_tables;        /* 1: EMULATE ggml's fp16 lookup tables (Q8; inferred from upstream ggerganov/ggml, the reference's fork is
-                                   absent): ggml_gelu = tanh-GELU through table_gelu_f16 (vits.cpp:673,687), ggml_soft_max = exp through
-                                   table_exp_f16, double sum, multiply by (float)(1/sum) (vits.cpp:329,719,735). 0 (default): erf-GELU, fp32 soft-max */
+    int32_t ggml_tables;        /* EMULATE ggml's fp16 lookup tables (Q8; inferred from upstream ggerganov/ggml, the reference's fork is absent):
+                                   ggml_gelu = tanh-GELU through table_gelu_f16 (vits.cpp:673,687), ggml_soft_max = exp through table_exp_f16, double
+                                   sum, multiply by (float)(1/sum) (vits.cpp:329,719,735). 0 (default): erf-GELU, fp32 soft-max.
+                                   1: stage one in the exact order of include/vits_exact_math.h (vits_oracle_exact.cpp), which the product's
+                                      vits_model_set_ggml_tables(model, 1) shares: bit-identical log-durations on both sides.
+                                   2: this file's own loops with the table lookups — the independent restatement mode 1 is compared with at
+                                      tolerance, and the counterpart of the product's mode 2. */
 } vo_opts;
 
 VO_API const char* vo_last_error(void);
