@@ -450,9 +450,24 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
                 if (frames[b] > wn.f0)  // owns frames here; the window holding the utterance's end also emits its tail (Q1)
                     row[(size_t)(n_up + 1) * B + b] = frames[b] <= wn.f1 ? (frames[b] - wn.lo) * M + sadd[n_up] : (wn.f1 - wn.lo) * M;
             }
-        HIP_OK(hipMemcpyAsync(c.s2.win_lens, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
-        prof.fence();
-        HIP_OK(hipStreamSynchronize(stream));  // wl goes out of scope
+        if (pend) {
+            // a pipelined batch: the table travels through pinned memory owned by the slot (it outlives this call), so that the submit does not
+            // drain the main stream — the previous batch's vocoder is running there (the synchronise below serialised windowed submits)
+            if (pend->win_cap < wl.size()) {
+                if (pend->win_pinned) hipHostFree(pend->win_pinned);
+                pend->win_pinned = nullptr;
+                pend->win_cap = 0;
+                HIP_OK(hipHostMalloc((void**)&pend->win_pinned, sizeof(int) * (wl.size() + wl.size() / 4 + 64), hipHostMallocDefault));
+                pend->win_cap = wl.size() + wl.size() / 4 + 64;
+            }
+            std::memcpy(pend->win_pinned, wl.data(), sizeof(int) * wl.size());
+            HIP_OK(hipMemcpyAsync(c.s2.win_lens, pend->win_pinned, sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
+            prof.fence();
+        } else {
+            HIP_OK(hipMemcpyAsync(c.s2.win_lens, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, stream));
+            prof.fence();
+            HIP_OK(hipStreamSynchronize(stream));  // wl goes out of scope
+        }
     }
     if (o.on_chunk) {
         const size_t need = (size_t)B * out_stride * sizeof(float);

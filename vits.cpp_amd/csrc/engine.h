@@ -231,6 +231,8 @@ class Engine {
         size_t host_cap = 0;  // bytes
         int* frames_pinned = nullptr;
         size_t frames_cap = 0;  // ints
+        int* win_pinned = nullptr;  // vocoder-window length table of a windowed batch (host side of its H2D copy)
+        size_t win_cap = 0;         // ints
         hipEvent_t s1_done = nullptr, done = nullptr;
     } pend_[2];
     std::atomic<uint64_t> submit_seq_{0}, wait_seq_{0};  // batch n lives in pend_[n & 1]; written under the busy flag, read by vits_model_pending

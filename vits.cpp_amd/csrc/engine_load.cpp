@@ -14,6 +14,7 @@ Engine::~Engine() {
     for (Pending& p : pend_) {
         if (p.host) hipHostFree(p.host);
         if (p.frames_pinned) hipHostFree(p.frames_pinned);
+        if (p.win_pinned) hipHostFree(p.win_pinned);
         if (p.s1_done) hipEventDestroy(p.s1_done);
         if (p.done) hipEventDestroy(p.done);
     }
