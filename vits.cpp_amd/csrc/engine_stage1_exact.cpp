@@ -1,6 +1,6 @@
 // engine_stage1_exact.cpp — stage one of a call in the emulated-ggml mode (vits_model_set_ggml_tables(model, 1)): the text encoder
 // (/root/reference/src/vits.cpp:244-440) and the stochastic duration predictor, reverse (:927-972), launched element kernel by element kernel
-// (exact_stage1.hip) in the sequence of oracle/vits_oracle_exact.cpp — same element functions (include/vits_exact_math.h), same operands, same
+// (exact_stage1.hip) in the sequence of the test oracle's exact-order translation unit (oracle/, never linked here) — same element functions (include/vits_exact_math.h), same operands, same
 // order, fp contraction off on both sides: the log-durations, and so the durations (vits.cpp:996-1001), are bit-identical to the oracle's.
 // Works on the tensors as the file holds them (torch layout; uploaded by Engine::set_ggml_tables), fills the same stage-one buffers as the
 // throughput path (x = encoder output, stats, z, dur / cum / frames / stage_lens), so everything behind the frame-count read is unchanged.

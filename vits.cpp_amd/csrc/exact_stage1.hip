@@ -1,6 +1,6 @@
 // exact_stage1.hip — device side of the emulated-ggml mode's stage one (vits_model_set_ggml_tables(model, 1)): every kernel below is "one thread
 // per output element, call the element function of include/vits_exact_math.h" — the same functions, operands and order of operations as the
-// oracle's oracle/vits_oracle_exact.cpp, compiled with floating-point contraction off (Makefile: -ffp-contract=off), so that the log-durations —
+// test oracle's exact-order translation unit (oracle/, never linked here), compiled with floating-point contraction off (Makefile: -ffp-contract=off), so that the log-durations —
 // and with them the path's integer output, the durations (vits.cpp:996-1001) — are bit-identical on both sides. NOT a throughput path: the default
 // mode's kernels (conv_mfma.hip, misc_kernels.hip) are what the benchmark runs. Layout as everywhere in stage one: [batch][channel][time], time fastest.
 #include <hip/hip_runtime.h>
