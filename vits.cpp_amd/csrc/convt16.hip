@@ -487,6 +487,10 @@ CtChoice ct_choice(const PackedConv& w) {
     if (w.rows / 32 <= 2) c.nr = 4, c.csplit = 2;
     else if (w.cin > 256) c.nr = 2, c.csplit = 1;
     else c.nr = 4, c.csplit = 1;
+    if (const int ov = kernel_knobs().convt16_r128; ov && w.rows == 128) {  // (developer override: same bits, another block shape)
+        c.nr = ov / 100, c.csplit = ov / 10 % 10, c.rs = (ov % 10) ? 16 : 8;
+        if (c.rs == 16 && w.cin % 128 != 0) c.rs = 8;
+    }
     return c;
 }
 }  // namespace

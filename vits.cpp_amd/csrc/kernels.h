@@ -44,6 +44,7 @@ struct KernelKnobs {
     bool fuse32_c128 = true;     // VITS_FUSE32_C128=0: fp32 k = 3 pairs at C = 128 as two launches
     int wn16_ncw = 1;            // VITS_WN16_NCW=2: 16-bit WaveNet layer with six waves, both column tiles each
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
+    int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
     int rb16_narrow_max = 64;    // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never)
     int flow_narrow_max = 96;    // VITS_FLOW_NARROW_MAX: 16-bit coupling-layer kernel on 16-frame blocks while the 48-frame tile would give at most this many blocks (0: never)
@@ -80,6 +81,7 @@ struct KernelKnobs {
         num("VITS_FLOW_NARROW_MAX", k.flow_narrow_max);
         num("VITS_RB16_NARROW_MAX", k.rb16_narrow_max);
         num("VITS_CONVT16_SPLIT_MAX", k.convt16_split_max);
+        num("VITS_CONVT16_R128", k.convt16_r128);
         flag("VITS_NO_LAT16", k.no_lat16);
         num("VITS_LAT16_MAX_WAVES", k.lat16_max_waves);
         return k;

@@ -1394,11 +1394,29 @@ __global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs
         for (int t = threadIdx.x; t < len; t += blockDim.x) zrow[t] = s_res[t];
         return;
     }
-    // Q6: the j-th outside token takes element j of the masked input (:832), the k-th inside token the result of token k (:849)
-    for (int t = threadIdx.x; t < len; t += blockDim.x) {
-        int nout = 0;
-        for (int j = 0; j < t; ++j) nout += 1 - s_in[j];
+    // Q6: the j-th outside token takes element j of the masked input (:832), the k-th inside token the result of token k (:849).
+    // nout(t) = outside tokens before t: every thread counts a contiguous chunk, one thread scans the per-thread counts (the
+    // first version let every thread count from token 0: O(T^2) LDS reads per utterance)
+    __shared__ int s_part[NT];
+    const int nthr = (int)blockDim.x, per = (len + nthr - 1) / nthr;
+    const int beg = min((int)threadIdx.x * per, len), end = min(beg + per, len);
+    int cnt = 0;
+    for (int t = beg; t < end; ++t) cnt += 1 - s_in[t];
+    s_part[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < nthr; ++i) {
+            const int v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int nout = s_part[threadIdx.x];
+    for (int t = beg; t < end; ++t) {
         zrow[t] = s_in[t] ? s_res[t - nout] : s_val[nout];
+        nout += 1 - s_in[t];
     }
 }
 
