@@ -330,35 +330,38 @@ def arith16_taps_for(parsed, T, seed, dtype, refmode=True):
 def arith16_op_fixtures():
     """Operator-level pins of the 16-bit-operand arithmetic, by torch: Conv1d / ConvTranspose1d with BOTH operands rounded to fp16 / bf16 and fp32
     accumulation (Q7: the im2col of custom-ops.h:684-690 is fp16, the exported weights are fp16, ggml accumulates in fp32), input LeakyReLU before
-    the rounding where the path fuses it (vits.cpp:554,613). Small shapes: the whole file is a few hundred KB."""
+    the rounding where the path fuses it (vits.cpp:554,613). One set of inputs per shape, one output per arithmetic (y_f16_i, y_bf16_i)."""
     rng = np.random.default_rng(2024)
     out, n = {}, 0
     F = torch.nn.functional
+    rd = lambda t, dtype: t.to(dtype).to(torch.float32)
+    types = (("f16", torch.float16), ("bf16", torch.bfloat16))
     conv_cases = [(24, 40, 1, 1, 40, 1.0), (32, 32, 3, 1, 48, 0.1), (32, 32, 3, 5, 48, 0.1), (16, 24, 5, 1, 40, 1.0), (32, 32, 7, 3, 64, 0.1), (32, 32, 11, 5, 96, 0.1),
                   (192, 29, 1, 1, 17, 1.0)]
-    for dt_name, dtype, arith in (("f16", torch.float16, 2), ("bf16", torch.bfloat16, 1)):
-        rd = lambda t: t.to(dtype).to(torch.float32)
-        for cin, cout, k, dil, T, slope in conv_cases:
+    for cin, cout, k, dil, T, slope in conv_cases:
+        x = rng.standard_normal((1, cin, T)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        xt = torch.from_numpy(x)
+        if slope != 1.0:
+            xt = F.leaky_relu(xt, slope)
+        out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "meta_%d" % n: np.array([0, dil, 0, round(slope * 1e6)], np.int64)})
+        for name, dtype in types:
+            out["y_%s_%d" % (name, n)] = F.conv1d(rd(xt, dtype), rd(torch.from_numpy(w), dtype), torch.from_numpy(b), dilation=dil, padding=(k - 1) * dil // 2).numpy()
+        n += 1
+    for cin, cout, k, s, T in ((32, 16, 16, 8, 12), (32, 16, 4, 2, 40)):
+        for crop in (0, (k - s) // 2):
             x = rng.standard_normal((1, cin, T)).astype(np.float32)
-            w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+            w = (rng.standard_normal((cin, cout, k)) / np.sqrt(cin * 2)).astype(np.float32)
             b = rng.standard_normal(cout).astype(np.float32)
-            xt = torch.from_numpy(x)
-            if slope != 1.0:
-                xt = F.leaky_relu(xt, slope)
-            y = F.conv1d(rd(xt), rd(torch.from_numpy(w)), torch.from_numpy(b), dilation=dil, padding=(k - 1) * dil // 2)
-            out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "y_%d" % n: y.numpy(), "meta_%d" % n: np.array([0, dil, 0, round(slope * 1e6), arith], np.int64)})
+            out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "meta_%d" % n: np.array([1, s, crop, 100000], np.int64)})
+            for name, dtype in types:
+                out["y_%s_%d" % (name, n)] = F.conv_transpose1d(rd(F.leaky_relu(torch.from_numpy(x), 0.1), dtype), rd(torch.from_numpy(w), dtype), torch.from_numpy(b), stride=s,
+                                                                 padding=crop).numpy()
             n += 1
-        for cin, cout, k, s, T in ((32, 16, 16, 8, 12), (32, 16, 4, 2, 40)):
-            for crop in (0, (k - s) // 2):
-                x = rng.standard_normal((1, cin, T)).astype(np.float32)
-                w = (rng.standard_normal((cin, cout, k)) / np.sqrt(cin * 2)).astype(np.float32)
-                b = rng.standard_normal(cout).astype(np.float32)
-                y = F.conv_transpose1d(rd(F.leaky_relu(torch.from_numpy(x), 0.1)), rd(torch.from_numpy(w)), torch.from_numpy(b), stride=s, padding=crop)
-                out.update({"x_%d" % n: x, "w_%d" % n: w, "b_%d" % n: b, "y_%d" % n: y.numpy(), "meta_%d" % n: np.array([1, s, crop, 100000, arith], np.int64)})
-                n += 1
     out["n_cases"] = np.array([n], np.int64)
     np.savez_compressed(os.path.join(HERE, "arith16_ops.npz"), **out)
-    print("arith16_ops.npz:", n, "cases,", os.path.getsize(os.path.join(HERE, "arith16_ops.npz")), "bytes")
+    print("arith16_ops.npz:", n, "cases x 2 arithmetics,", os.path.getsize(os.path.join(HERE, "arith16_ops.npz")), "bytes")
 
 
 def make_ids(T, vocab, seed):

@@ -537,17 +537,19 @@ def test_16bit_conv_kernels_reproduce_torch_with_rounded_operands(pkg):
     g = golden("arith16_ops.npz")
     for i in range(int(g["n_cases"][0])):
         meta = g["meta_%d" % i]
-        kind, p1, crop, slope, arith = int(meta[0]), int(meta[1]), int(meta[2]), float(meta[3]) / 1e6, int(meta[4])
-        x, w, b, y = g["x_%d" % i], g["w_%d" % i], g["b_%d" % i], g["y_%d" % i]
+        kind, p1, crop, slope = int(meta[0]), int(meta[1]), int(meta[2]), float(meta[3]) / 1e6
+        x, w, b = g["x_%d" % i], g["w_%d" % i], g["b_%d" % i]
         outs = {}
-        for a in (arith, pkg.ARITH_F32):
+        for a in (pkg.ARITH_F16, pkg.ARITH_BF16, pkg.ARITH_F32):
             pkg.op_set_arith(a)
             if kind == 0:
                 outs[a] = pkg.op_conv1d(x, w, b, dilation=p1, **(dict(pre_slope=slope) if slope != 1.0 else {}))
             else:
                 outs[a] = pkg.op_conv_transpose1d(x, w, b, p1, crop, pre_slope=slope)
-        assert rel_err(outs[arith], y) < 2e-5, (i, meta.tolist())
-        assert rel_err(outs[pkg.ARITH_F32], y) > (2e-4 if arith == 2 else 1.5e-3), (i, meta.tolist())
+        for name, a in (("f16", pkg.ARITH_F16), ("bf16", pkg.ARITH_BF16)):
+            y = g["y_%s_%d" % (name, i)]
+            assert rel_err(outs[a], y) < 2e-5, (i, name, meta.tolist())
+            assert rel_err(outs[pkg.ARITH_F32], y) > (2e-4 if name == "f16" else 1.5e-3), (i, name, meta.tolist())
 
 
 @pytest.mark.parametrize("arch", ["tiny", "full"])
