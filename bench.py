@@ -297,6 +297,18 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
     out["c2_f32"] = entry(e, s_, fr, n, 128, "f32", 1)
     out["c2_f32"]["ms_per_utterance"] = 1000.0 * e / n
     out["c2_f32"]["schedule"] = "serial calls (latency figure: one utterance in, its PCM out)"
+
+    def reference_api_ms(reps):
+        """the reference's OWN entry point (vits_model_process_ids == vits_model_process behind the tokenizer: libstdc++ noise stream drawn on the host, fp32 PCM
+        returned in host memory, /root/reference/src/vits.cpp:1225-1232), ms per utterance"""
+        for _ in range(3):
+            base_model.process_ids(ids1[0])
+        t = time.perf_counter()
+        for _ in range(reps):
+            base_model.process_ids(ids1[0])
+        return 1000.0 * (time.perf_counter() - t) / reps
+
+    out["c2_f32"]["reference_api_ms"] = reference_api_ms(n)
     b2, _ = buf_for(1, 128, 2)
     e, s_, fr = run([(base_model, ids1, noise_base, b2, cap)], n, warmup=1, pipelined=True)
     out["c2_f32"]["pipelined_throughput"] = {"value": s_ / e, "ms_per_utterance": 1000.0 * e / n,
@@ -308,6 +320,7 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
         out["c2_f16"] = entry(e, s_, fr, n, 128, "f16", 1, tag="c2|b1|f16")
         out["c2_f16"]["ms_per_utterance"] = 1000.0 * e / n
         out["c2_f16"]["schedule"] = "serial calls (latency figure: one utterance in, its PCM out)"
+        out["c2_f16"]["reference_api_ms"] = reference_api_ms(n)
     finally:
         base_model.set_arith(pkg.ARITH_F32)
     # c3 in fp32 (pipelined beside the headline's serial figure) and in the 16-bit arithmetic modes (default scope: stage one exact,
@@ -536,6 +549,8 @@ def compact_line(res, detail_path=None):
                 e["frac_mfma16"] = _sig(d["frac_mfma16"])
             if "serial_calls" in d:
                 e["serial_ms_per_step"] = _sig(d["serial_calls"].get("ms_per_step"))
+            if "reference_api_ms" in d:
+                e["reference_api_ms"] = _sig(d["reference_api_ms"])
             m[name] = e
         out["sub_results"] = m
     dm = res.get("duration_boundary_margin")

@@ -261,6 +261,12 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         return -1;
     }
     Call c(o, err, ids, B, id_stride);
+    struct AheadGuard {  // an error path between the speculative draw and its commit must not leave the reference stream locked
+        RefNoiseAhead& a;
+        ~AheadGuard() {
+            if (a.active()) a.finish(a.drawn());
+        }
+    } ahead_guard{ref_ahead_};
     c.md = o.mode == VITS_MODE_DEFAULT ? mode : o.mode;
     c.refmode = c.md == VITS_MODE_REFERENCE;
     c.tlen.resize(B);
@@ -305,6 +311,21 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         if (!ev_async_) HIP_OK(hipEventCreateWithFlags(&ev_async_, hipEventDisableTiming));
         HIP_OK(hipEventRecord(ev_async_, main_stream));
         HIP_OK(hipStreamWaitEvent(front_, ev_async_, 0));
+    }
+    if (B == 1 && o.noise_kind == VITS_NOISE_REFERENCE && !o.frames_only && knobs.ref_ahead_frames_per_id > 0) {
+        // The reference's own call (vits_model_process: one utterance, libstdc++ noise). Its two noise tensors are drawn on the host: [T, 2] at
+        // vits.cpp:948 and [L, 192] at :1059 — ~1.25 ms for 128 ids, and L is known only behind stage one. A helper thread draws the stream from NOW on,
+        // while this thread queues stage one and the device runs it (RefNoiseAhead, engine_support.cpp); run_prior_sampling names the size.
+        const size_t want = (size_t)hp.flow_size * ((size_t)knobs.ref_ahead_frames_per_id * c.Tmax + 64);
+        if (ref_noise_cap_ < want) {
+            if (ref_noise_pinned_) hipHostFree(ref_noise_pinned_);
+            ref_noise_pinned_ = nullptr;
+            ref_noise_cap_ = 0;
+            HIP_OK(hipHostMalloc((void**)&ref_noise_pinned_, want * sizeof(float), hipHostMallocDefault));
+            ref_noise_cap_ = want;
+        }
+        ref_ahead_.start((size_t)2 * c.tlen[0], ref_noise_pinned_, ref_noise_cap_);
+        c.ref_ahead = &ref_ahead_;
     }
     if (layout_stage_one(c)) return -1;
     if (ggml_tables == 1) {

@@ -133,9 +133,32 @@ struct Knobs {
     int split_first_pct = 50;    // VITS_SPLIT_FIRST_PCT: share of the utterances in the first part (its stage one is the exposed one)
     int flow_chains = 2;         // VITS_FLOW_CHAINS: 16-bit modes: the fused coupling layers of the flow as two independent chains of launches over halves of the batch (1: one chain)
     int flow_chain_min_blocks = 256;  // VITS_FLOW_CHAIN_MIN_BLOCKS: ... when a layer has more blocks than this (one block per CU at a time: 256 = one full round)
+    int ref_ahead_frames_per_id = 6;  // VITS_REF_AHEAD_FRAMES_PER_ID: batch-1 calls with the reference noise stream draw the prior noise ahead, into a block sized for this many frames per id
+                                      // (it grows if the utterance turns out longer; 0 = draw behind stage one as the reference does)
     bool no_pipeline = false;    // VITS_NO_PIPELINE: vits_model_submit_batch queues both stages on the main stream (no overlap)
     KernelKnobs kernel;          // the launch functions' own tuning knobs (kernels.h), installed per call by KernelKnobsScope
     void read();
+};
+
+// the reference stream of one batch-1 call drawn on a helper thread (engine_support.cpp): start, duration_noise, finish(n)
+class RefNoiseAhead {
+  public:
+    RefNoiseAhead();
+    ~RefNoiseAhead();
+    RefNoiseAhead(const RefNoiseAhead&) = delete;
+    RefNoiseAhead& operator=(const RefNoiseAhead&) = delete;
+    void start(size_t n_dur, float* prior, size_t cap);  // draws n_dur values (the [T, 2] tensor), then the prior stream into `prior` (up to cap values)
+    const float* duration_noise();                       // waits for the first tensor
+    void rebase(float* prior, size_t cap);               // a larger prior buffer (values [0, drawn) copied by the caller), only when drawn() == capacity()
+    void finish(size_t n);   // the prior tensor has n values: the global engine ends where exactly n draws leave it; joins the thread
+    bool active() const { return active_; }
+    size_t drawn() const;
+    size_t capacity() const;
+
+  private:
+    struct Impl;
+    Impl* impl_;
+    bool active_ = false;
 };
 
 struct Call;    // engine_internal.h: the state of one process_batch call
@@ -237,6 +260,13 @@ class Engine {
     } pend_[2];
     std::atomic<uint64_t> submit_seq_{0}, wait_seq_{0};  // batch n lives in pend_[n & 1]; written under the busy flag, read by vits_model_pending
     hipStream_t front_ = nullptr;             // stage one of pipelined batches (created on first use)
+    // batch-1 calls with the reference noise stream: the prior noise is drawn into pinned memory while stage one runs (engine.cpp)
+    float* ref_noise_pinned_ = nullptr;
+    size_t ref_noise_cap_ = 0;  // floats
+    RefNoiseAhead ref_ahead_;
+    float* dur_noise_pinned_ = nullptr;  // the [T, 2] duration noise of such a call
+    size_t dur_noise_cap_ = 0;
+    hipEvent_t dur_noise_ev_ = nullptr;
     bool async_tail_ = false;                 // the last process_batch returned with device work still queued (opts.async)
     hipEvent_t ev_async_ = nullptr;           // orders the front-end stream behind that tail
     int process_split(const int32_t* ids, const int32_t* id_lens, int batch, int id_stride, const vits_process_opts& o, vits_batch_result* out, std::string& err);

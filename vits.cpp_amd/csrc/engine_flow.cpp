@@ -1,6 +1,8 @@
 // engine_flow.cpp — stage two of a call up to the vocoder: arena layout (sized by B x L after the host read of the frame
 // counts), prior sampling through the alignment (vits.cpp:1028-1064) and the residual coupling flow, reverse
 // (vits.cpp:519-538,500-517,452-498).
+#include <thread>
+
 #include "engine_internal.h"
 
 namespace vits {
@@ -99,7 +101,31 @@ int Engine::run_prior_sampling(Call& c) {
     TensorRef stats = TR(s1.stats, 2 * F, c.ts);
     c.rx.phase("vits.prior_sampling");
     TensorRef zp = TR(s2.zp, F, ls), noise = TR(s2.noise, F, ls);
-    if (need_noise_buf) {
+    if (c.ref_ahead) {
+        // batch 1, reference noise: the tensor was (mostly) drawn while stage one ran (engine.cpp); it is one dense [F][L] block in pinned memory
+        const int L = frames[0];
+        const size_t n = (size_t)F * (size_t)L;
+        if (n > ref_noise_cap_) {  // (more frames per id than the block was sized for: a larger block once the helper rests at the old capacity; keep what was drawn)
+            while (c.ref_ahead->drawn() < c.ref_ahead->capacity()) std::this_thread::yield();
+            float* bigger = nullptr;
+            HIP_OK(hipHostMalloc((void**)&bigger, n * sizeof(float), hipHostMallocDefault));
+            std::memcpy(bigger, ref_noise_pinned_, sizeof(float) * c.ref_ahead->drawn());
+            float* old = ref_noise_pinned_;
+            ref_noise_pinned_ = bigger;
+            ref_noise_cap_ = n;
+            c.ref_ahead->rebase(ref_noise_pinned_, ref_noise_cap_);
+            c.ref_ahead->finish(n);
+            hipHostFree(old);
+        } else
+            c.ref_ahead->finish(n);
+        c.ref_ahead = nullptr;
+        noise.cs = L;
+        noise.bs = (int64_t)F * L;
+        HIP_OK(hipMemcpyAsync(s2.noise, ref_noise_pinned_, sizeof(float) * n, hipMemcpyHostToDevice, stream));
+        prof.fence();
+        if (o.async) HIP_OK(hipStreamSynchronize(stream));  // (the pinned block is reused by the next call)
+        if (o.collect_taps) snapshot("noise_prior", noise, F, Lmax, B, frames);
+    } else if (need_noise_buf) {
         std::vector<float> hn((size_t)B * F * ls, 0.f);
         for (int b = 0; b < B; ++b) {
             const int L = frames[b];

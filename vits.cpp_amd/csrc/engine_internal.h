@@ -107,6 +107,7 @@ struct Call {
     } s1{};
     std::vector<int> smul, sadd;  // vocoder stage lengths as affine functions of the frame count: len_i = L * smul[i] + sadd[i]
     int c_first = 0;              // physical row of z holding the log-durations after the duration predictor's flips
+    RefNoiseAhead* ref_ahead = nullptr;  // batch 1, reference noise: the prior noise drawn while stage one runs (engine.cpp)
 
     // the one data-dependent shape (vits.cpp:1133)
     std::vector<int> frames;

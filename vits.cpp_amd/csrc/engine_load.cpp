@@ -30,6 +30,9 @@ Engine::~Engine() {
         if (hs.ev) hipEventDestroy(hs.ev);
     }
     if (ev_async_) hipEventDestroy(ev_async_);
+    if (ref_noise_pinned_) hipHostFree(ref_noise_pinned_);
+    if (dur_noise_pinned_) hipHostFree(dur_noise_pinned_);
+    if (dur_noise_ev_) hipEventDestroy(dur_noise_ev_);
     if (ev_fork_) hipEventDestroy(ev_fork_);
     for (hipEvent_t e : ev_done_)
         if (e) hipEventDestroy(e);

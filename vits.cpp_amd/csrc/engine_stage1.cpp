@@ -253,6 +253,27 @@ int Engine::run_duration_predictor(Call& c) {
         prof.begin("noise_dur", 0, 0, stream);
         HIP_OK(launch_noise_dur(z, dl, B, Tmax, o.noise_seed, s1.seed_off, hp.noise_scale_dur, stream));
         prof.end(stream);
+    } else if (c.ref_ahead) {
+        // the reference's own call: the [T, 2] draws (vits.cpp:948) come from the helper thread (it holds the stream's lock: nobody else may draw now),
+        // through a small pinned block — a copy from pageable memory in the middle of stage one would make the host wait for the text encoder
+        const size_t n = (size_t)2 * ts;
+        if (dur_noise_cap_ < n) {
+            if (dur_noise_pinned_) hipHostFree(dur_noise_pinned_);
+            dur_noise_pinned_ = nullptr;
+            dur_noise_cap_ = 0;
+            HIP_OK(hipHostMalloc((void**)&dur_noise_pinned_, (n + 256) * sizeof(float), hipHostMallocDefault));
+            dur_noise_cap_ = n + 256;
+        }
+        if (dur_noise_ev_) HIP_OK(hipEventSynchronize(dur_noise_ev_));  // (the previous call's copy out of this block)
+        else HIP_OK(hipEventCreateWithFlags(&dur_noise_ev_, hipEventDisableTiming));
+        const float* tmpn = c.ref_ahead->duration_noise();  // memory order [2][T]
+        std::memset(dur_noise_pinned_, 0, sizeof(float) * n);
+        for (int ch = 0; ch < 2; ++ch) std::memcpy(dur_noise_pinned_ + (size_t)ch * ts, tmpn + (size_t)ch * tlen[0], sizeof(float) * tlen[0]);
+        HIP_OK(hipMemcpyAsync(s1.z, dur_noise_pinned_, sizeof(float) * n, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipEventRecord(dur_noise_ev_, stream));
+        prof.fence();
+        if (o.collect_taps) snapshot("noise_dur", z, 2, Tmax, B, tlen);
+        HIP_OK(launch_scale_rows(z, 2, hp.noise_scale_dur, B, Tmax, stream));
     } else {
         host_noise.assign((size_t)B * 2 * ts, 0.f);
         for (int b = 0; b < B; ++b) {

@@ -166,6 +166,16 @@ int Engine::run_stage_one_exact(Call& c) {
         prof.begin("noise_dur", 0, 0, stream);
         HIP_OK(launch_noise_dur(z, dl, B, Tmax, o.noise_seed, s1.seed_off, hp.noise_scale_dur, stream));  // one multiply per element (:948-949)
         prof.end(stream);
+    } else if (c.ref_ahead) {
+        // (batch 1, reference noise: the helper thread of engine.cpp holds the stream — take the [T, 2] tensor from it)
+        host_noise.assign((size_t)2 * ts, 0.f);
+        const float* tmpn = c.ref_ahead->duration_noise();
+        for (int ch = 0; ch < 2; ++ch) std::memcpy(&host_noise[(size_t)ch * ts], tmpn + (size_t)ch * tlen[0], sizeof(float) * tlen[0]);
+        HIP_OK(hipMemcpyAsync(s1.z, host_noise.data(), sizeof(float) * host_noise.size(), hipMemcpyHostToDevice, stream));
+        prof.fence();
+        if (o.collect_taps) snapshot("noise_dur", z, 2, Tmax, B, tlen);
+        HIP_OK(launch_scale_rows(z, 2, hp.noise_scale_dur, B, Tmax, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // host_noise goes out of scope
     } else {
         host_noise.assign((size_t)B * 2 * ts, 0.f);
         for (int b = 0; b < B; ++b) {

@@ -1,9 +1,11 @@
 // engine_support.cpp — the engine's plumbing: roctx ranges, the reference noise stream, tokenizer, HIP-event profiler, arenas, knobs.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <mutex>
 #include <random>
 #include <sstream>
+#include <thread>
 
 #include "engine_internal.h"
 
@@ -41,6 +43,7 @@ void Knobs::read() {
     if (const char* e = std::getenv("VITS_PROF_ATTACH")) prof_attach = std::atoi(e) != 0;
     if (const char* e = std::getenv("VITS_FRONT_PRIO")) front_prio = std::atoi(e);
     no_pipeline = flag("VITS_NO_PIPELINE");
+    if (const char* e = std::getenv("VITS_REF_AHEAD_FRAMES_PER_ID")) ref_ahead_frames_per_id = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("VITS_FLOW_CHAINS")) flow_chains = std::atoi(e);
     if (const char* e = std::getenv("VITS_FLOW_CHAIN_MIN_BLOCKS")) flow_chain_min_blocks = std::atoi(e);
     if (const char* e = std::getenv("VITS_SPLIT_MIN_BATCH")) split_min_batch = std::atoi(e);
@@ -60,6 +63,89 @@ void reference_noise_fill(float* dst, size_t n) {
     std::lock_guard<std::mutex> lk(g_ref_mu);
     std::normal_distribution<float> dist(0.0f, 1.0f);
     for (size_t i = 0; i < n; ++i) dst[i] = dist(g_ref_rng);
+}
+
+// ---- the reference stream of ONE batch-1 call, drawn on a helper thread while the device runs stage one -----------------------------------
+// vits.cpp draws tensor_randn {T, 2} at :948 and tensor_randn_like(prior_means) = [L, 192] at :1059, the second only once L is known, i.e. behind
+// stage one; on the host that is ~1.25 ms for 128 ids (libstdc++'s polar method, ~28 ns per value) during which the device waits — while during stage
+// one the calling thread is busy queueing ~70 launches (at batch 1 the host barely keeps ahead of the device). The values are one sequential stream
+// whatever L turns out to be (element n of the tensor is draw n), so a helper thread draws them from the start of the call; the engine state after every
+// value is kept, and finish(n) leaves the global engine exactly where n draws leave it (a fresh normal_distribution per tensor, ggml-util.h:187-199: a
+// cached second value of the polar method is discarded with the distribution object). The stream's lock is held from start to finish.
+struct RefNoiseAhead::Impl {
+    std::thread th;
+    std::vector<std::default_random_engine> states;  // states[i] = engine after prior value i + 1
+    std::default_random_engine start;                // ... and before the first one
+    std::vector<float> dur;
+    std::atomic<int> dur_ready{0};
+    std::atomic<size_t> target{SIZE_MAX}, drawn{0}, cap{0};
+    std::atomic<float*> buf{nullptr};
+};
+RefNoiseAhead::RefNoiseAhead() : impl_(new Impl) {}
+RefNoiseAhead::~RefNoiseAhead() {
+    if (active_) finish(impl_->drawn.load());
+    delete impl_;
+}
+void RefNoiseAhead::start(size_t n_dur, float* prior, size_t cap) {
+    Impl& I = *impl_;
+    I.dur.assign(n_dur, 0.f);
+    I.dur_ready.store(0);
+    I.target.store(SIZE_MAX);
+    I.drawn.store(0);
+    if (I.states.size() < cap) I.states.resize(cap);
+    I.cap.store(cap);
+    I.buf.store(prior);
+    I.th = std::thread([this] {
+        Impl& I = *impl_;
+        std::lock_guard<std::mutex> lk(g_ref_mu);
+        {
+            std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:948
+            for (float& v : I.dur) v = dist(g_ref_rng);
+        }
+        I.dur_ready.store(1, std::memory_order_release);
+        std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:1059
+        I.start = g_ref_rng;
+        size_t n = 0;
+        for (;;) {
+            const size_t tgt = I.target.load(std::memory_order_acquire);
+            const size_t lim = std::min(tgt, I.cap.load(std::memory_order_acquire));
+            if (n < lim) {
+                float* b = I.buf.load(std::memory_order_acquire);
+                const size_t end = std::min(lim, n + 256);
+                for (; n < end; ++n) {
+                    b[n] = dist(g_ref_rng);
+                    I.states[n] = g_ref_rng;
+                }
+                I.drawn.store(n, std::memory_order_release);
+                continue;
+            }
+            if (tgt != SIZE_MAX && n >= tgt) {
+                if (n > tgt) g_ref_rng = tgt > 0 ? I.states[tgt - 1] : I.start;
+                break;
+            }
+            std::this_thread::yield();  // at the capacity with the size still unknown (or a larger buffer on its way)
+        }
+    });
+    active_ = true;  // (only once the thread exists: finish() joins it)
+}
+const float* RefNoiseAhead::duration_noise() {
+    while (!impl_->dur_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+    return impl_->dur.data();
+}
+size_t RefNoiseAhead::drawn() const { return impl_->drawn.load(std::memory_order_acquire); }
+size_t RefNoiseAhead::capacity() const { return impl_->cap.load(std::memory_order_acquire); }
+void RefNoiseAhead::rebase(float* prior, size_t cap) {
+    // only while the worker rests at the old capacity (drawn() == capacity()): nothing of its state is being touched
+    Impl& I = *impl_;
+    if (I.states.size() < cap) I.states.resize(cap);
+    I.buf.store(prior, std::memory_order_release);
+    I.cap.store(cap, std::memory_order_release);
+}
+void RefNoiseAhead::finish(size_t n) {
+    if (!active_) return;
+    impl_->target.store(n, std::memory_order_release);
+    impl_->th.join();
+    active_ = false;
 }
 
 // ---- tokenizer (src/vits_tokenizer.cpp:57-78,182-208; deterministic longest match instead of unordered_map order, Q11) ----
