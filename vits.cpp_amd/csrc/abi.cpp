@@ -122,8 +122,13 @@ static vits_result process_ids_impl(vits_model* model, const int32_t* ids, size_
     }
     // vits.cpp:1226-1231: a fresh buffer of exactly `size` samples owned by the library
     r.size = (size_t)br.lengths[0];
-    r.data = new float[r.size];
-    std::memcpy(r.data, br.data, sizeof(float) * r.size);
+    if (br.batch == 1 && br.stride >= r.size) {  // one utterance: its row IS the result (no second buffer, no copy)
+        r.data = br.data;
+        br.data = nullptr;
+    } else {
+        r.data = new float[r.size];
+        std::memcpy(r.data, br.data, sizeof(float) * r.size);
+    }
     vits_free_batch_result(&br);
     return r;
 }
