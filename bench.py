@@ -18,6 +18,7 @@ line, and fails if any rank fails or fewer than N devices are visible — it nev
 Prints ONE JSON line (< 4 KB: compact_line) on rank 0, LAST on stdout; the full record goes to bench_detail.json.
 """
 import argparse
+import gc
 import glob
 import importlib.util
 import json
@@ -216,6 +217,10 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
             wait()
             wait()
         torch.cuda.synchronize()
+        # (no cyclic-GC pause inside a timed region: a generation-2 collection over the records of the main run — 40 ms with --steps 20 —
+        # once landed in the 16 serial f16 steps and read as 16.4 instead of 14.0 ms per step)
+        gc.collect()
+        gc.disable()
         t = time.perf_counter()
         samples = 0
         if pipelined:
@@ -231,7 +236,9 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
                 n, frames = one(k)
                 samples += n
         torch.cuda.synchronize()
-        return time.perf_counter() - t, samples, frames
+        e = time.perf_counter() - t
+        gc.enable()
+        return e, samples, frames
 
     def measured_bytes(tag):
         """whole-step HBM bytes of a PMC artefact (profiles/*_pmc_traffic.json) collected for THIS build on the workload `tag`, or None"""
@@ -303,10 +310,14 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
         returned in host memory, /root/reference/src/vits.cpp:1225-1232), ms per utterance"""
         for _ in range(3):
             base_model.process_ids(ids1[0])
+        gc.collect()
+        gc.disable()
         t = time.perf_counter()
         for _ in range(reps):
             base_model.process_ids(ids1[0])
-        return 1000.0 * (time.perf_counter() - t) / reps
+        e = time.perf_counter() - t
+        gc.enable()
+        return 1000.0 * e / reps
 
     out["c2_f32"]["reference_api_ms"] = reference_api_ms(n)
     b2, _ = buf_for(1, 128, 2)
@@ -768,13 +779,17 @@ def main():
 
     def timed(n, **kw):
         fence()
+        gc.collect()
+        gc.disable()  # (no cyclic-GC pause inside the timed region)
         t = time.perf_counter()
         samples = 0
         for _ in range(n):
             lengths, frames = step(**kw)
             samples += int(lengths.sum())
         fence()
-        return time.perf_counter() - t, samples, frames
+        e = time.perf_counter() - t
+        gc.enable()
+        return e, samples, frames
 
     models = [j["model"] for j in jobs]
     if args.single_pass and not args.no_prof:
