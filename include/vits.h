@@ -330,7 +330,15 @@ VITS_API int vits_write_wav16(const char* path, const float* pcm, size_t n, int3
  * elem_bytes 4 = fp32 PCM, 2 = PCM16 (vits_pcm16_from_float_device first: half the bytes on the links). `hip_stream` = the stream the PCM was
  * produced on (the exchange is ordered behind it without a host wait), NULL when the producer has been synchronised — vits_model_process_batch
  * without opts.async has. The call returns when the gathered block is complete; it stays valid until the next call on the same object.
- * One call at a time per object. Return 0 / non-NULL on success, else -1 / NULL with vits_last_error(). */
+ * One call at a time per object. Return 0 / non-NULL on success, else -1 / NULL with vits_last_error().
+ * Failure is COLLECTIVE as well: the first all-gather carries every rank's row_capacity and lengths, a rank whose own arguments are unusable
+ * (NULL buffer, a negative length, a row longer than its pcm_stride or than row_capacity) sends -1 for the row instead of returning early, and
+ * every rank derives the same verdict from the same table — all ranks return -1 with the offending (rank, row) in vits_last_error(), none is left
+ * blocked in RCCL, and the object stays usable. pcm_stride need only reach the rank's OWN longest row. A HIP / RCCL error inside an exchange aborts
+ * the communicator (ncclCommAbort) and the object refuses further calls: destroy it on every rank. Elements of a gathered row between its length
+ * and `stride` are UNSPECIFIED (padding; rows are not zero-filled).
+ * vits_pcm_gather_verdict is that decision as a pure host function of the gathered table (per rank: row_capacity, then `rows` lengths with -1 for an
+ * unusable row): 0 and the common row width in *stride_out, or -1 with the message in vits_last_error(). */
 #define VITS_GATHER_ID_BYTES 128
 typedef struct vits_gather_ctx vits_gather_ctx;
 typedef struct vits_gather_result {
@@ -345,6 +353,7 @@ VITS_API vits_gather_ctx* vits_pcm_gather_init(const char* id, size_t id_bytes, 
 VITS_API int vits_pcm_gather(vits_gather_ctx* g, const void* pcm_device, int64_t pcm_stride, const int64_t* lengths_host, void* hip_stream,
                              vits_gather_result* out);
 VITS_API void vits_pcm_gather_destroy(vits_gather_ctx* g);
+VITS_API int vits_pcm_gather_verdict(const int64_t* table, int32_t world, int32_t rows, int64_t* stride_out);
 
 /* Select the HIP device used by subsequent loads on this thread (one process per GPU: pass LOCAL_RANK). */
 VITS_API int vits_set_device(int32_t device);

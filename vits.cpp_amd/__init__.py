@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "vits_model_set_arith", "vits_model_get_arith", "vits_model_file_validate", "vits_op_set_arith",
     "vits_model_set_arith_scope", "vits_model_get_arith_scope", "vits_model_submit_batch", "vits_model_wait", "vits_model_pending",
     "vits_model_set_ggml_tables", "vits_model_get_ggml_tables",
-    "vits_pcm_gather_unique_id", "vits_pcm_gather_init", "vits_pcm_gather", "vits_pcm_gather_destroy",
+    "vits_pcm_gather_unique_id", "vits_pcm_gather_init", "vits_pcm_gather", "vits_pcm_gather_destroy", "vits_pcm_gather_verdict",
 ]
 
 
@@ -589,6 +589,18 @@ def gather_unique_id():
     if f(buf) != 0:
         raise VitsError(last_error())
     return buf.raw
+
+
+def gather_verdict(table, world, rows):
+    """vits_pcm_gather_verdict: the decision every rank takes on the table of the first all-gather ([row_capacity, lengths...] per rank, -1 = a row
+    its rank could not use). Returns the common row width; raises VitsError with the message every rank would report."""
+    t = np.ascontiguousarray(table, dtype=np.int64).reshape(world, rows + 1)
+    f = lib().vits_pcm_gather_verdict
+    f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    out = C.c_int64(0)
+    if f(_ptr(t), world, rows, C.byref(out)) != 0:
+        raise VitsError(last_error())
+    return int(out.value)
 
 
 class PcmGather:

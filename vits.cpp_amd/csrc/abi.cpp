@@ -772,11 +772,11 @@ VITS_API vits_gather_ctx* vits_pcm_gather_init(const char* id, size_t id_bytes, 
 
 VITS_API int vits_pcm_gather(vits_gather_ctx* g, const void* pcm_device, int64_t pcm_stride, const int64_t* lengths_host, void* hip_stream, vits_gather_result* out) {
     VITS_TRY
-    if (out) std::memset(out, 0, sizeof(*out));
-    if (!g) {
+    if (!g || !out) {  // (nothing to hand a result to, or no communicator to tell the peers through)
         set_err("null argument");
         return -1;
     }
+    std::memset(out, 0, sizeof(*out));
     vits::BusyGuard guard(&g->busy);
     if (!guard.entered()) {
         set_err("gather busy: one call at a time per gather object");
@@ -792,6 +792,21 @@ VITS_API int vits_pcm_gather(vits_gather_ctx* g, const void* pcm_device, int64_t
     out->stride = r.stride;
     out->lengths = r.lengths;
     out->rows_total = r.rows_total;
+    return 0;
+    VITS_CATCH(-1)
+}
+
+VITS_API int vits_pcm_gather_verdict(const int64_t* table, int32_t world, int32_t rows, int64_t* stride_out) {
+    VITS_TRY
+    if (!table || !stride_out || world < 1 || rows < 1) {
+        set_err("null argument");
+        return -1;
+    }
+    std::string err;
+    if (vits::PcmGather::verdict(table, world, rows, stride_out, err) != 0) {
+        set_err(err);
+        return -1;
+    }
     return 0;
     VITS_CATCH(-1)
 }

@@ -22,6 +22,7 @@ struct RcclApi {
     int (*CommDestroy)(void* comm) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s) = nullptr;
+    int (*CommAbort)(void* comm) = nullptr;  // optional (rccl.h ncclCommAbort): the failure path of PcmGather::gather
     std::string why;  // why it is not available
     bool ok() const { return AllGather != nullptr; }
     static const RcclApi& get();  // dlopen(VITS_RCCL_LIB or librccl.so.1 / librccl.so) once per process
@@ -41,7 +42,13 @@ class PcmGather {
     };
     // pcm: device [rows][pcm_stride] elements, row b valid up to lengths_host[b]; producer: the stream the PCM was written on (the
     // exchange is ordered behind it; nullptr = the caller has synchronised). Blocks until the gathered block is complete.
+    // COLLECTIVE, also in failure: a rank whose own arguments are unusable still takes part in the first all-gather (its rows travel as -1)
+    // and every rank returns -1 with the same verdict; elements of a gathered row beyond its length are unspecified.
     int gather(const void* pcm, int64_t pcm_stride, const int64_t* lengths_host, hipStream_t producer, Result* out, std::string& err);
+    // the verdict on the table of the first all-gather ([row_capacity, lengths...] per rank): 0 + the common row width, or -1 + a message.
+    // A pure function of the table (identical on every rank), exported as vits_pcm_gather_verdict for the CPU tests.
+    static int verdict(const int64_t* table, int world, int rows, int64_t* smax_out, std::string& err);
+    bool aborted() const { return aborted_; }
     int world() const { return world_; }
     bool uses_rccl() const { return comm_ != nullptr; }
     int64_t bytes_moved = 0;
@@ -52,7 +59,10 @@ class PcmGather {
     void* comm_ = nullptr;
     hipStream_t side_ = nullptr;
     hipEvent_t ev_ = nullptr;
-    int64_t *len_send_h_ = nullptr, *len_all_h_ = nullptr;  // pinned
+    bool broken_ = false, aborted_ = false;
+    void poison();  // a HIP / RCCL failure inside an exchange: abort the communicator (peers get an error, not a hang), refuse further calls
+    std::vector<int64_t> len_out_h_;                         // [world * rows]: what Result::lengths points at
+    int64_t *len_send_h_ = nullptr, *len_all_h_ = nullptr;  // pinned, [rows + 1] and [world][rows + 1]
     int64_t *len_send_d_ = nullptr, *len_all_d_ = nullptr;
     char *send_ = nullptr, *out_ = nullptr;
 };
