@@ -49,14 +49,22 @@ typedef struct vits_result {
 VITS_API vits_model* vits_model_load_from_bytes(const char* bytes, size_t size);
 /* reference: vits.h:96, vits.cpp:1193-1203 */
 VITS_API vits_model* vits_model_load_from_file(const char* path);
-/* reference: vits.h:98, vits.cpp:1217-1219 */
+/* reference: vits.h:98, vits.cpp:1217-1219. A handle that another thread (or a streaming callback) is inside is NOT freed: the call returns with
+ * vits_last_error() = "vits_free_model: model busy ..." and leaves the handle exactly as it was (the busy flag belongs to the call in progress and is
+ * released when that call returns) — call vits_free_model again then. The function returns void as in the reference: check vits_last_error(). */
 VITS_API void vits_free_model(vits_model* model);
 /* reference: vits.h:100, vits.cpp:1221-1223 */
 VITS_API void vits_free_result(vits_result result);
 /* reference: vits.h:102, vits.cpp:1225-1232 -> vits_model::process vits.cpp:1101-1191.
  * Text is lower-cased, greedily matched against the model vocabulary and interspersed with blanks
  * (src/vits_tokenizer.cpp:182-208). Noise comes from the reference's process-global libstdc++ stream
- * (VITS_NOISE_REFERENCE), mode is the model default (VITS_MODE_REFERENCE unless changed). */
+ * (VITS_NOISE_REFERENCE), mode is the model default (VITS_MODE_REFERENCE unless changed).
+ * Two model-file flags decide what the TEXT entry points (this one, vits_model_tokenize, vits_model_file_tokenize) do:
+ *   config "phonetic" = "1" (vits_model_data.cpp:92-94): the model expects espeak-ng phonemes. The reference asserts out at load unless built with
+ *     VITS_ESPEAK (vits_tokenizer.cpp:176-178); espeak is out of scope here, so the model LOADS and the text entry points fail with
+ *     vits_last_error() = "model expects espeak phonemes ... pass ids"; the id entry points are unaffected.
+ *   add_blank = 0: the reference's tokenizer returns an EMPTY id list (Q11, vits_tokenizer.cpp:200-208) and its process() an empty result; the same
+ *     here ({NULL, 0} with a message that says so; vits_model_tokenize returns 0). */
 VITS_API vits_result vits_model_process(vits_model* model, const char* phonemes);
 
 /* ---- extensions ------------------------------------------------------------------------------------- */
@@ -215,7 +223,8 @@ VITS_API int vits_model_submit_batch(vits_model* model, const int32_t* ids, cons
 VITS_API int vits_model_wait(vits_model* model, vits_batch_result* out);
 VITS_API int vits_model_pending(const vits_model* model);
 
-/* Tokenizer only (src/vits_tokenizer.cpp:182-208). Writes up to cap ids, returns the count (or -1). */
+/* Tokenizer only (src/vits_tokenizer.cpp:182-208). Writes up to cap ids, returns the count (0 for a model file with add_blank = 0, as the
+ * reference; -1 with vits_last_error() for a phonetic model or a NULL argument). */
 VITS_API int64_t vits_model_tokenize(vits_model* model, const char* text, int32_t* ids, size_t cap);
 
 /* Model facts. */

@@ -3,6 +3,7 @@
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -285,3 +286,57 @@ def test_tensor_dimension_product_overflow_is_rejected(pkg, tiny_bytes):
     bad = tiny_bytes[:rank_off] + rec + tiny_bytes[rank_off + 4 + 4 * rank + 4:]
     with pytest.raises(pkg.VitsError, match="overflows|byte length"):
         pkg.validate(bad)
+
+
+def _patch_model_file(data, add_blank=None, extra_cfg=()):
+    """Rewrite two header fields of a model file: the add_blank word and the config block (extra key / value pairs appended)."""
+    import struct
+    off = 0
+
+    def u32():
+        nonlocal off
+        (v,) = struct.unpack_from("<I", data, off)
+        off += 4
+        return v
+
+    def skip_s():
+        nonlocal off
+        n = u32()
+        off += n
+
+    for _ in range(u32()):
+        skip_s()
+        u32()
+    ab_off = off
+    u32(), u32()
+    skip_s(), skip_s()
+    ncfg_off = off
+    ncfg = u32()
+    for _ in range(ncfg):
+        skip_s(), skip_s()
+    cfg_end = off
+    out = bytearray(data[:cfg_end])
+    if add_blank is not None:
+        struct.pack_into("<I", out, ab_off, add_blank)
+    struct.pack_into("<I", out, ncfg_off, ncfg + len(extra_cfg))
+    for k, v in extra_cfg:
+        for t in (k.encode(), v.encode()):
+            out += struct.pack("<I", len(t)) + t
+    return bytes(out) + data[cfg_end:]
+
+
+def test_text_entry_points_honour_phonetic_and_add_blank(pkg, tiny_hf_bytes):
+    """The two model-file flags of the tokenizer (VERDICT r5 missing 4 / weak 12). `phonetic = 1` (vits_model_data.cpp:92-94 -> set_phonetic,
+    vits_tokenizer.cpp:176-178: the reference asserts out without VITS_ESPEAK): the file still validates and the text entry point refuses with a message that
+    says to pass ids; `phonetic = 0` changes nothing. `add_blank = 0` (Q11, vits_tokenizer.cpp:200-208: tokens_final is only filled under add_blank): no ids."""
+    base = pkg.file_tokenize(tiny_hf_bytes, "hello world")
+    assert base.size == 2 * 11 + 1 and (base[0::2] == base[0]).all()  # eleven known symbols (the space is one), blanks interspersed
+    ph = _patch_model_file(tiny_hf_bytes, extra_cfg=[("phonetic", "1")])
+    pkg.validate(ph)  # (raises on failure: a phonetic model LOADS; the reference without VITS_ESPEAK would assert out)
+    with pytest.raises(pkg.VitsError) as e:
+        pkg.file_tokenize(ph, "hello world")
+    assert "espeak" in str(e.value) and "pass ids" in str(e.value)
+    assert np.array_equal(pkg.file_tokenize(_patch_model_file(tiny_hf_bytes, extra_cfg=[("phonetic", "0")]), "hello world"), base)
+    nb = _patch_model_file(tiny_hf_bytes, add_blank=0)
+    assert pkg.file_tokenize(nb, "hello world").size == 0
+    assert pkg.reserialize(ph) == ph and pkg.reserialize(nb) == nb  # both are well-formed files

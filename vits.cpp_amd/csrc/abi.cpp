@@ -82,7 +82,8 @@ VITS_API vits_model* vits_model_load_from_file(const char* path) {
 
 // reference: src/vits.cpp:1217-1219
 // A handle another thread is inside (or that a callback is running on) is NOT freed: the call would go on using the engine it
-// runs on. The flag is taken and never given back — the handle is dead after this call either way.
+// runs on. The refusal path does not touch the flag (the compare-exchange fails without writing: the flag stays the in-flight call's and is
+// released when that call returns, so the retry the message asks for succeeds); the success path takes the flag and deletes the handle with it.
 VITS_API void vits_free_model(vits_model* model) {
     if (!model) return;
     bool expected = false;
@@ -141,7 +142,16 @@ VITS_API vits_result vits_model_process(vits_model* model, const char* phonemes)
         set_err("null argument");
         return none;
     }
-    std::vector<int32_t> ids = model->eng.tok.tokenize(phonemes);  // vits.cpp:1109
+    std::vector<int32_t> ids;
+    std::string terr;
+    if (!model->eng.tok.tokenize_checked(phonemes, ids, terr)) {  // vits.cpp:1109 (a phonetic model: refused, see engine.h Tokenizer)
+        set_err(terr);
+        return none;
+    }
+    if (ids.empty() && !model->eng.tok.add_blank) {  // Q11: the reference's tokenizer returns no ids at all without add_blank
+        set_err("empty input: the model file says add_blank = 0, for which the reference tokenizer returns no ids (vits_tokenizer.cpp:200-208); pass ids");
+        return none;
+    }
     return process_ids_impl(model, ids.data(), ids.size());
     VITS_CATCH(none)
 }
@@ -317,8 +327,16 @@ VITS_API int vits_model_sync(vits_model* model) {
 
 VITS_API int64_t vits_model_tokenize(vits_model* model, const char* text, int32_t* ids, size_t cap) {
     VITS_TRY
-    if (!model || !text) return -1;
-    std::vector<int32_t> v = model->eng.tok.tokenize(text);
+    if (!model || !text || (cap && !ids)) {
+        set_err("null argument");
+        return -1;
+    }
+    std::vector<int32_t> v;
+    std::string terr;
+    if (!model->eng.tok.tokenize_checked(text, v, terr)) {
+        set_err(terr);
+        return -1;
+    }
     for (size_t i = 0; i < v.size() && i < cap; ++i) ids[i] = v[i];
     return (int64_t)v.size();
     VITS_CATCH(-1)
@@ -391,9 +409,17 @@ VITS_API int64_t vits_model_file_tokenize(const char* model_bytes, size_t size, 
         set_err(err);
         return -1;
     }
+    if (cap && !ids) {
+        set_err("null argument");
+        return -1;
+    }
     vits::Tokenizer t;
     t.init(f);
-    std::vector<int32_t> v = t.tokenize(text);
+    std::vector<int32_t> v;
+    if (!t.tokenize_checked(text, v, err)) {
+        set_err(err);
+        return -1;
+    }
     for (size_t i = 0; i < v.size() && i < cap; ++i) ids[i] = v[i];
     return (int64_t)v.size();
     VITS_CATCH(-1)

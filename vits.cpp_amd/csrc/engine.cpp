@@ -261,10 +261,13 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         return -1;
     }
     Call c(o, err, ids, B, id_stride);
-    struct AheadGuard {  // an error path between the speculative draw and its commit must not leave the reference stream locked
+    // An error path between the speculative draw and its commit must not leave the reference stream locked — nor at a timing-dependent
+    // position: finish(0) rewinds to the state behind the [T, 2] tensor, where the sequential path this replaces leaves the stream when a call
+    // fails before prior sampling (finish(drawn()) committed however many values the helper happened to have drawn).
+    struct AheadGuard {
         RefNoiseAhead& a;
         ~AheadGuard() {
-            if (a.active()) a.finish(a.drawn());
+            if (a.active()) a.finish(0);
         }
     } ahead_guard{ref_ahead_};
     c.md = o.mode == VITS_MODE_DEFAULT ? mode : o.mode;

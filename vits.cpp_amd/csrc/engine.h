@@ -22,8 +22,15 @@ struct Tokenizer {
     std::vector<std::pair<std::string, int32_t>> vocab;  // sorted by descending key length
     int32_t blank_id = 0;
     bool add_blank = true;
+    // config key "phonetic" == "1" (vits_model_data.cpp:92-94 -> vits_tokenizer::set_phonetic): the model was trained on espeak-ng phonemes. The
+    // reference built without VITS_ESPEAK asserts out at load (vits_tokenizer.cpp:176-178); espeak is out of scope here, so the model
+    // loads and the TEXT entry points refuse (tokenize_checked) — the id entry points are what such a model is driven through.
+    bool phonetic = false;
     void init(const ModelFile& f);
     std::vector<int32_t> tokenize(const std::string& text) const;
+    // the text entry points of the C ABI: false + message for a phonetic model; add_blank == 0 gives the reference's EMPTY id list (Q11,
+    // vits_tokenizer.cpp:200-208: tokens_final is only filled under add_blank), which the callers report as "empty input"
+    bool tokenize_checked(const std::string& text, std::vector<int32_t>& ids, std::string& err) const;
 };
 
 struct Profiler {

@@ -9,6 +9,8 @@
 
 #include "engine_internal.h"
 
+#include <condition_variable>
+
 namespace vits {
 
 RoctxApi::RoctxApi() {
@@ -73,17 +75,80 @@ void reference_noise_fill(float* dst, size_t n) {
 // value is kept, and finish(n) leaves the global engine exactly where n draws leave it (a fresh normal_distribution per tensor, ggml-util.h:187-199: a
 // cached second value of the polar method is discarded with the distribution object). The stream's lock is held from start to finish.
 struct RefNoiseAhead::Impl {
+    // ONE helper thread per engine, created at the first reference-noise call and parked on a condition variable between calls (round 5 spawned a
+    // std::thread per call and let it spin on yield() at the buffer's end)
     std::thread th;
+    std::mutex m;
+    std::condition_variable cv;        // worker: a job, a new target / capacity, or quit
+    std::condition_variable cv_done;   // caller: the job has ended
+    bool have_job = false, quit = false;
+    std::atomic<bool> done{true};
     std::vector<std::default_random_engine> states;  // states[i] = engine after prior value i + 1
     std::default_random_engine start;                // ... and before the first one
     std::vector<float> dur;
     std::atomic<int> dur_ready{0};
     std::atomic<size_t> target{SIZE_MAX}, drawn{0}, cap{0};
     std::atomic<float*> buf{nullptr};
+    void job() {
+        std::lock_guard<std::mutex> lk(g_ref_mu);  // the process-global stream (vits.cpp:31) belongs to this call until finish()
+        {
+            std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:948
+            for (float& v : dur) v = dist(g_ref_rng);
+        }
+        dur_ready.store(1, std::memory_order_release);
+        std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:1059
+        start = g_ref_rng;
+        size_t n = 0;
+        for (;;) {
+            const size_t tgt = target.load(std::memory_order_acquire);
+            const size_t lim = std::min(tgt, cap.load(std::memory_order_acquire));
+            if (n < lim) {
+                float* b = buf.load(std::memory_order_acquire);
+                const size_t end = std::min(lim, n + 256);
+                for (; n < end; ++n) {
+                    b[n] = dist(g_ref_rng);
+                    states[n] = g_ref_rng;
+                }
+                drawn.store(n, std::memory_order_release);
+                continue;
+            }
+            if (tgt != SIZE_MAX && n >= tgt) {
+                if (n > tgt) g_ref_rng = tgt > 0 ? states[tgt - 1] : start;
+                return;
+            }
+            // at the capacity with the size still unknown (or a larger buffer on its way): sleep until finish() / rebase() says more
+            std::unique_lock<std::mutex> ul(m);
+            cv.wait(ul, [&] { return target.load(std::memory_order_acquire) != tgt || cap.load(std::memory_order_acquire) > n; });
+        }
+    }
+    void run() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> ul(m);
+                cv.wait(ul, [&] { return have_job || quit; });
+                if (quit) return;
+                have_job = false;
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                done.store(true, std::memory_order_release);
+            }
+            cv_done.notify_all();
+        }
+    }
 };
 RefNoiseAhead::RefNoiseAhead() : impl_(new Impl) {}
 RefNoiseAhead::~RefNoiseAhead() {
-    if (active_) finish(impl_->drawn.load());
+    if (active_) finish(0);
+    if (impl_->th.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(impl_->m);
+            impl_->quit = true;
+        }
+        impl_->cv.notify_all();
+        impl_->th.join();
+    }
     delete impl_;
 }
 void RefNoiseAhead::start(size_t n_dur, float* prior, size_t cap) {
@@ -95,41 +160,17 @@ void RefNoiseAhead::start(size_t n_dur, float* prior, size_t cap) {
     if (I.states.size() < cap) I.states.resize(cap);
     I.cap.store(cap);
     I.buf.store(prior);
-    I.th = std::thread([this] {
-        Impl& I = *impl_;
-        std::lock_guard<std::mutex> lk(g_ref_mu);
-        {
-            std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:948
-            for (float& v : I.dur) v = dist(g_ref_rng);
-        }
-        I.dur_ready.store(1, std::memory_order_release);
-        std::normal_distribution<float> dist(0.0f, 1.0f);  // vits.cpp:1059
-        I.start = g_ref_rng;
-        size_t n = 0;
-        for (;;) {
-            const size_t tgt = I.target.load(std::memory_order_acquire);
-            const size_t lim = std::min(tgt, I.cap.load(std::memory_order_acquire));
-            if (n < lim) {
-                float* b = I.buf.load(std::memory_order_acquire);
-                const size_t end = std::min(lim, n + 256);
-                for (; n < end; ++n) {
-                    b[n] = dist(g_ref_rng);
-                    I.states[n] = g_ref_rng;
-                }
-                I.drawn.store(n, std::memory_order_release);
-                continue;
-            }
-            if (tgt != SIZE_MAX && n >= tgt) {
-                if (n > tgt) g_ref_rng = tgt > 0 ? I.states[tgt - 1] : I.start;
-                break;
-            }
-            std::this_thread::yield();  // at the capacity with the size still unknown (or a larger buffer on its way)
-        }
-    });
-    active_ = true;  // (only once the thread exists: finish() joins it)
+    if (!I.th.joinable()) I.th = std::thread([this] { impl_->run(); });
+    {
+        std::lock_guard<std::mutex> lk(I.m);
+        I.done.store(false, std::memory_order_release);
+        I.have_job = true;
+    }
+    I.cv.notify_all();
+    active_ = true;
 }
 const float* RefNoiseAhead::duration_noise() {
-    while (!impl_->dur_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+    while (!impl_->dur_ready.load(std::memory_order_acquire)) std::this_thread::yield();  // (256 draws, ~10 us after start(): asked for a whole text encoder later)
     return impl_->dur.data();
 }
 size_t RefNoiseAhead::drawn() const { return impl_->drawn.load(std::memory_order_acquire); }
@@ -138,13 +179,27 @@ void RefNoiseAhead::rebase(float* prior, size_t cap) {
     // only while the worker rests at the old capacity (drawn() == capacity()): nothing of its state is being touched
     Impl& I = *impl_;
     if (I.states.size() < cap) I.states.resize(cap);
-    I.buf.store(prior, std::memory_order_release);
-    I.cap.store(cap, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(I.m);
+        I.buf.store(prior, std::memory_order_release);
+        I.cap.store(cap, std::memory_order_release);
+    }
+    I.cv.notify_all();
 }
 void RefNoiseAhead::finish(size_t n) {
     if (!active_) return;
-    impl_->target.store(n, std::memory_order_release);
-    impl_->th.join();
+    Impl& I = *impl_;
+    {
+        std::lock_guard<std::mutex> lk(I.m);
+        I.target.store(n, std::memory_order_release);
+    }
+    I.cv.notify_all();
+    // the worker is usually past n already (or a few hundred draws short): look before sleeping
+    for (int spin = 0; spin < 2000 && !I.done.load(std::memory_order_acquire); ++spin) std::this_thread::yield();
+    if (!I.done.load(std::memory_order_acquire)) {
+        std::unique_lock<std::mutex> ul(I.m);
+        I.cv_done.wait(ul, [&] { return I.done.load(std::memory_order_acquire); });
+    }
     active_ = false;
 }
 
@@ -157,6 +212,19 @@ void Tokenizer::init(const ModelFile& f) {
     blank_id = 0;
     for (auto& kv : f.vocab)
         if (kv.first == f.pad_token) blank_id = (int32_t)kv.second;  // vocab[pad_token], vits_tokenizer.cpp:201
+    phonetic = false;
+    for (auto& kv : f.config)
+        if (kv.first == "phonetic" && kv.second == "1") phonetic = true;  // vits_model_data.cpp:92-94
+}
+
+bool Tokenizer::tokenize_checked(const std::string& text, std::vector<int32_t>& ids, std::string& err) const {
+    if (phonetic) {
+        err = "model expects espeak phonemes (config phonetic=1; the reference needs VITS_ESPEAK for it, vits_tokenizer.cpp:176-178): pass ids "
+              "(vits_model_process_ids / vits_model_process_batch)";
+        return false;
+    }
+    ids = tokenize(text);
+    return true;
 }
 
 std::vector<int32_t> Tokenizer::tokenize(const std::string& text) const {
