@@ -30,26 +30,36 @@ def to_host(ptr, shape, dtype):
     return out
 
 
-# the 128 bytes travel through a file (the host application's job)
-if rank == 0:
-    uid = pkg.gather_unique_id()
-    with open(id_file + ".tmp", "wb") as f:
-        f.write(uid)
-    os.rename(id_file + ".tmp", id_file)
-else:
+_n_ids = [0]
+
+
+def fresh_uid():
+    """one unique id per communicator (RCCL's bootstrap serves an id once); the 128 bytes travel through a file (the host application's job)"""
+    path = "%s.%d" % (id_file, _n_ids[0])
+    _n_ids[0] += 1
+    if rank == 0:
+        uid = pkg.gather_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(path + ".tmp", path)
+        return uid
     t0 = time.time()
-    while not os.path.exists(id_file):
+    while not os.path.exists(path):
         assert time.time() - t0 < 60, "rank 0 never wrote the unique id"
         time.sleep(0.01)
-    uid = open(id_file, "rb").read()
+    return open(path, "rb").read()
+
 
 m = pkg.Model(pkg.synth_model_bytes(0x5EED, pkg.SYNTH_TINY))
 rows = 3
-id_lens = np.array([12, 3, 9, 5, 1, 6], np.int32)  # rank 0 owns the three longer utterances: the ranks' local maxima differ
+id_lens = np.array([12, 3, 9, 5, 1, 6], np.int32)
 ids = np.zeros((6, 12), np.int32)
 for b, n in enumerate(id_lens):
     ids[b, :n] = pkg.synth_ids(1, int(n), ids_seed=70 + b)[0]
 glob = np.arange(6, dtype=np.int32)
+_, l0, _ = m.process_batch(ids, id_lengths=id_lens, noise_seed=9, noise_seed_offsets=glob, keep_pcm=False)
+order = np.argsort(-l0.astype(np.int64), kind="stable")  # rank 0 owns the three LONGEST utterances: the ranks' local maxima differ
+ids, id_lens, glob = ids[order], id_lens[order], glob[order].astype(np.int32)  # (an utterance's noise stream follows it: noise_seed_offsets)
 want, lengths, _ = m.process_batch(ids, id_lengths=id_lens, noise_seed=9, noise_seed_offsets=glob)  # every rank knows the whole answer
 lengths = lengths.astype(np.int64)
 mine = slice(rank * rows, (rank + 1) * rows)
@@ -80,7 +90,7 @@ def expect_failure(g, src, st, lens, needle):
 
 
 for eb, src, dtype in ((4, pcm, np.float32), (2, pcm16, np.int16)):
-    with pkg.PcmGather(uid, rank, world, rows, cap, eb) as g:
+    with pkg.PcmGather(fresh_uid(), rank, world, rows, cap, eb) as g:
         def good():
             data, st, all_len = g.gather(src, stride, lengths[mine])
             assert st == smax and np.array_equal(all_len, lengths), (st, smax, all_len, lengths)
@@ -105,7 +115,7 @@ for eb, src, dtype in ((4, pcm, np.float32), (2, pcm16, np.int16)):
             expect_failure(g, src, stride, lengths[mine], "rank 1")
         good()  # the object is still usable: failures were collective, the two ranks are in step
     # (D) ranks that disagree on row_capacity are told so, together
-    with pkg.PcmGather(uid, rank, world, rows, cap + rank, eb) as g2:
+    with pkg.PcmGather(fresh_uid(), rank, world, rows, cap + rank, eb) as g2:
         expect_failure(g2, src, stride, lengths[mine], "row_capacity")
 m.close()
 print("gather2 ok rank %d" % rank)

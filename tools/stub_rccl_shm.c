@@ -10,7 +10,8 @@
 #include <time.h>
 #include <unistd.h>
 typedef struct { char internal[128]; } ncclUniqueId;
-typedef struct { int rank, world; long seq; char dir[512]; } comm_t;
+typedef struct { int rank, world, index; long seq; char dir[512]; } comm_t;
+static int n_comms = 0; /* communicators are created in the same order on every rank: the index keeps their files apart */
 static void note(const char* what, int rank, long seq) {
     const char* path = getenv("STUB_RCCL_LOG");
     if (!path) return;
@@ -28,7 +29,7 @@ int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank) {
     const char* d = getenv("STUB_RCCL_DIR");
     if (!d) return 1;
     comm_t* c = (comm_t*)calloc(1, sizeof(comm_t));
-    c->rank = rank, c->world = nranks, c->seq = 0;
+    c->rank = rank, c->world = nranks, c->seq = 0, c->index = n_comms++;
     snprintf(c->dir, sizeof c->dir, "%s", d);
     *comm = c;
     note("init", rank, 0);
@@ -46,8 +47,8 @@ int ncclAllGather(const void* send, void* recv, size_t n, int dt, void* comm, vo
     char* host = (char*)malloc(n ? n : 1);
     if (hipMemcpy(host, send, n, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     char tmp[700], fin[700];
-    snprintf(tmp, sizeof tmp, "%s/ag_%ld_%d.tmp", c->dir, seq, c->rank);
-    snprintf(fin, sizeof fin, "%s/ag_%ld_%d", c->dir, seq, c->rank);
+    snprintf(tmp, sizeof tmp, "%s/ag_%d_%ld_%d.tmp", c->dir, c->index, seq, c->rank);
+    snprintf(fin, sizeof fin, "%s/ag_%d_%ld_%d", c->dir, c->index, seq, c->rank);
     FILE* f = fopen(tmp, "wb");
     if (!f) return 1;
     fwrite(&n, sizeof n, 1, f);
@@ -55,7 +56,7 @@ int ncclAllGather(const void* send, void* recv, size_t n, int dt, void* comm, vo
     fclose(f);
     if (rename(tmp, fin) != 0) return 1;
     for (int r = 0; r < c->world; ++r) {
-        snprintf(fin, sizeof fin, "%s/ag_%ld_%d", c->dir, seq, r);
+        snprintf(fin, sizeof fin, "%s/ag_%d_%ld_%d", c->dir, c->index, seq, r);
         const time_t t0 = time(NULL);
         FILE* g = NULL;
         while (!(g = fopen(fin, "rb"))) {
