@@ -239,3 +239,46 @@ def test_c_abi_pcm_gather_world_one_with_and_without_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gather_check.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "gather_check ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_latency_dds_kernels_are_bit_identical_to_the_throughput_path(pkg, full_bytes, monkeypatch):
+    """csrc/stage1_lat.hip (round 6): on small grids every DDS layer of the duration predictor runs on 16-token blocks with element-parallel
+    phases and 16 x 16 x 4 MFMA tiles, the conv flow's 1 -> H conv + conditioning / the predictor's first 1x1 conv inside the first layer's kernel and the
+    1x1 conv behind the block inside the last one's (vits.cpp:864,939,941,869). Every sum keeps the order of dds_layer_kernel + the separate launches
+    (VITS_NO_DDS_LAT=1): log-durations, durations and PCM must not move by a bit — batch 1 at the benchmark's length, token counts around the 16-token
+    tile (1, 15, 16, 17, 33), a ragged batch, both semantics modes, the emulated-ggml GELU table inside the kernels, and — VITS_DDS_LAT_MAX_BLOCKS raised — a
+    batch large enough that blocks of one launch retire before others start."""
+    cases = []
+    cases.append((pkg.synth_ids(1, 128), None))
+    Ts = [30, 1, 40, 3, 33, 15, 16, 17]
+    ids = np.zeros((len(Ts), 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = pkg.synth_ids(1, T, ids_seed=170 + b)[0]
+    cases.append((ids, np.array(Ts, np.int32)))
+    big = pkg.synth_ids(24, 300, ids_seed=99)
+    outs = {}
+    for lat in (True, False):
+        if not lat:
+            monkeypatch.setenv("VITS_NO_DDS_LAT", "1")
+        monkeypatch.setenv("VITS_DDS_LAT_MAX_BLOCKS", "100000")
+        with pkg.Model(full_bytes) as m:
+            for tables in (0, 2):
+                m.set_ggml_tables(tables)
+                for ci, (x, lens) in enumerate(cases):
+                    for mode in (pkg.MODE_REFERENCE, pkg.MODE_HF):
+                        pcm, lengths, frames = m.process_batch(x, id_lengths=lens, mode=mode, noise_seed=21, collect_taps=True)
+                        nb = 1 if lens is None else len(lens)
+                        outs[(lat, tables, ci, mode)] = (pcm, lengths, frames, np.concatenate([m.tap("log_duration", u) for u in range(nb)]),
+                                                         np.concatenate([m.tap("durations", u) for u in range(nb)]))
+            m.set_ggml_tables(0)
+            outs[(lat, "big")] = m.process_batch(big, noise_seed=5, frames_only=True)[2]
+    assert np.array_equal(outs[(True, "big")], outs[(False, "big")])
+    for key, a in outs.items():
+        if key[0] is not True or key[1] == "big":
+            continue
+        b_ = outs[(False,) + key[1:]]
+        assert np.array_equal(a[3], b_[3]), ("log_duration", key)
+        assert np.array_equal(a[4], b_[4]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2]), key
+        for x, y in zip(a[0], b_[0]):
+            assert np.array_equal(x, y), key

@@ -320,6 +320,19 @@ class Engine {
     bool load_dds(const ModelFile& f, const std::string& base, DdsW& d, std::string& err);
     hipError_t conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on = nullptr);  // on == nullptr: the main stream
     hipError_t run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p, const int* lens, int batch, int tmax, int64_t sum_t);
+    // The DDS block on the latency kernels (stage1_lat.hip) with the per-token ops around it fused in: the head (a conv flow's 1 -> H conv +
+    // conditioning, or an H -> H 1x1 conv of head_x) and the 1x1 conv behind the block (tail -> tail_y). Scratch a, b: [B][H][ts].
+    struct DdsEnds {
+        const float *head_w = nullptr, *head_b = nullptr;  // conv flow: pre weights / bias, latent z row zc, conditioning
+        TensorRef z, cond;
+        int zc = 0;
+        const PackedConv* head_conv = nullptr;  // or: 1x1 conv of head_x
+        TensorRef head_x;
+        const PackedConv* tail_conv = nullptr;
+        TensorRef tail_y;
+    };
+    bool dds_lat_ok(const DdsW& d, const DdsEnds& e, int batch, int tmax) const;
+    hipError_t run_dds_lat(const DdsW& d, const DdsEnds& e, TensorRef a, TensorRef b, const int* lens, int batch, int tmax, int64_t sum_t);
     void snapshot(const char* name, TensorRef t, int channels, int stride, int batch, const std::vector<int>& lens);
     void clear_taps();
     // the phases of one call (engine_stage1.cpp, engine_flow.cpp, engine_vocoder.cpp); each returns 0 or -1 with c.err set

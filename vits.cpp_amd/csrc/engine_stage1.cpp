@@ -46,6 +46,59 @@ hipError_t Engine::run_dds(const DdsW& d, TensorRef x, TensorRef y, TensorRef p,
     return hipSuccess;
 }
 
+// Small grids (batch 1, a few short utterances): every DDS layer on the 16-token latency kernel, the per-token ops in front of and behind the block
+// inside its first / last layer (stage1_lat.hip). Same floats as run_dds + the separate launches (tests/test_gpu_edge_and_scale.py).
+bool Engine::dds_lat_ok(const DdsW& d, const DdsEnds& e, int batch, int tmax) const {
+    if (knobs.kernel.no_dds_lat || knobs.no_dds_fuse || arith_now_ != VITS_ARITH_F32 || hp.dds_layers < 2) return false;
+    if ((int64_t)batch * ((tmax + 15) / 16) > knobs.kernel.dds_lat_max_blocks) return false;
+    for (int i = 0, dl = 1; i < hp.dds_layers; ++i, dl *= hp.dp_k)
+        if (!dds_layer_lat_supported(d.pw[i], hp.hidden, hp.dp_k, dl)) return false;
+    auto conv_ok = [&](const PackedConv* c, bool square) {
+        return !c || (c->cin == hp.hidden && c->kt == 1 && c->epi == EPI_STD && c->bias && c->wp_l16 && (square ? c->cout == hp.hidden : c->cout <= hp.hidden));
+    };
+    return conv_ok(e.head_conv, true) && conv_ok(e.tail_conv, false);
+}
+
+hipError_t Engine::run_dds_lat(const DdsW& d, const DdsEnds& e, TensorRef a, TensorRef b, const int* lens, int batch, int tmax, int64_t sum_t) {
+    const int H = hp.hidden, n = hp.dds_layers;
+    TensorRef src;
+    int dil = 1;
+    for (int i = 0; i < n; ++i) {
+        DdsLatCall c;
+        c.dw_w = d.dw_w[i], c.dw_b = d.dw_b[i], c.g1 = d.n1_g[i], c.b1 = d.n1_b[i], c.g2 = d.n2_g[i], c.b2 = d.n2_b[i];
+        c.pw = &d.pw[i];
+        c.lens = lens;
+        c.batch = batch, c.channels = H, c.tmax = tmax, c.k = hp.dp_k, c.dil = dil;
+        c.tabs = ggml_tabs_;
+        double flop = 2.0 * H * H * (double)sum_t, bytes = 8.0 * H * (double)sum_t + (double)d.pw[i].bytes;
+        if (i == 0) {
+            if (e.head_w) {
+                c.head_w = e.head_w, c.head_b = e.head_b, c.z = e.z, c.cond = e.cond, c.zc = e.zc;
+            } else if (e.head_conv) {
+                c.head_conv = e.head_conv, c.x = e.head_x;
+                flop += 2.0 * H * H * (double)sum_t;
+                bytes += (double)e.head_conv->bytes;
+            } else
+                c.x = e.head_x;
+        } else
+            c.x = src;
+        TensorRef dst = src.p == a.p ? b : a;
+        if (i == n - 1 && e.tail_conv) {
+            c.tail_conv = e.tail_conv, c.y2 = e.tail_y;
+            flop += 2.0 * e.tail_conv->cout * H * (double)sum_t;
+            bytes += (double)e.tail_conv->bytes;
+        } else
+            c.y = i == n - 1 ? e.tail_y : dst;
+        prof.begin("dds_layer_lat", flop, bytes, stream);
+        hipError_t err = launch_dds_layer_lat(c, stream);
+        prof.end(stream);
+        if (err != hipSuccess) return err;
+        src = dst;
+        dil *= hp.dp_k;
+    }
+    return hipSuccess;
+}
+
 int Engine::layout_stage_one(Call& c) {
     std::string& err = c.err;
     const vits_process_opts& o = c.o;
@@ -245,9 +298,17 @@ int Engine::run_duration_predictor(Call& c) {
     };
     c.rx.phase("vits.duration_predictor");
     TensorRef dpx = TR(s1.dpx, H, ts), dpy = TR(s1.dpy, H, ts), dpp = TR(s1.dpp, H, ts), cond = TR(s1.cond, H, ts), z = TR(s1.z, 2, ts), u = TR(s1.u, 32, ts);
-    HIP_OK(conv("conv1x1_dp", dp_pre_, mk(x, dpx, Tmax)));
-    HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax, sum_t));
-    HIP_OK(conv("conv1x1_dp", dp_proj_, mk(dpx, cond, Tmax)));
+    {
+        DdsEnds e;  // conv_pre (vits.cpp:939) -> DDS block -> conv_proj (:941): three launches on small grids
+        e.head_conv = &dp_pre_, e.head_x = x, e.tail_conv = &dp_proj_, e.tail_y = cond;
+        if (dds_lat_ok(dp_dds_, e, B, Tmax)) {
+            HIP_OK(run_dds_lat(dp_dds_, e, dpy, dpp, dl, B, Tmax, sum_t));
+        } else {
+            HIP_OK(conv("conv1x1_dp", dp_pre_, mk(x, dpx, Tmax)));
+            HIP_OK(run_dds(dp_dds_, dpx, dpy, dpp, dl, B, Tmax, sum_t));
+            HIP_OK(conv("conv1x1_dp", dp_proj_, mk(dpx, cond, Tmax)));
+        }
+    }
     std::vector<float> host_noise;
     if (o.noise_kind == VITS_NOISE_COUNTER) {
         prof.begin("noise_dur", 0, 0, stream);
@@ -305,12 +366,18 @@ int Engine::run_duration_predictor(Call& c) {
             prof.end(stream);
         } else {
             const DpFlowW& W = dp_flows_[fl - 1];
-            // conv_pre (1 -> H, vits.cpp:864) fused with "inputs + global_conditioning" of the DDS block (:651-653)
-            prof.begin("dp_flow_pre", 0, 0, stream);
-            HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream, arith_now_));
-            prof.end(stream);
-            HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax, sum_t));
-            HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
+            DdsEnds e;  // small grids: conv_pre + conditioning inside the first DDS layer's kernel, the projection inside the last one's
+            e.head_w = W.pre_w, e.head_b = W.pre_b, e.z = z, e.cond = cond, e.zc = c_first, e.tail_conv = &W.proj, e.tail_y = u;
+            if (dds_lat_ok(W.dds, e, B, Tmax)) {
+                HIP_OK(run_dds_lat(W.dds, e, dpx, dpp, dl, B, Tmax, sum_t));
+            } else {
+                // conv_pre (1 -> H, vits.cpp:864) fused with "inputs + global_conditioning" of the DDS block (:651-653)
+                prof.begin("dp_flow_pre", 0, 0, stream);
+                HIP_OK(launch_pointwise_from1(z, c_first, W.pre_w, W.pre_b, cond, dpy, dl, B, H, Tmax, stream, arith_now_));
+                prof.end(stream);
+                HIP_OK(run_dds(W.dds, dpy, dpx, dpp, dl, B, Tmax, sum_t));
+                HIP_OK(conv("conv1x1_dp", W.proj, mk(dpy, u, Tmax)));
+            }
             prof.begin("dp_spline", 0, 0, stream);
             HIP_OK(launch_spline(u, z, 1 - c_first, dl, B, Tmax, hp.dp_bins, hp.dp_tail, inv_sqrt, md, stream, ggml_tabs_));
             prof.end(stream);

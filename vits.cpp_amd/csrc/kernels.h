@@ -48,6 +48,8 @@ struct KernelKnobs {
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
     int rb16_narrow_max = 64;    // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never)
     int flow_narrow_max = 96;    // VITS_FLOW_NARROW_MAX: 16-bit coupling-layer kernel on 16-frame blocks while the 48-frame tile would give at most this many blocks (0: never)
+    bool no_dds_lat = false;     // VITS_NO_DDS_LAT: the duration predictor's DDS layers always on dds_layer_kernel (no 16-token latency kernel, no fused 1x1 convs around it)
+    int dds_lat_max_blocks = 96; // VITS_DDS_LAT_MAX_BLOCKS: the latency kernel is taken while batch x ceil(tokens / 16) is at most this
     bool no_lat16 = false;       // VITS_NO_LAT16: tiny grids with long K chains on the 128 x 32 tile of conv_mfma instead of conv_lat16_kernel
     int lat16_max_waves = 768;   // VITS_LAT16_MAX_WAVES: standard convs with at most this many 32 x 32 output tiles take conv_lat16_kernel (0: tiny grids only)
     static KernelKnobs from_env() {
@@ -57,6 +59,8 @@ struct KernelKnobs {
         };
         auto flag = [](const char* name, bool& v) { v = getenv(name) != nullptr; };
         num("VITS_NARROW_TILES", k.narrow_tiles);
+        flag("VITS_NO_DDS_LAT", k.no_dds_lat);
+        num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
         flag("VITS_NO_NARROW", k.no_narrow);
@@ -368,6 +372,26 @@ bool dds_layer_supported(const PackedConv& pw, int channels, int k, int dil, int
 hipError_t launch_dds_layer(TensorRef x, TensorRef y, const float* dw_w, const float* dw_b, const float* g1, const float* b1, const PackedConv& pw, const float* g2,
                             const float* b2, const int* lens, int batch, int channels, int tmax, int k, int dil, float eps, int arith, hipStream_t s,
                             GgmlTables tabs = GgmlTables());
+// The same layer for latency-bound launches (stage1_lat.hip: 16-token blocks, element-parallel phases, 16x16x4 MFMA tiles; bit-identical), optionally
+// with the per-token op in front of the DDS block fused in (head_w: the conv flow's 1 -> H conv of latent row zc + conditioning, vits.cpp:864,651-653;
+// head_conv: an H -> H 1x1 conv of x, vits.cpp:939) and the 1x1 conv behind it (tail_conv -> y2; y is then not written). fp32 arithmetic only.
+struct DdsLatCall {
+    TensorRef x, y;
+    const float *dw_w = nullptr, *dw_b = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    const PackedConv* pw = nullptr;
+    const float *head_w = nullptr, *head_b = nullptr;
+    TensorRef z, cond;
+    int zc = 0;
+    const PackedConv* head_conv = nullptr;
+    const PackedConv* tail_conv = nullptr;
+    TensorRef y2;
+    const int* lens = nullptr;
+    int batch = 1, channels = 0, tmax = 0, k = 3, dil = 1;
+    float eps = 1e-5f;
+    GgmlTables tabs;
+};
+bool dds_layer_lat_supported(const PackedConv& pw, int channels, int k, int dil);
+hipError_t launch_dds_layer_lat(const DdsLatCall& c, hipStream_t s);
 hipError_t launch_pointwise_from1(TensorRef z, int zc, const float* w, const float* bias, TensorRef cond, TensorRef y, const int* lens, int batch,
                                   int channels, int tmax, hipStream_t s, int arith = 0);
 hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int batch, int tmax, int bins, float tail, float inv_sqrt, int mode,

@@ -1363,29 +1363,47 @@ __device__ __forceinline__ float spline_row(float x, const float* ub, int u_cs, 
 template <int NT, bool TAB>
 __global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs, int u_cs, float* z, int64_t z_bs, int z_cs, int zc, const int* lens, int tmax,
                                                       int nb, float B, float inv_sqrt, int mode, const uint16_t* exp_tab) {
-    extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance
+    extern __shared__ float spline_lds[];  // [3][tpad]: masked input, spline result, inside flag of every token of the utterance; then [3 nb - 1][blockDim] parameters
     const int b = blockIdx.x;
     const int len = lens ? lens[b] : tmax;
     const int tpad = (tmax + 63) & ~63;
     float* s_val = spline_lds;
     float* s_res = spline_lds + tpad;
     int* s_in = reinterpret_cast<int*>(spline_lds + 2 * tpad);
+    float* s_u = spline_lds + 3 * tpad;  // the parameters of the block's current chunk of tokens, [3 nb - 1][nthr]
     float* zrow = z + (int64_t)b * z_bs + (int64_t)zc * z_cs;
     const bool ref = mode == VITS_MODE_REFERENCE;
     int any_outside = 0;
-    for (int t = threadIdx.x; t < len; t += blockDim.x) {
-        const float x = zrow[t];
-        const bool inside = x >= -B && x <= B;
-        const float* ub = u + (int64_t)b * u_bs + t;
-        float r = x;  // HF: identity outside the interval (HF:143-151)
-        if (inside || ref) r = spline_row<TAB>(inside ? x : 0.f, ub, u_cs, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside, exp_tab);
-        if (ref) {
-            s_val[t] = inside ? x : 0.f;  // tensor_masked_get(inputs, inside_interval_mask): the shape is kept
-            s_res[t] = r;
-            s_in[t] = inside ? 1 : 0;
-            any_outside |= inside ? 0 : 1;
-        } else {
-            zrow[t] = r;
+    // A token's 3 nb - 1 parameters are 3 nb - 1 rows of u, one cache line each per token: read through the pointer inside spline_row they were four
+    // dependent rounds of strided loads (16 us per launch at 128 tokens, most of it memory latency). The block stages them chunk by chunk with
+    // coalesced loads, all rows in flight at once; the values — and every operation on them — are the same.
+    const int nthr = (int)blockDim.x, nrow = 3 * nb - 1;
+    for (int c0 = 0; c0 < len; c0 += nthr) {
+        const int t = c0 + (int)threadIdx.x;
+        {
+            const float* ub = u + (int64_t)b * u_bs + (t < len ? t : len - 1);
+            float v[3 * MAX_BINS - 1];
+#pragma unroll
+            for (int r = 0; r < 3 * MAX_BINS - 1; ++r) v[r] = r < nrow ? ub[(int64_t)r * u_cs] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 3 * MAX_BINS - 1; ++r)
+                if (r < nrow) s_u[r * nthr + threadIdx.x] = v[r];
+        }
+        // (each thread reads back only what it wrote: no barrier needed)
+        if (t < len) {
+            const float x = zrow[t];
+            const bool inside = x >= -B && x <= B;
+            const float* ub = s_u + threadIdx.x;
+            float r = x;  // HF: identity outside the interval (HF:143-151)
+            if (inside || ref) r = spline_row<TAB>(inside ? x : 0.f, ub, nthr, nb, B, inv_sqrt, mode, ref && t == len - 1, !inside, exp_tab);
+            if (ref) {
+                s_val[t] = inside ? x : 0.f;  // tensor_masked_get(inputs, inside_interval_mask): the shape is kept
+                s_res[t] = r;
+                s_in[t] = inside ? 1 : 0;
+                any_outside |= inside ? 0 : 1;
+            } else {
+                zrow[t] = r;
+            }
         }
     }
     if (!ref) return;
@@ -1398,7 +1416,7 @@ __global__ __launch_bounds__(NT) void spline_kernel(const float* u, int64_t u_bs
     // nout(t) = outside tokens before t: every thread counts a contiguous chunk, one thread scans the per-thread counts (the
     // first version let every thread count from token 0: O(T^2) LDS reads per utterance)
     __shared__ int s_part[NT];
-    const int nthr = (int)blockDim.x, per = (len + nthr - 1) / nthr;
+    const int per = (len + nthr - 1) / nthr;
     const int beg = min((int)threadIdx.x * per, len), end = min(beg + per, len);
     int cnt = 0;
     for (int t = beg; t < end; ++t) cnt += 1 - s_in[t];
@@ -1427,8 +1445,16 @@ hipError_t launch_spline(TensorRef u, TensorRef z, int zc, const int* lens, int 
     // 512 threads: one token per thread up to 512 tokens, two rounds for 1024-id inputs (a 1024-thread build is capped at 128 VGPRs and spills
     // the bin arrays: 74 us per launch against 32 at 8 x 1024 ids)
 #define VITS_SPLINE_LAUNCH(NT, TAB)                                                                                                                 \
-    VITS_KLAUNCH((spline_kernel<NT, TAB>), dim3(batch), dim3(tpad < NT ? tpad : NT), (size_t)3 * tpad * sizeof(float), s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, \
-                 tmax, bins, tail, inv_sqrt, mode, tabs.exp)
+    do {                                                                                                                                            \
+        const size_t lds_ = ((size_t)3 * tpad + (size_t)(3 * bins - 1) * (tpad < NT ? tpad : NT)) * sizeof(float);                                  \
+        static BigLdsOnce big;                                                                                                                      \
+        if (lds_ > 64 * 1024 && big.needed()) {                                                                                                     \
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_kernel<NT, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)) return e; /* (+ the kernel's static s_part) */ \
+            big.done();                                                                                                                             \
+        }                                                                                                                                           \
+        VITS_KLAUNCH((spline_kernel<NT, TAB>), dim3(batch), dim3(tpad < NT ? tpad : NT), lds_, s, u.p, u.bs, u.cs, z.p, z.bs, z.cs, zc, lens, tmax, bins, tail, inv_sqrt, \
+                     mode, tabs.exp);                                                                                                               \
+    } while (0)
     if (tabs.exp) {
         VITS_SPLINE_LAUNCH(512, true);
     } else {
