@@ -282,3 +282,36 @@ def test_latency_dds_kernels_are_bit_identical_to_the_throughput_path(pkg, full_
         assert np.array_equal(a[4], b_[4]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2]), key
         for x, y in zip(a[0], b_[0]):
             assert np.array_equal(x, y), key
+
+
+@pytest.mark.gpu
+def test_layer_norm_on_load_is_bit_identical_to_the_separate_launch(pkg, full_bytes, monkeypatch):
+    """conv_mfma.hip conv_lat16_kernel with ConvCall::ln_gamma (round 6): on tiny grids the text encoder's twelve add + norm nodes (vits.cpp:365-372,412-418)
+    are applied ON LOAD by the conv that consumes them (QKV of the next layer, the first FFN conv, the prior projection) in add_layer_norm_kernel's order of
+    operations, the normalised tensor written back by the conv's first row group (it is the next residual). Against VITS_NO_LN_FUSE=1: encoder output, prior
+    statistics, log-durations, durations and PCM bit for bit — batch 1 at the benchmark's length, token counts around the 16-column tile, a ragged batch, both modes."""
+    Ts = [30, 1, 40, 3, 33, 15, 16, 17]
+    ids = np.zeros((len(Ts), 40), np.int32)
+    for b, T in enumerate(Ts):
+        ids[b, :T] = pkg.synth_ids(1, T, ids_seed=270 + b)[0]
+    cases = [(pkg.synth_ids(1, 128), None), (ids, np.array(Ts, np.int32)), (pkg.synth_ids(1, 257, ids_seed=3), None)]
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("VITS_NO_LN_FUSE", "1")
+        with pkg.Model(full_bytes) as m:
+            for ci, (x, lens) in enumerate(cases):
+                for mode in (pkg.MODE_REFERENCE, pkg.MODE_HF):
+                    pcm, lengths, frames = m.process_batch(x, id_lengths=lens, mode=mode, noise_seed=31, collect_taps=True)
+                    nb = 1 if lens is None else len(lens)
+                    taps = {n: np.concatenate([m.tap(n, u) for u in range(nb)]) for n in ("enc_out", "prior_mean", "prior_logvar", "log_duration", "durations")}
+                    outs[(fused, ci, mode)] = (pcm, lengths, frames, taps)
+    for key, a in outs.items():
+        if not key[0]:
+            continue
+        b_ = outs[(False,) + key[1:]]
+        for n in a[3]:
+            assert np.array_equal(a[3][n], b_[3][n]), (n, key)
+        assert np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2]), key
+        for x, y in zip(a[0], b_[0]):
+            assert np.array_equal(x, y), key

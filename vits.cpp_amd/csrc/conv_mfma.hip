@@ -79,6 +79,12 @@ struct ConvParams {
     int kt_rt;  // taps (the latency kernel below takes them at run time; every other kernel has them as a template parameter)
     const float* wl16;  // conv_lat16_kernel's A fragments
     int l16_fill4;      // conv_lat16_kernel: rows 16-byte aligned -> float4 fill
+    // conv_lat16_kernel: LayerNorm over the input channels on load (ConvCall::ln_gamma)
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    float* ln_out;
+    int64_t lo_bs;
+    int lo_cs;
 };
 
 // DIL > 0 (or < 0 for the transposed conv): compile-time dilation -> the LDS row stride and every tap offset are
@@ -1075,6 +1081,15 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     float4 ar[R];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) ar[i] = load_q(i);  // (in front of the fill: one memory latency for both)
+    float lng[3], lnb[3];  // LayerNorm on load: this thread's share of gamma / beta (c_in <= 768), requested with everything else
+    if (p.ln_gamma) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = tid + 256 * u;
+            lng[u] = c < p.cin ? p.ln_gamma[c] : 0.f;
+            lnb[u] = c < p.cin ? p.ln_beta[c] : 0.f;
+        }
+    }
     // ---- fill. 16-byte aligned rows (the engine's arenas): the 24 floats from the 4-aligned time below tile_start as six float4 per row,
     // ten rows per wave instruction, every load of a thread in flight at once; LDS column 0 = that aligned time, the B operands are read
     // `shift` floats further right (launch_lat16 sizes the pitch for it). Otherwise element by element.
@@ -1138,6 +1153,85 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     }
     L16_STAMP(2);
     __syncthreads();
+    if (p.ln_gamma) {
+        // LayerNorm over the channels of every column of the tile that lies inside the sequence, in place (the encoder's add + norm nodes, vits.cpp:365-372,
+        // 412-418, were a launch of add_layer_norm_kernel in front of this conv: 7 us for microseconds of work at batch 1). Same order of operations as that
+        // kernel: sixteen channel groups, group g sums channels g, g + 16, ... in ascending order, the groups are combined in ascending order; variance the
+        // same way around the mean; (v - mean) * inv * gamma + beta. Columns outside the sequence stay zero (the conv's padding).
+        float* red = xs + ((size_t)p.nchunks + 1) * CK * P;  // [2][16][32] partial sums of up to 32 columns, then gamma[C], beta[C]
+        float* gb = red + 2 * 16 * 32;
+        const int C = p.cin;
+        const int ncol = 16 + (KT - 1) * dil;  // the columns the K loop reads: LDS columns shift .. shift + ncol - 1 (<= 32: conv_ln_on_load_ok)
+        const int tc0 = tile_start;            // time of the first of them
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {  // (the two parameter vectors once, into LDS: a load per element in the last pass was 18 exposed round trips)
+            const int c = tid + 256 * u;
+            if (c < C) gb[c] = lng[u], gb[C + c] = lnb[u];
+        }
+        // thread (g = tid / 16, jj = tid % 16): channel group g of column jj — and of column jj + 16 where the tile has one (a 3-tap conv: two of them)
+        const int g = tid >> 4, jj = tid & 15;
+        const int ncs = jj + 16 < ncol ? 2 : 1;
+        const float* colp = xs + shift + jj;
+        for (int u = 0; u < ncs; ++u) {
+            float s = 0.f;
+#pragma unroll 12
+            for (int c = g; c < C; c += 16) s += colp[c * P + 16 * u];
+            red[g * 32 + jj + 16 * u] = s;
+        }
+        __syncthreads();
+        float mean[2], inv[2];
+        for (int u = 0; u < ncs; ++u) {
+            float msum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) msum += red[q * 32 + jj + 16 * u];
+            mean[u] = msum / (float)C;
+            float vs = 0.f;
+#pragma unroll 12
+            for (int c = g; c < C; c += 16) {
+                const float d = colp[c * P + 16 * u] - mean[u];
+                vs += d * d;
+            }
+            red[(16 + g) * 32 + jj + 16 * u] = vs;
+        }
+        __syncthreads();
+        const bool writer = blockIdx.y == 0;
+        float* lob = p.ln_out + (int64_t)b * p.lo_bs;
+        for (int u = 0; u < ncs; ++u) {
+            float vsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vsum += red[(16 + q) * 32 + jj + 16 * u];
+            const float var = vsum / (float)C;
+            inv[u] = 1.0f / sqrtf(var + p.ln_eps);
+        }
+        if (ncs > 1) {  // the (few) columns past the sixteenth: their statistics to LDS, their elements are normalised by the whole block below
+            if (g == 0) red[jj + 16] = mean[1], red[32 + jj + 16] = inv[1];
+        }
+        {
+            const int tt = tc0 + jj;
+            if (tt >= 0 && tt < len_in) {  // (outside the sequence: the conv's zero padding stays)
+                float* cp = xs + shift + jj;
+#pragma unroll 12
+                for (int c = g; c < C; c += 16) {
+                    const float v = (cp[c * P] - mean[0]) * inv[0] * gb[c] + gb[C + c];
+                    cp[c * P] = v;
+                    if (writer && tt >= t0 && tt < t0 + 16) lob[(int64_t)c * p.lo_cs + tt] = v;
+                }
+            }
+        }
+        if (ncol > 16) {
+            __syncthreads();  // (block-uniform: ncol is)
+            const int nx = ncol - 16;
+            for (int idx = tid; idx < C * nx; idx += 256) {
+                const int c = idx / nx, j = 16 + idx - c * nx, tt = tc0 + j;
+                if (tt < 0 || tt >= len_in) continue;
+                float* e = xs + c * P + shift + j;
+                const float v = (*e - red[j]) * red[32 + j] * gb[c] + gb[C + c];
+                *e = v;
+                if (writer && tt >= t0 && tt < t0 + 16) lob[(int64_t)c * p.lo_cs + tt] = v;  // (a left pad puts the block's last own column(s) here)
+            }
+        }
+        __syncthreads();
+    }
     L16_STAMP(3);
     typedef const volatile __attribute__((address_space(3))) float* LdsVF;
     LdsVF xl = (LdsVF)(xs + jg * P + col + shift);
@@ -1238,7 +1332,8 @@ static hipError_t launch_lat16(const PackedConv& w, const ConvParams& p0, int nc
     p.xw = pitch;
     p.kt_rt = w.kt;
     p.wl16 = w.wp_l16;
-    const size_t lds = ((size_t)w.nchunks + 1) * CK * pitch * sizeof(float);  // (+ one chunk of slack rows: the look-ahead of the last tap)
+    size_t lds = ((size_t)w.nchunks + 1) * CK * pitch * sizeof(float);  // (+ one chunk of slack rows: the look-ahead of the last tap)
+    if (p.ln_gamma) lds += ((size_t)2 * 16 * 32 + 2 * (size_t)w.cin) * sizeof(float);  // LayerNorm on load: partial sums of up to 32 columns; gamma, beta
     dim3 grid((ncols_max + 15) / 16, (w.mtiles_used + 1) / 2, batch);
 #define VITS_L16(E, PP)                                                                                                                          \
     do {                                                                                                                                         \
@@ -1619,6 +1714,12 @@ hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, Co
     p.kt_rt = w.kt;
     p.wl16 = w.wp_l16;
     p.l16_fill4 = 0;
+    p.ln_gamma = c.ln_gamma;
+    p.ln_beta = c.ln_beta;
+    p.ln_eps = c.ln_eps;
+    p.ln_out = c.ln_out.p;
+    p.lo_bs = c.ln_out.bs;
+    p.lo_cs = c.ln_out.cs;
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     const TileShape ts = tile_shape(tile);
     const int bn = ts.wn * ts.nr * 32;
@@ -1654,11 +1755,22 @@ hipError_t make_conv_params(const PackedConv& w, const ConvCall& c, int tile, Co
     return hipSuccess;
 }
 
+// LayerNorm on load exists in conv_lat16_kernel only (the launches it pays for are the latency-bound ones): a standard conv without an input activation
+// whose tile choice is TILE_LAT16, with the statistics' scratch beside the input tile in LDS, and the input lengths = the output lengths (padded 'same' conv)
+bool conv_ln_on_load_ok(const PackedConv& w, const ConvCall& c) {
+    if (w.epi != EPI_STD || c.pre_act || !w.wp_l16 || c.len_in != c.len_out || c.t_in != c.t_out) return false;
+    if (resolve_conv_tile(w, c) != TILE_LAT16) return false;
+    const int span = (w.kt - 1) * (w.kt == 1 ? 1 : c.dil);
+    const int pitch = lat16_pitch(span);
+    return pitch && span <= 16 && (((size_t)w.nchunks + 1) * CK * pitch + 2 * 16 * 32 + 2 * (size_t)w.cin) * sizeof(float) <= 150 * 1024;
+}
+
 hipError_t launch_conv(const PackedConv& w, const ConvCall& c, hipStream_t s) {
     ConvParams p;
     const int ncols_max = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
     const int tile = resolve_conv_tile(w, c);
     if (hipError_t e = make_conv_params(w, c, tile, p)) return e;
+    if (c.ln_gamma && (tile != TILE_LAT16 || !c.ln_beta || !c.ln_out.p || !conv_ln_on_load_ok(w, c))) return hipErrorInvalidValue;
     if (tile == TILE_LAT16) return launch_lat16(w, p, ncols_max, c.batch, s);
     const int span = (w.kt - 1) * p.dil;  // signed extent of the taps
     if ((span < 0 ? -span : span) > 64) return hipErrorInvalidValue;  // generic kernels stage at most BN + 64 columns

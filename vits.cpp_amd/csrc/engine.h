@@ -120,7 +120,8 @@ struct UpStageW {
 // not thread-safe against setenv, and a per-layer lookup is host time inside the caller's timed region). INTEGRATION.md §9.
 struct Knobs {
     int rb_streams = 3;          // VITS_RB_STREAMS (1 serialises the three resblocks of a stage on the main stream)
-    int rb16_serial_max_frames = 1300;  // VITS_RB16_SERIAL_MAX_FRAMES: 16-bit vocoder windows of at most this many frames (all utterances) use one stream
+    int rb16_serial_max_frames = 1300;  // VITS_RB16_SERIAL_MAX_FRAMES: 16-bit vocoder windows of at most this many frames (all utterances) use one stream ...
+    int rb16_serial_min_frames = 600;   // VITS_RB16_SERIAL_MIN_FRAMES: ... unless they have fewer than this (one or two 128-id utterances: kernels of 15-60 blocks, three of which side by side fill more of the chip than the fork / join costs — round 6, batch 1 / 2 / 4: 1.70 -> 1.60 / 1.77 -> 1.71 / 2.09 -> 2.17 ms with three streams)
     int lrelu_copy_minc = 128;   // VITS_LRELU_COPY_MINC: stages at least this wide also store leaky_relu(y)
     bool no_dds_fuse = false;    // VITS_NO_DDS_FUSE: DDS layer as three launches
     bool no_wn_fuse = false;     // VITS_NO_WN_FUSE: WaveNet layer as two launches

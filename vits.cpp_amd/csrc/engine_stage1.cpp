@@ -231,9 +231,37 @@ int Engine::run_text_encoder(Call& c) {
     HIP_OK(launch_embed(s1.ids, id_stride, dl, emb_, H, (float)std::sqrt((double)H), x, B, Tmax, stream));
     prof.end(stream);
     const float q_scale = (float)std::pow((double)hd, -0.5);
+    // A LayerNorm whose only consumer is a conv that will run on conv_lat16_kernel (tiny grids: batch 1, a few short utterances) is applied by that conv
+    // ON LOAD (ConvCall::ln_gamma: same order of operations, the normalised tensor written to x by the conv's first row group) instead of being a launch of
+    // its own: 12 of the text encoder's 43 launches at batch 1. `pending`: tmp holds a sum that still awaits its norm.
+    struct PendingLn {
+        const float *g = nullptr, *b = nullptr;
+    } pending;
+    auto norm_now = [&]() -> hipError_t {  // the separate launch: tmp -> x
+        prof.begin("layer_norm", 0, 0, stream);
+        hipError_t e = launch_add_layer_norm(tmp, none, pending.g, pending.b, x, dl, B, H, Tmax, hp.ln_eps, 0, none, stream);
+        prof.end(stream);
+        pending = PendingLn();
+        return e;
+    };
+    // conv of LN(tmp) (or of x when nothing is pending); leaves the normalised tensor in x either way
+    auto conv_of_norm = [&](const char* label, const PackedConv& w, ConvCall cc) -> hipError_t {
+        if (pending.g) {
+            ConvCall fused = cc;
+            fused.x = tmp;
+            fused.ln_gamma = pending.g, fused.ln_beta = pending.b, fused.ln_eps = hp.ln_eps, fused.ln_out = x;
+            if (!knobs.kernel.no_ln_fuse && arith_now_ == VITS_ARITH_F32 && conv_ln_on_load_ok(w, fused)) {
+                pending = PendingLn();
+                return conv(label, w, fused);
+            }
+            if (hipError_t e = norm_now()) return e;
+        }
+        cc.x = x;
+        return conv(label, w, cc);
+    };
     for (int l = 0; l < hp.layers; ++l) {
         const EncoderLayerW& L = enc_[l];
-        HIP_OK(conv("enc_qkv_gemm", L.qkv, mk(x, qkv, Tmax)));
+        HIP_OK(conv_of_norm("enc_qkv_gemm", L.qkv, mk(x, qkv, Tmax)));
         prof.begin("rel_attention", 0, 0, stream);
         HIP_OK(launch_rel_attention(sub(qkv, 0), sub(qkv, H), sub(qkv, 2 * H), L.rel_k, L.rel_v, att, dl, B, heads, hd, Tmax, hp.window, q_scale, stream, ggml_tabs_));
         prof.end(stream);
@@ -242,14 +270,12 @@ int Engine::run_text_encoder(Call& c) {
             c.res = x;  // residual + attention output (vits.cpp:367)
             HIP_OK(conv("enc_out_gemm", L.out, c));
         }
-        prof.begin("layer_norm", 0, 0, stream);
-        HIP_OK(launch_add_layer_norm(tmp, none, L.ln1_g, L.ln1_b, x, dl, B, H, Tmax, hp.ln_eps, 0, none, stream));
-        prof.end(stream);
+        pending.g = L.ln1_g, pending.b = L.ln1_b;  // :365-372
         {
             ConvCall c = mk(x, ffn, Tmax);
             c.pad_l = (hp.ffn_k - 1) / 2;  // vits.cpp:388
             c.post_act = 1;                // relu :397
-            HIP_OK(conv("enc_ffn_conv", L.ffn1, c));
+            HIP_OK(conv_of_norm("enc_ffn_conv", L.ffn1, c));
         }
         {
             ConvCall c = mk(ffn, tmp, Tmax);
@@ -257,12 +283,10 @@ int Engine::run_text_encoder(Call& c) {
             c.res = x;  // :416
             HIP_OK(conv("enc_ffn_conv", L.ffn2, c));
         }
-        prof.begin("layer_norm", 0, 0, stream);
-        HIP_OK(launch_add_layer_norm(tmp, none, L.ln2_g, L.ln2_b, x, dl, B, H, Tmax, hp.ln_eps, 0, none, stream));
-        prof.end(stream);
+        pending.g = L.ln2_g, pending.b = L.ln2_b;  // :412-418
     }
     TensorRef stats = TR(s1.stats, 2 * F, ts);
-    HIP_OK(conv("enc_project", enc_proj_, mk(x, stats, Tmax)));  // :429 ; split :436 = channel ranges [0,F) and [F,2F)
+    HIP_OK(conv_of_norm("enc_project", enc_proj_, mk(x, stats, Tmax)));  // :429 ; split :436 = channel ranges [0,F) and [F,2F)
     if (o.collect_taps) {
         snapshot("enc_out", x, H, Tmax, B, tlen);
         snapshot("prior_mean", sub(stats, 0), F, Tmax, B, tlen);

@@ -108,7 +108,7 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         }
         // (small windows — up to four 128-id utterances — run the three resblocks one behind the other: a fork and a join cost ~11 us each per
         // stage, more than the overlap of these short kernels returns: f16 batch 4 2.33 -> 2.18 ms, batch 1 -1 %; from batch 8 on three streams win)
-        const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on && w.ssum[0] > knobs.rb16_serial_max_frames;
+        const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on && (w.ssum[0] > knobs.rb16_serial_max_frames || w.ssum[0] < knobs.rb16_serial_min_frames);
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));

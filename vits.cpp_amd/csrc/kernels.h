@@ -46,8 +46,9 @@ struct KernelKnobs {
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
     int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
-    int rb16_narrow_max = 64;    // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never)
+    int rb16_narrow_max = 128;   // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never; 64 until round 6: batch 4 / 6 -1 ... -2 % with 128)
     int flow_narrow_max = 96;    // VITS_FLOW_NARROW_MAX: 16-bit coupling-layer kernel on 16-frame blocks while the 48-frame tile would give at most this many blocks (0: never)
+    bool no_ln_fuse = false;     // VITS_NO_LN_FUSE: the encoder's LayerNorms always as their own launches (never applied on load by the consuming conv_lat16_kernel)
     bool no_dds_lat = false;     // VITS_NO_DDS_LAT: the duration predictor's DDS layers always on dds_layer_kernel (no 16-token latency kernel, no fused 1x1 convs around it)
     int dds_lat_max_blocks = 96; // VITS_DDS_LAT_MAX_BLOCKS: the latency kernel is taken while batch x ceil(tokens / 16) is at most this
     bool no_lat16 = false;       // VITS_NO_LAT16: tiny grids with long K chains on the 128 x 32 tile of conv_mfma instead of conv_lat16_kernel
@@ -60,6 +61,7 @@ struct KernelKnobs {
         auto flag = [](const char* name, bool& v) { v = getenv(name) != nullptr; };
         num("VITS_NARROW_TILES", k.narrow_tiles);
         flag("VITS_NO_DDS_LAT", k.no_dds_lat);
+        flag("VITS_NO_LN_FUSE", k.no_ln_fuse);
         num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
@@ -208,7 +210,14 @@ struct ConvCall {
     int scale_div = 0;
     int ct_crop = 0;  // EPI_CONVT: output crop
     int tile = -1;    // ConvTile override (-1: chosen from the shape)
+    // LayerNorm over the input channels applied ON LOAD (round 6; conv_lat16_kernel only — conv_ln_on_load_ok() tells, launch_conv refuses otherwise):
+    // x is the UN-normalised tensor (add_layer_norm_kernel's input), every block normalises the columns of its input tile in that kernel's order of
+    // operations, and ln_out (any layout) receives the normalised tensor — each column written once, by the blocks of the first row group.
+    const float *ln_gamma = nullptr, *ln_beta = nullptr;
+    float ln_eps = 0.f;
+    TensorRef ln_out;
 };
+bool conv_ln_on_load_ok(const PackedConv& w, const ConvCall& c);
 
 // host-side packing: w is torch layout [cout][cin][k] (EPI_STD / EPI_GATE) or [cin][cout][k] (EPI_CONVT)
 std::vector<float> pack_conv_weights(const float* w, int cout, int cin, int k, int epi, int ct_stride, int* rows, int* mtiles_used, int* mtiles,

@@ -554,6 +554,9 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
             dim3 gridm((tmax + ATT_Q - 1) / ATT_Q, heads, batch);
             const int nw_env = kernel_knobs().att_nw;
             int nw = 2 * ldsm > 160 * 1024 ? 8 : 4;
+            // latency-bound launches (at most 128 blocks: up to eight 128-token utterances): eight waves deal the key tiles and the d tiles out one per wave
+            // (per-block stamps at 128 tokens, tools/att_micro.hip: P V 5.0 -> 3.0 us, block life 15.2 -> 13.9; batch 1 / 2 / 4 / 8: -1 ... -3 % per call, round 6)
+            if ((int64_t)gridm.x * gridm.y * gridm.z <= 128) nw = 8;
             if (nw_env == 4 || nw_env == 8) nw = nw_env;
 #define VITS_ATTM_LAUNCH(NW, MS, SH)                                                                                                                   \
     do {                                                                                                                                         \
