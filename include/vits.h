@@ -94,12 +94,19 @@ VITS_API int vits_model_get_mode(const vits_model* model);
  *   VITS_ARITH_F16: the literal Q7 arithmetic: conv inputs rounded to fp16 (round-to-nearest-even) where the tile is staged,
  *     fp16 weights, fp32 accumulation on v_mfma_f32_32x32x16_f16.
  *   VITS_ARITH_BF16: the same with bf16 operands (BASELINE.json configs[4]: bf16 weights) on v_mfma_f32_32x32x16_bf16.
+ *   VITS_ARITH_F32_SPLIT (round 6, opt-in): fp32-ACCURATE results on the bf16 matrix cores. The ResBlock convolutions of the vocoder's wide stages
+ *     (C >= 128: 64 % of the path's FLOPs) take their fp16-valued weights as the exact sum of two bf16 values and their fp32 activations as the exact sum of
+ *     three, and accumulate the five significant cross products in fp32 (csrc/conv_split.hip): the same accuracy against the exact sum as the fp32 fmaf
+ *     chain (measured, tools/split_micro.hip), at 1.8x its matrix-core rate — but NOT the same bits (another summation order), so "batch 1 == row of a
+ *     batch, bit for bit" is asserted for VITS_ARITH_F32 only. Everything else, stage one included (durations bit-exact), is the VITS_ARITH_F32 path.
+ *     The scope setting does not apply. Weights that are not exactly two bf16 pieces (an fp32-stored conv) keep the fp32 kernels.
  * 16-bit modes apply to the Conv1d / ConvTranspose1d of the scope chosen with vits_model_set_arith_scope (never to the Linear
  * layers q/k/v/out, which are ggml_mul_mat on f32 x f32 in the reference, vits.cpp:287-289,358); everything else (layer norms,
  * attention softmax, splines, gates, residual adds, accumulators) stays fp32. Set between calls, not during one. */
 #define VITS_ARITH_F32 0
 #define VITS_ARITH_BF16 1
 #define VITS_ARITH_F16 2
+#define VITS_ARITH_F32_SPLIT 3
 VITS_API int vits_model_set_arith(vits_model* model, int arith);
 VITS_API int vits_model_get_arith(const vits_model* model);
 /* Which convolutions a 16-bit arithmetic mode applies to.

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("VITS_HIP_LIB", os.path.join(_HERE, "csrc", "libvits_h
 MODE_DEFAULT, MODE_REFERENCE, MODE_HF = -1, 0, 1
 NOISE_REFERENCE, NOISE_COUNTER, NOISE_EXPLICIT = 0, 1, 2
 SYNTH_FULL, SYNTH_TINY, SYNTH_BF16 = 0, 1, 0x100
-ARITH_F32, ARITH_BF16, ARITH_F16 = 0, 1, 2
+ARITH_F32, ARITH_BF16, ARITH_F16, ARITH_F32_SPLIT = 0, 1, 2, 3
 SCOPE_FLOW_VOCODER, SCOPE_ALL_CONVS = 0, 1
 
 #: every symbol include/vits.h declares (checked by tests/test_abi.py)

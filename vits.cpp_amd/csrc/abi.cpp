@@ -176,7 +176,7 @@ VITS_API int vits_model_get_mode(const vits_model* model) { return model ? model
 VITS_API void vits_reference_noise_seed(uint32_t seed) { vits::reference_noise_seed(seed); }
 VITS_API int vits_model_set_arith(vits_model* model, int arith) {
     VITS_TRY
-    if (!model || (arith != VITS_ARITH_F32 && arith != VITS_ARITH_BF16 && arith != VITS_ARITH_F16)) {
+    if (!model || (arith != VITS_ARITH_F32 && arith != VITS_ARITH_BF16 && arith != VITS_ARITH_F16 && arith != VITS_ARITH_F32_SPLIT)) {
         set_err("bad arithmetic mode");
         return -1;
     }

@@ -71,6 +71,19 @@ hipError_t Engine::conv16_transparent(const char* name, const PackedConv& w, con
 
 hipError_t Engine::conv(const char* name, const PackedConv& w, ConvCall c, hipStream_t on) {
     hipStream_t stream = on ? on : this->stream;
+    if (c.xs3.p) {
+        // VITS_ARITH_F32_SPLIT: a conv whose input exists as split planes (the wide stages' resblocks, engine_vocoder.cpp) runs on conv_split.hip
+        if (prof.on) {
+            char full[160];
+            std::snprintf(full, sizeof(full), "%s|k%d|d%d|S128|e0|c%dx%d", name, w.kt, c.dil, w.cin, w.cout);
+            const int64_t tot = c.sum_out >= 0 ? c.sum_out : (int64_t)c.batch * c.t_out;
+            const double bytes = (double)tot * (6.0 * w.cin + (double)w.cout * (4.0 * ((c.y.p ? 1 : 0) + (c.res.p ? 1 : 0) + (c.acc.p ? 1 : 0)) + (c.ys3.p ? 6.0 : 0.0))) + (double)w.bytes_s;
+            prof.begin(full, conv_flops(w, c, tot), bytes, stream, /*chain=*/true);
+        }
+        hipError_t e = launch_conv_split(w, c, stream);
+        prof.end(stream);
+        return e;
+    }
     if (arith_now_ != VITS_ARITH_F32 && w.wp16) return conv16_transparent(name, w, c, stream);
     if (prof.on) {
         // name = label|k<taps>|d<dilation>|t<tile>|e<epilogue>|c<cin>x<cout>: one entry per kernel instantiation and shape, so the
@@ -302,7 +315,7 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
     // ---- stage one: text encoder + duration predictor -------------------------------------------------------
     // Under VITS_ARITH_SCOPE_FLOW_VOCODER (default) stage one is exact fp32 in every arithmetic mode: the durations — the path's
     // only integer output, ceil() of a float (vits.cpp:996-1001) — are then bit-identical to the fp32 path's.
-    arith_now_ = arith_scope == VITS_ARITH_SCOPE_ALL_CONVS ? arith : VITS_ARITH_F32;
+    arith_now_ = arith_scope == VITS_ARITH_SCOPE_ALL_CONVS ? arith_kernels() : VITS_ARITH_F32;
     // pipelined batch: stage one goes to the front-end stream (the per-kernel profiler needs kernels that do not overlap: then,
     // and under VITS_NO_PIPELINE, everything stays on the main stream and a pipelined batch is merely a deferred result)
     const bool overlap = pend && front_ && !prof.on;
@@ -338,7 +351,7 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         if (run_text_encoder(c)) return -1;
         if (run_duration_predictor(c)) return -1;
     }
-    arith_now_ = arith;
+    arith_now_ = arith_kernels();
 
     // ---- the one data-dependent shape (vits.cpp:1133): frames per utterance ---------------------------------
     c.rx.phase("vits.frame_count_sync");

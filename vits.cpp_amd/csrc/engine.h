@@ -290,6 +290,9 @@ class Engine {
     // arithmetic of the convolutions being queued right now: `arith`, or fp32 while stage one runs under
     // VITS_ARITH_SCOPE_FLOW_VOCODER (every conv wrapper and fused kernel reads this one, never `arith` itself)
     int arith_now_ = VITS_ARITH_F32;
+    // VITS_ARITH_F32_SPLIT: every dispatch sees VITS_ARITH_F32 (arith_kernels()); only the vocoder's resblock scheduling asks split_on()
+    int arith_kernels() const { return arith == VITS_ARITH_F32_SPLIT ? VITS_ARITH_F32 : arith; }
+    bool split_on() const { return arith == VITS_ARITH_F32_SPLIT; }
     // emulated-ggml mode 1: the stage-one tensors as the file holds them (host, storage type) and their fp32 device copies (first use)
     std::vector<TensorEntry> exact_src_;
     struct ExactTensor {

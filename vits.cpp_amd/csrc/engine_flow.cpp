@@ -39,6 +39,12 @@ int Engine::layout_stage_two(Call& c) {
     c.fuse16 = fast16 && !knobs.no_fuse16;  // resblock conv pairs of the narrow stages as one kernel
     const size_t x16_elems2 = arith_now_ != VITS_ARITH_F32 ? std::max({big, (size_t)B * round_up(H, 8) * round_up(ls, 8), (size_t)B * round_up(hp.up_init, 8) * round_up(lws, 8), (size_t)B * round_up(F, 8) * round_up(ls, 8)}) + 64 : 0;
     const int S_stride = c.S_stride = round_up(smax[n_up], 32);
+    // VITS_ARITH_F32_SPLIT: three bf16 planes per conv input of the wide stages' resblocks (conv_split.hip): the stage input once, t and the stream per
+    // concurrently running resblock
+    size_t sp_elems = 0;
+    if (split_on())
+        for (int i = 0; i < n_up; ++i)
+            if (ups_[i].channels >= 128 && ups_[i].channels % 32 == 0) sp_elems = std::max(sp_elems, (size_t)3 * B * ups_[i].channels * sts[i + 1] + 64);
     auto layout2 = [&](Arena& a) {
         s2.zp = a.alloc<float>((size_t)B * F * ls);
         s2.noise = need_noise_buf ? a.alloc<float>((size_t)B * F * ls) : nullptr;
@@ -58,6 +64,12 @@ int Engine::layout_stage_two(Call& c) {
         s2.bs = a.alloc<float>(big);
         s2.bs16 = fast16 ? a.alloc<float>(big / 2 + 64) : nullptr;
         for (int j = 0; j < 3; ++j) s2.x16[j] = (x16_elems2 && (j == 0 || (knobs.rb_streams > 1 && !fast16))) ? a.alloc<uint16_t>(x16_elems2) : nullptr;
+        s2.sp_u = sp_elems ? a.alloc<uint16_t>(sp_elems) : nullptr;
+        for (int j = 0; j < 3; ++j) {
+            const bool own = j == 0 || (knobs.rb_streams > 1 && (size_t)j < hp.rb_k.size());
+            s2.sp_t[j] = !sp_elems ? nullptr : (own ? a.alloc<uint16_t>(sp_elems) : s2.sp_t[0]);
+            s2.sp_y[j] = !sp_elems ? nullptr : (own ? a.alloc<uint16_t>(sp_elems) : s2.sp_y[0]);
+        }
         s2.pre = o.collect_taps ? a.alloc<float>((size_t)B * S_stride) : nullptr;
         s2.wave = a.alloc<float>((size_t)B * S_stride);
     };

@@ -128,6 +128,7 @@ struct Call {
     struct S2 {
         float *zp, *noise, *hout, *gate, *h0, *bu, *bul, *by[3], *bt[3], *byl[3], *bs, *bs16, *pre, *wave;
         uint16_t* x16[3];
+        uint16_t *sp_u, *sp_t[3], *sp_y[3];  // VITS_ARITH_F32_SPLIT: split planes of the stage input, and per concurrent resblock of t and of the stream
         int* win_lens;  // [window][n_up + 2][B]: stage lengths of each utterance inside the window, then its emit end
     } s2{};
     int ls = 0, lws = 0, S_stride = 0;

@@ -555,6 +555,37 @@ int64_t Engine::get_tap(const char* name, int utt, float* dst, size_t cap) {
 
 int Engine::set_arith(int a, std::string& err) {
     if (a == arith) return 0;
+    if (a == VITS_ARITH_F32_SPLIT) {
+        // two bf16 planes of A fragments for every conv the split kernels may take (conv_split.hip conv_split_candidate), built once; a conv whose weights are
+        // not exactly two bf16 pieces (fp32-stored) simply keeps its fp32 kernels. Transactional like the 16-bit packing below.
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<std::pair<PackedConv*, uint16_t*>> fresh;
+        std::vector<int64_t> fresh_bytes;
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < packs_.size() && e == hipSuccess; ++i) {
+            const PackSrc& ps = packs_[i];
+            if (ps.pc->wps || !conv_split_candidate(ps.epi, ps.k, ps.cin, ps.cout)) continue;
+            const std::vector<float> w = ps.widen();
+            std::vector<uint16_t> packed;
+            if (!pack_conv_weights_split(w.data(), ps.cout, ps.cin, ps.k, packed)) continue;
+            uint16_t* d = nullptr;
+            e = hipMalloc((void**)&d, packed.size() * sizeof(uint16_t));
+            if (e == hipSuccess) e = hipMemcpy(d, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            if (d) fresh.emplace_back(ps.pc, d), fresh_bytes.push_back((int64_t)packed.size() * 2);
+        }
+        if (e != hipSuccess) {
+            for (auto& f : fresh) hipFree(f.second);
+            err = std::string("vits_model_set_arith: ") + hipGetErrorString(e) + " while packing the split weight planes; the model stays in its previous arithmetic";
+            return -1;
+        }
+        for (size_t i = 0; i < fresh.size(); ++i) {
+            fresh[i].first->wps = fresh[i].second;
+            fresh[i].first->bytes_s = fresh_bytes[i];
+            owned_.push_back(fresh[i].second);
+        }
+        arith = a;
+        return 0;
+    }
     if (a != VITS_ARITH_F32) {
         // pack every conv's weights as 16-bit A fragments of the requested type (rounded to nearest even; a no-op on the values
         // when the file already stores that type, as the reference's exporter does for fp16: export_vits.py:87).

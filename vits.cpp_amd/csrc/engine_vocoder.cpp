@@ -365,6 +365,30 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             for (size_t d = 0; d < R.dil.size() && f; ++d) f = R.c1[d].wp && R.c2[d].wp;
             blockrb[j] = f;
         }
+        // VITS_ARITH_F32_SPLIT: the un-fused resblocks of a wide stage run their convs on the bf16 matrix cores with split operands (conv_split.hip): their
+        // inputs are three-plane tensors written by the producing epilogue — the stage input by a converter launch —, the fp32 stream and the sum stay put.
+        bool splitrb[3] = {false, false, false};
+        bool any_split = false;
+        for (size_t j = 0; j < nk && j < 3 && split_on() && s2.sp_u; ++j) {
+            const ResBlockW& R = U.rbs[j];
+            bool f = !fusedrb[j] && C >= 128;
+            for (size_t d = 0; d < R.dil.size() && f; ++d) f = conv_split_supported(R.c1[d], R.dil[d]) && conv_split_supported(R.c2[d], 1);
+            splitrb[j] = f;
+            any_split = any_split || f;
+        }
+        auto SR = [&](uint16_t* ptr) {
+            Split3Ref r;
+            r.p = ptr;
+            r.ts = sts[st_out];
+            r.ps = (int64_t)C * sts[st_out];
+            r.bs = 3 * r.ps;
+            return r;
+        };
+        if (any_split) {
+            prof.begin("split_planes", 0, 10.0 * (double)C * (double)ssum[st_out], stream);
+            HIP_OK(launch_split_planes(bu, C, d_len[st_out], B, smax[st_out], hp.lrelu, SR(s2.sp_u), stream));
+            prof.end(stream);
+        }
         auto run_block = [&](size_t j, hipStream_t sj) -> int {
             const ResBlockW& R = U.rbs[j];
             const PackedConv* w1[3] = {&R.c1[0], &R.c1[1], &R.c1[2]};
@@ -408,7 +432,7 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
         // (measured, batch 64 x 128 ids: serialised launches 79.7 ms per step, grouped 79.1, three streams 76.8 — kernels of DIFFERENT
         // launches share a CU, which blocks of one launch do not, so the streams win where they can be used: the
         // grouped schedule is for the single-stream case, i.e. under the per-kernel profiler; VITS_RB_GROUP=1 forces it)
-        bool grouped = exact32 && !knobs.no_rb_group && nk >= 2 && nk <= 3 && knobs.rb_streams > 1 && (prof.on || knobs.rb_group_always);
+        bool grouped = exact32 && !any_split && !knobs.no_rb_group && nk >= 2 && nk <= 3 && knobs.rb_streams > 1 && (prof.on || knobs.rb_group_always);
         {
             int members = 0, seen = 0;
             for (size_t j = 0; j < nk && grouped; ++j) {
@@ -452,6 +476,16 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             c1.slope = hp.lrelu;
             c1.post_act = 2;  // bt = leaky_relu(conv1(...)): what the second conv consumes (vits.cpp:556-566)
             c1.post_slope = hp.lrelu;
+            if (j < 3 && splitrb[j]) {
+                // split arithmetic: the input is the planes of leaky_relu(stage input / stream), the output ONLY the planes of leaky_relu(t)
+                c1.x = TensorRef();
+                c1.xs3 = d > 0 ? SR(s2.sp_y[q]) : SR(s2.sp_u);
+                c1.y = TensorRef();
+                c1.ys3 = SR(s2.sp_t[q]);
+                c1.ys3_slope = hp.lrelu;
+                c1.pre_act = 0;
+                c1.post_act = 0;
+            }
             return c1;
         };
         auto mk_c2 = [&](size_t j, size_t d) {
@@ -467,6 +501,16 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             c2.dil = 1;
             c2.pad_l = (R.k - 1) / 2;
             c2.res = d == 0 ? bu : by;  // residual add (vits.cpp:578)
+            if (j < 3 && splitrb[j]) {
+                c2.y = by;  // (mk_c1 cleared it; the last conv of the resblock redirects it to the sum below)
+                c2.xs3 = SR(s2.sp_t[q]);
+                c2.y2 = nullptr;
+                c2.ys3 = Split3Ref();
+                if (d + 1 < nd) {
+                    c2.ys3 = SR(s2.sp_y[q]);  // planes of leaky_relu(y'): the next pair's first conv
+                    c2.ys3_slope = hp.lrelu;
+                }
+            }
             if (d + 1 < nd) c2.y = by;
             else {
                 // last conv of this resblock: fold the sum over resblocks and the 1/num_kernels scale (vits.cpp:622-635)

@@ -182,12 +182,22 @@ struct PackedConv {
     uint16_t* wp16 = nullptr;  // 16-bit A fragments of the VITS_ARITH_F16 / BF16 path (packed by Engine::set_arith)
     float* wp_l16 = nullptr;   // the same weights as v_mfma_f32_16x16x4_f32 A fragments (repack_conv_weights_l16) for conv_lat16_kernel, or nullptr
     int64_t bytes16 = 0;
+    uint16_t* wps = nullptr;   // VITS_ARITH_F32_SPLIT: the weights as TWO bf16 planes of A fragments (conv_split.hip pack_conv_weights_split), or nullptr
+    int64_t bytes_s = 0;
 };
 
 // 16-bit activation in "group layout" [batch][channel/8][time][8] (conv16.hip): one 16-byte slot = 8 channels of one time step
 struct Ref16 {
     uint16_t* p = nullptr;
     int64_t bs = 0;  // batch stride (16-bit elements)
+    int32_t ts = 0;  // slots per group row (time stride)
+};
+
+// a conv input of VITS_ARITH_F32_SPLIT (conv_split.hip): the three bf16 planes of an fp32 tensor in the group layout, [batch][plane 3][channel/8][time][8]
+struct Split3Ref {
+    uint16_t* p = nullptr;
+    int64_t bs = 0;  // batch stride (16-bit elements)
+    int64_t ps = 0;  // plane stride
     int32_t ts = 0;  // slots per group row (time stride)
 };
 
@@ -216,7 +226,17 @@ struct ConvCall {
     const float *ln_gamma = nullptr, *ln_beta = nullptr;
     float ln_eps = 0.f;
     TensorRef ln_out;
+    // VITS_ARITH_F32_SPLIT (launch_conv_split only): the input as split planes (x is then unused), and — optional — the planes of leaky_relu(ys3_slope) of the
+    // result for the next conv (y may then be null: a tensor whose only reader is the next conv is never stored in fp32)
+    Split3Ref xs3, ys3;
+    float ys3_slope = 1.f;
 };
+// VITS_ARITH_F32_SPLIT (conv_split.hip): fp32-accurate convs on the bf16 matrix cores by operand splitting — see the file's head comment
+bool conv_split_candidate(int epi, int kt, int cin, int cout);  // the layers that get split weight planes at vits_model_set_arith
+bool pack_conv_weights_split(const float* w, int cout, int cin, int k, std::vector<uint16_t>& out);  // w: torch layout [cout][cin][k]; false = not exactly two bf16 pieces
+bool conv_split_supported(const PackedConv& w, int dil);
+hipError_t launch_conv_split(const PackedConv& w, const ConvCall& c, hipStream_t s);
+hipError_t launch_split_planes(TensorRef x, int channels, const int* lens, int batch, int tmax, float slope, Split3Ref out, hipStream_t s);
 bool conv_ln_on_load_ok(const PackedConv& w, const ConvCall& c);
 
 // host-side packing: w is torch layout [cout][cin][k] (EPI_STD / EPI_GATE) or [cin][cout][k] (EPI_CONVT)
