@@ -290,6 +290,11 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
              "algorithmic_tflops": fl / e / 1e12}
         if arith == "f32":
             d.update({"binding_roof": "mfma_f32", "frac_of_binding_roof": fl / e / 1e12 / PEAK_F32_TFLOPS})
+        elif arith == "f32split":
+            # VITS_ARITH_F32_SPLIT: the resblock convs of the wide stages run as five bf16 MFMAs per 16 products (peak 2500 / 5 = 500 TFLOP/s-equivalent),
+            # the rest of the path on the fp32 MFMA (157.3): the roof of the whole path is the FLOP-weighted harmonic blend of the two
+            d.update({"binding_roof": "mfma_bf16_split_blend", "frac_of_binding_roof": fl / e / 1e12 / SPLIT_BLEND_PEAK_TFLOPS, "blend_peak_tflops": SPLIT_BLEND_PEAK_TFLOPS,
+                      "dtype": "fp32-accurate results: bf16 x (2 weight, 3 activation) operand split on the bf16 matrix cores, fp32 accumulate (wide-stage resblock convs); rest exact fp32"})
         else:
             # HBM side: MEASURED bytes (PMC FETCH_SIZE x 2 + WRITE_SIZE over every launch of a step, tools/pmc_traffic.py) when an artefact of
             # this build and workload exists; otherwise the layer-granular MODEL of SURVEY 8(d), labelled as such — the fused kernels move
@@ -374,6 +379,10 @@ def sub_results(pkg, torch, base_model, base_bytes, mode, steps_scale=1.0):
         base_model.set_arith(arith)
         n = max(3, int(16 * steps_scale))
         both("c3_" + name, [(base_model, ids64, noise_base, b, cap)], n, 128, name, 64, tag="c3|b64|" + name)
+    # c3 with fp32-accurate results from the bf16 matrix cores (VITS_ARITH_F32_SPLIT, csrc/conv_split.hip): opt-in, never the headline
+    base_model.set_arith(pkg.ARITH_F32_SPLIT)
+    n = max(3, int(6 * steps_scale))
+    both("c3_f32split", [(base_model, ids64, noise_base, b, cap)], n, 128, "f32split", 64)
     base_model.set_arith(pkg.ARITH_F32)
     del b
     # c5: two resident bf16-stored models, 8 x 1024 ids each, calls interleaved
@@ -536,6 +545,11 @@ def default_schedule_roofline(pkg, model_bytes, mode, ids, noise_base, cap, out_
 FINAL_LINE_LIMIT = 4096  # bytes; the driver keeps only a bounded tail of stdout (round 4: a 24 KB line came back as parsed: null)
 
 
+# VITS_ARITH_F32_SPLIT: MACs per frame that run on the split kernels for the MMS-TTS architecture (ResBlocks C = 256 at rate 8, all taps 3 + 7 + 11;
+# C = 128 at rate 64, all taps) against the path's 314.5 M (HiFiGAN 307.45 + flow 7.08); five bf16 MFMAs per 16
+# products = 2500 / 5 TFLOP/s-equivalent for that share, the fp32 MFMA peak for the rest: harmonic blend
+_SPLIT_MACS, _ALL_MACS = 6 * 256 * 256 * 21 * 8 + 6 * 128 * 128 * 21 * 64, 307453952 + 7077888
+SPLIT_BLEND_PEAK_TFLOPS = _ALL_MACS / (_SPLIT_MACS / 500.0 + (_ALL_MACS - _SPLIT_MACS) / 157.3)
 WORKLOAD_LABEL_MAX = 110  # the driver's record keeps 120 characters of config.workload (BENCH_r05 lost "mode=reference, conv arithmetic f32" at its end)
 
 
@@ -702,7 +716,7 @@ def main():
     ap.add_argument("--ids-per-utt", type=int, default=0, help="encoder input ids per utterance (after blank interspersing); default 128 (c3) / 1024 (c5)")
     ap.add_argument("--pinned", type=int, default=0, help=">0: pin every id to this many frames (SURVEY §8d run ii)")
     ap.add_argument("--mode", choices=["reference", "hf"], default="reference")
-    ap.add_argument("--arith", choices=["f32", "bf16", "f16"], default="f32",
+    ap.add_argument("--arith", choices=["f32", "bf16", "f16", "f32split"], default="f32",
                     help="conv operand precision: f32 (exact, default), or 16-bit MFMA operands with fp32 accumulation (vits_model_set_arith)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -760,7 +774,7 @@ def main():
     mode = pkg.MODE_REFERENCE if args.mode == "reference" else pkg.MODE_HF
     # c3: "vits-english"; c5: "vits-spanish + english": two synthetic weight sets resident at once, conv weights stored as bf16
     model_specs = [(0x5EED, pkg.SYNTH_FULL | pkg.SYNTH_BF16, 1234), (0xBEEF, pkg.SYNTH_FULL | pkg.SYNTH_BF16, 91234)] if c5 else [(0x5EED, pkg.SYNTH_FULL, 1234)]
-    arith = {"f32": pkg.ARITH_F32, "bf16": pkg.ARITH_BF16, "f16": pkg.ARITH_F16}[args.arith]
+    arith = {"f32": pkg.ARITH_F32, "bf16": pkg.ARITH_BF16, "f16": pkg.ARITH_F16, "f32split": pkg.ARITH_F32_SPLIT}[args.arith]
     cap = 256 * 8 * T + 294  # PCM row capacity: up to 8 frames per id
     jobs = []
     for seed, arch, ids_seed in model_specs:
@@ -916,7 +930,7 @@ def main():
                       "audio samples/sec end-to-end (ids -> fp32 PCM in HBM), two resident bf16-stored models, 1024-id utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.arith, "data": "synthetic", "ranks_seen": ranks_seen, "rccl_world_size": dist.get_world_size() if dist_on else 1,
+            "dtype": args.arith if args.arith != "f32split" else "f32 (bf16 operand split on the matrix cores, fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen, "rccl_world_size": dist.get_world_size() if dist_on else 1,
             "devices_seen": devices_seen,
             "config": {"workload": workload, "workload_long": workload_long, "batch_per_gpu": B * len(jobs), "ids_per_utterance": T, "frames_per_utterance_mean": float(np.mean(frames)),
                        "samples_per_step": total_samples // args.steps, "sampling_rate": sr, "parallelism": f"utterance-sharded x{world}",
@@ -926,8 +940,8 @@ def main():
             "algorithmic_tflops": flops_step * args.steps / elapsed / 1e12,
         }
         # whole-path fraction of the matrix-core peak of the arithmetic in use (fp32: 157.3 TFLOP/s; 16-bit operands: 2.5 PFLOP/s dense)
-        res["frac_fp32_peak_whole_path" if args.arith == "f32" else "frac_mfma16_peak_whole_path"] = \
-            flops_step * args.steps / elapsed / 1e12 / ((PEAK_F32_TFLOPS if args.arith == "f32" else 2500.0) * world)
+        res["frac_fp32_peak_whole_path" if args.arith == "f32" else ("frac_split_blend_peak_whole_path" if args.arith == "f32split" else "frac_mfma16_peak_whole_path")] = \
+            flops_step * args.steps / elapsed / 1e12 / ((PEAK_F32_TFLOPS if args.arith == "f32" else SPLIT_BLEND_PEAK_TFLOPS if args.arith == "f32split" else 2500.0) * world)
         res["schedule"] = ("instrumented (single pass under a profiler): per-kernel HIP events, resblocks of a stage serialised" if args.single_pass and not args.no_prof
                            else "library default: no per-kernel events, resblocks of a stage on 3 concurrent streams")
         if "instrumented" in extra:
@@ -974,7 +988,7 @@ def main():
                             "t": "conv_mfma_kernel", "w": "wavenet32_kernel", "G": "conv_group_kernel", "B": "rbblock16_kernel (whole ResBlock)", "b": "rbblock32_kernel (whole 3-tap ResBlock, fp32)",
                             "C": "flow_couple16_kernel (whole coupling layer)"}
             dom_members = None
-            if args.arith != "f32" and mfma_keys:
+            if args.arith not in ("f32", "f32split") and mfma_keys:
                 fam = {}
                 for kk in mfma_keys:
                     fam.setdefault(family_of(kk), []).append(kk)
@@ -991,13 +1005,15 @@ def main():
             achieved = dom["flop"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
             all_ms = sum(g["ms"] for g in groups.values())
             peak = PEAK_F32_TFLOPS if args.arith == "f32" else PEAK_MFMA16_TFLOPS  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
+            if args.arith == "f32split":  # the split kernels (tile letter S): five bf16 MFMAs per 16 products; every other kernel of this mode is the fp32 path
+                peak = PEAK_MFMA16_TFLOPS / 5.0 if family_of(dom_members[0]) == "S" else PEAK_F32_TFLOPS
             alg_gbs = dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
             mfma_frac, hbm_frac = achieved / peak, alg_gbs / PEAK_HBM_GBS
-            if args.arith == "f32" or mfma_frac >= hbm_frac:
+            if args.arith in ("f32", "f32split") or mfma_frac >= hbm_frac:
                 res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": mfma_frac}
             else:  # 16-bit operands: 16x the MFMA rate, the same bytes -> the conv is bound by HBM, not by the matrix cores
                 res["roofline"] = {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
-            if args.arith != "f32":
+            if args.arith not in ("f32", "f32split"):
                 # context for the 16-bit fractions: a register-only loop of v_mfma_f32_32x32x16_{f16,bf16} sustains 1.67 (f16) /
                 # 1.80 (bf16) PFLOP/s at 1.63 / 1.78 GHz on operands with random signs and exponents spread over 2^-7..2^0, 1.96 PFLOP/s on
                 # same-sign same-exponent operands (tools/mfma16_peak.hip) - the power budget, not the issue rate, sets the ceiling
@@ -1026,11 +1042,11 @@ def main():
                 ws = art[1].get("whole_step")
                 if ws:
                     sps = total_samples / args.steps / world
-                    alg = (ALG_BYTES_PER_SAMPLE_F32 if args.arith == "f32" else ALG_BYTES_PER_SAMPLE_16) * sps
+                    alg = (ALG_BYTES_PER_SAMPLE_F32 if args.arith in ("f32", "f32split") else ALG_BYTES_PER_SAMPLE_16) * sps
                     res["roofline"]["whole_step_traffic"] = {
                         "hbm_bytes_per_step": ws["hbm_bytes_per_step"], "fetch_bytes_per_step": ws["fetch_bytes_per_step"], "write_bytes_per_step": ws["write_bytes_per_step"],
                         "algorithmic_bytes_per_step": alg, "algorithmic_model": "%.1f KB per output sample (SURVEY 8d layer-granular activation model%s) x %d samples" % (
-                            (ALG_BYTES_PER_SAMPLE_F32 if args.arith == "f32" else ALG_BYTES_PER_SAMPLE_16) / 1e3, "" if args.arith == "f32" else ", 16-bit conv inputs: x 16/24", sps),
+                            (ALG_BYTES_PER_SAMPLE_F32 if args.arith in ("f32", "f32split") else ALG_BYTES_PER_SAMPLE_16) / 1e3, "" if args.arith in ("f32", "f32split") else ", 16-bit conv inputs: x 16/24", sps),
                         "ratio": ws["hbm_bytes_per_step"] / alg, "samples_per_step_in_trace": ws.get("samples_per_step"),
                         "hbm_gbs_at_this_step_time": ws["hbm_bytes_per_step"] / (elapsed / args.steps) / 1e9,
                         "frac_of_hbm_peak": ws["hbm_bytes_per_step"] / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS, "source": os.path.relpath(art[0], ROOT)}

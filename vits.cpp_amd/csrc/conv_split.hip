@@ -91,9 +91,12 @@ struct ConvSplitParams {
     float ys_slope;
 };
 
-template <int KT, int DIL>
+// WM: 32-row tiles per block. 4: 128 rows x 128 columns (c_out multiples of 128). 2: 64 rows x 256 columns (C = 64: the four compute waves are two row tiles x two
+// 128-column halves, so that an A fragment still feeds 4 x 5 MFMAs — at 128 columns the two planes of weight fragments would be 51 B / clock / CU from L2, the
+// whole L2 -> CU path); its two LDS buffers hold a 64-channel input completely (120 KB: one block per CU).
+template <int KT, int DIL, int WM>
 __global__ __launch_bounds__(320) void conv_split_kernel(const ConvSplitParams p) {
-    constexpr int BN = 128, NR = 4, STEPS = KT * 2;
+    constexpr int WN = 4 / WM, BN = 128 * WN, NR = 4, STEPS = KT * 2;
     constexpr int XWP = (BN + (KT - 1) * DIL + 7) / 8 * 8;  // slots per LDS group row
     constexpr int BUF = 3 * 4 * XWP;                         // slots per buffer: [plane][group][XWP]
     extern __shared__ __attribute__((aligned(16))) cs_int4v xs[];
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(320) void conv_split_kernel(const ConvSplitParams p
 
     if (wid == 4) {
         // ---- producer wave (conv16.hip's protocol): fill(0); B; for c: { fill(c + 1); B } ----
-        constexpr int NMP = 3;  // 64-slot pieces per group row (XWP <= 184). NOT (XWP + 63) / 64: with an array whose size depends on the template parameters
+        constexpr int NMP = 5;  // 64-slot pieces per group row (XWP <= 312). NOT (XWP + 63) / 64: with an array whose size depends on the template parameters
                                 // captured by the DMA lambda below, hipcc 7.2 silently drops the kernel's HOST definition (undefined symbol at load)
         static_assert(XWP <= 64 * NMP, "pieces");
         const bool interior = tile_start >= 0 && tile_start + XWP <= len_in;
@@ -159,8 +162,9 @@ __global__ __launch_bounds__(320) void conv_split_kernel(const ConvSplitParams p
         return;
     }
 
-    // ---- compute waves: row tile blockIdx.y * 4 + wid, all four column tiles ----
-    const int mt = blockIdx.y * 4 + wid;
+    // ---- compute waves: row tile wm of the block, four column tiles from column 128 wn ----
+    const int wm = wid % WM, wn = wid / WM;
+    const int mt = blockIdx.y * WM + wm;
     cs_floatx16 acc[NR];
 #pragma unroll
     for (int n = 0; n < NR; ++n)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(320) void conv_split_kernel(const ConvSplitParams p
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     const int h = lane >> 5;
     typedef const __attribute__((address_space(3))) cs_int4v* LdsV;
-    const int lane_slot = h * XWP + (lane & 31);
+    const int lane_slot = h * XWP + 128 * wn + (lane & 31);
     const int total_steps = p.nchunks * STEPS;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, 0x7fffffff, 0x00020000);
     const int wvoff = (int)((((size_t)mt * total_steps * 2) * 64 + lane) * 16);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(320) void conv_split_kernel(const ConvSplitParams p
     }
 
     // ---- epilogue: conv_mfma.hip's EPI_STD expressions on the fp32 [b][c][t] tensors; the split planes of the next conv's input ----
-    const int colbase = t0 + (lane & 31);
+    const int colbase = t0 + 128 * wn + (lane & 31);
     float* yb = p.y ? p.y + (int64_t)b * p.y_bs : nullptr;
     const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
     const float* ab = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
@@ -342,6 +346,8 @@ bool pack_conv_weights_split(const float* w, int cout, int cin, int k, std::vect
     return true;
 }
 
+// (C = 64 was tried on the 64 x 256 tile below (WM = 2): 92 TFLOP/s-equivalent against 124 for the fused fp32 pairs — a 60 KB chunk per buffer leaves one block per CU,
+// and ONE producer wave's LDS-DMA stream, ~1 KB per 0.12 us, takes as long per chunk as the chunk's MFMAs; the narrow stages keep their fused fp32 kernels)
 bool conv_split_candidate(int epi, int kt, int cin, int cout) {
     return epi == EPI_STD && (kt == 3 || kt == 7 || kt == 11) && cin >= 128 && (cin & 31) == 0 && (cout & 127) == 0;
 }
@@ -364,27 +370,34 @@ hipError_t launch_conv_split(const PackedConv& w, const ConvCall& c, hipStream_t
     p.scale = c.scale, p.scale_div = c.scale_div;
     p.post_act = c.post_act, p.post_slope = c.post_slope;
     p.ys = c.ys3.p, p.ys_bs = c.ys3.bs, p.ys_ps = c.ys3.ps, p.ys_ts = c.ys3.ts, p.ys_slope = c.ys3_slope;
-    dim3 grid((c.t_out + 127) / 128, w.cout / 128, c.batch);
-#define VITS_CS(K, D)                                                                                                                             \
+    const int wm = 4;  // (the 64-row tile, WM = 2, is not instantiated: see conv_split_candidate)
+    const int bn = 128 * (4 / wm);
+    dim3 grid((c.t_out + bn - 1) / bn, w.cout / (32 * wm), c.batch);
+#define VITS_CS(K, D, M)                                                                                                                          \
     do {                                                                                                                                          \
-        constexpr size_t lds = (size_t)2 * 12 * ((128 + (K - 1) * D + 7) / 8 * 8) * 16;                                                          \
+        constexpr size_t lds = (size_t)2 * 12 * ((128 * (4 / M) + (K - 1) * D + 7) / 8 * 8) * 16;                                                 \
         static BigLdsOnce big;                                                                                                                    \
         if (lds > 64 * 1024 && big.needed()) {                                                                                                    \
-            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e; \
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<K, D, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e; \
             big.done();                                                                                                                           \
         }                                                                                                                                         \
-        VITS_KLAUNCH((conv_split_kernel<K, D>), grid, dim3(320), lds, s, p);                                                                      \
+        VITS_KLAUNCH((conv_split_kernel<K, D, M>), grid, dim3(320), lds, s, p);                                                                   \
         return hipGetLastError();                                                                                                                 \
     } while (0)
-#define VITS_CS_D(K)               \
-    do {                           \
-        if (c.dil == 1) VITS_CS(K, 1); \
-        if (c.dil == 3) VITS_CS(K, 3); \
-        VITS_CS(K, 5);             \
+#define VITS_CS_D(K, M)                    \
+    do {                                   \
+        if (c.dil == 1) VITS_CS(K, 1, M);  \
+        if (c.dil == 3) VITS_CS(K, 3, M);  \
+        VITS_CS(K, 5, M);                  \
     } while (0)
-    if (w.kt == 3) VITS_CS_D(3);
-    if (w.kt == 7) VITS_CS_D(7);
-    VITS_CS_D(11);
+#define VITS_CS_M(K)         \
+    do {                     \
+        VITS_CS_D(K, 4);     \
+    } while (0)
+    if (w.kt == 3) VITS_CS_M(3);
+    if (w.kt == 7) VITS_CS_M(7);
+    VITS_CS_M(11);
+#undef VITS_CS_M
 #undef VITS_CS_D
 #undef VITS_CS
 }

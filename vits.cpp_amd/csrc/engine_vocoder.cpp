@@ -353,6 +353,13 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             const ResBlockW& R = U.rbs[j];
             bool f = exact32 && !knobs.no_fuse32 && al16(bu) && (reinterpret_cast<uintptr_t>(s2.by[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(s2.bt[0]) & 15) == 0 && (sts[st_out] & 3) == 0;
             for (size_t d = 0; d < R.dil.size() && f; ++d) f = rbpair32_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
+            // VITS_ARITH_F32_SPLIT: a resblock the split kernels take (conv_split.hip: C >= 128, any tap count) runs un-fused — the C = 128, k = 3 pairs, fused in
+            // the exact mode, are 1.56 ms each there and 0.9 as two split convs
+            if (f && split_on() && s2.sp_u && C >= 128) {
+                bool sp = true;
+                for (size_t d = 0; d < R.dil.size() && sp; ++d) sp = conv_split_supported(R.c1[d], R.dil[d]) && conv_split_supported(R.c2[d], 1);
+                if (sp) f = false;
+            }
             fusedrb[j] = f;
         }
         // narrow stages, 3-tap resblocks: the WHOLE resblock as one kernel (rbblock32.hip: the stream stays in registers across its three pairs;
