@@ -98,64 +98,10 @@ struct ConvParams {
 //     (VALU and MFMA share the issue port); LeakyReLU is normally applied by whoever WROTE the input, otherwise by the
 //     producer in LDS (k >= 5) or at the B-operand read (k <= 3); zero padding at the sequence ends is a fix-up by the
 //     producer on boundary tiles only. DESIGN.md section 4.1 has the measurements behind each of these choices.
-#ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/conv_micro.hip): per-block phase timestamps, 100 MHz clock
-__device__ unsigned long long vits_phase_buf[8 * 65536];  // [block][0..3] 100 MHz stamps, [4..5] shader clock around the K loop, [6..7] HW_ID / XCC_ID
-__device__ unsigned long long vits_prod_buf[4 * 65536];  // [block][0..3]: producer wave, shader cycles in issue / DMA wait / post-processing / barrier
-__device__ unsigned long long vits_chunk_buf[8 * 65536];  // [block][2c], [2c+1]: shader clock at the end of chunk c < 4 and behind its barrier
-#define VITS_STAMP(k)                                                                                               \
-    do {                                                                                                            \
-        if (tid == 0) {                                                                                             \
-            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
-            if (lin < 65536) {                                                                                      \
-                vits_phase_buf[8 * lin + (k)] = __builtin_amdgcn_s_memrealtime();                                   \
-                if ((k) == 1 || (k) == 2) vits_phase_buf[8 * lin + 3 + (k)] = __builtin_amdgcn_s_memtime();         \
-                if ((k) == 0) {                                                                                     \
-                    unsigned hw, xcc;                                                                               \
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
-                    vits_phase_buf[8 * lin + 6] = hw;                                                               \
-                    vits_phase_buf[8 * lin + 7] = xcc;                                                              \
-                }                                                                                                   \
-            }                                                                                                       \
-        }                                                                                                           \
-    } while (0)
-__device__ unsigned long long vits_epi_buf[8 * 65536];  // [block][0..6]: shader clock at the epilogue's entry, in front of its first sub-tile, behind each of (up to) four sub-tiles, at its end
-__device__ unsigned long long vits_wave_end[8 * 65536];  // [block][wave]: 100 MHz clock when wave 0..4 retires
-#define VITS_WSTAMP()                                                                                               \
-    do {                                                                                                            \
-        if (lane == 0) {                                                                                            \
-            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
-            if (lin < 65536) vits_wave_end[8 * lin + wid] = __builtin_amdgcn_s_memrealtime();                       \
-        }                                                                                                           \
-    } while (0)
-__device__ unsigned long long vits_wave_start[8 * 65536];  // [block][wave]: 100 MHz clock at the first instructions of wave 0..4; [5..7]: HW_ID of waves 0, 1, 4
-#define VITS_WSTART()                                                                                               \
-    do {                                                                                                            \
-        if (lane == 0) {                                                                                            \
-            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
-            if (lin < 65536) {                                                                                      \
-                vits_wave_start[8 * lin + wid] = __builtin_amdgcn_s_memrealtime();                                  \
-                if (wid == 0 || wid == 1 || wid == 4) {                                                             \
-                    unsigned hw;                                                                                    \
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
-                    vits_wave_start[8 * lin + (wid == 0 ? 5 : wid == 1 ? 6 : 7)] = hw;                             \
-                }                                                                                                   \
-            }                                                                                                       \
-        }                                                                                                           \
-    } while (0)
-#define VITS_ESTAMP(k)                                                                                              \
-    do {                                                                                                            \
-        if (tid == 0) {                                                                                             \
-            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                            \
-            if (lin < 65536) vits_epi_buf[8 * lin + (k)] = __builtin_amdgcn_s_memtime();                           \
-        }                                                                                                           \
-    } while (0)
-#else
-#define VITS_STAMP(k)
-#define VITS_ESTAMP(k)
-#define VITS_WSTAMP()
-#define VITS_WSTART()
-#endif
+// Developer instrumentation (per-block phase stamps, VITS_PHASE_TIMING) and the compiled-out ablation hooks of tools/conv_micro.hip (VAR_*: what a variant of the
+// kernel WITHOUT some part of it costs — DESIGN.md 4.1 quotes them) live in conv_mfma_ablations.inc; every hook below (VITS_STAMP, VITS_ABL_*) expands to nothing in
+// the product build.
+#include "conv_mfma_ablations.inc"
 
 #ifndef VITS_WAVES_ATTR
 #define VITS_WAVES_ATTR
@@ -178,11 +124,7 @@ __device__ __forceinline__ void zero_oob_columns(float* lbase, int ts, int len, 
     const int noob = nl + XWP - rs;
     if (noob <= 0) return;
     float* row = lbase + (lane & 31) * XWP;
-#ifdef VITS_ZERO_OOB_NOROT  // ablation: every row starts at outside-column 0 (the round-3 walk, 16-way conflicts)
-    int k = 0;
-#else
-    int k = (lane & 31) % noob;  // (loop-invariant over the chunks of a block: computed once)
-#endif
+    int k = VITS_ABL_ZERO_OOB_START((lane & 31) % noob);  // (loop-invariant over the chunks of a block: computed once)
     for (int i = lane >> 5; i < noob; i += 2) {
         int kk = k + i;
         kk = kk >= noob ? kk - noob : kk;
@@ -211,10 +153,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
     const int wm = wid / WN, wn = wid % WN;
     const int b = bz;
     const int t0 = bx * BN;
-#ifdef VAR_SETPRIO  // ablation (tools/conv_micro.hip): prologue / producer / epilogue at wave priority 3, the K loop at 0 — no effect on the
-                   // starvation described at the K loop (DESIGN.md 4.1 "what the remaining 20 % are")
-    if constexpr (DB) __builtin_amdgcn_s_setprio(3);
-#endif
+    if constexpr (DB) VITS_ABL_SETPRIO(3);
     VITS_WSTART();
     const int len_in = p.len_in ? p.len_in[b] : p.t_in;
     // number of valid GEMM columns for this utterance
@@ -385,18 +324,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                 finish(0, 0);
                 __syncthreads();
                 int b1 = 1, b2 = 2;  // buffers of chunks c + 1 and c + 2
-#ifdef VITS_PHASE_TIMING
-                unsigned long long pt[4] = {0, 0, 0, 0};
-#define PSTAMP(k)                                              \
-    do {                                                       \
-        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
-        pt[k] += now - pprev;                                  \
-        pprev = now;                                           \
-    } while (0)
-                unsigned long long pprev = __builtin_amdgcn_s_memtime();
-#else
-#define PSTAMP(k)
-#endif
+                VITS_PSTAMP_BEGIN();
                 for (int c = 0; c + 1 < n; ++c) {
                     const bool more = c + 2 < n;
                     if (more) issue(c + 2, b2);  // last read during chunk c - 1, which every compute wave left before B(c)
@@ -411,13 +339,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                     b1 = b2;
                     b2 = b2 == 2 ? 0 : b2 + 1;
                 }
-#ifdef VITS_PHASE_TIMING
-                if (lane == 0) {
-                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
-                    if (lin < 65536)
-                        for (int k = 0; k < 4; ++k) vits_prod_buf[4 * lin + k] = pt[k];
-                }
-#endif
+                VITS_PSTAMP_END();
             }
             if (wid == 4) {
                 VITS_WSTAMP();
@@ -508,20 +430,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = *(LdsVF)(xj + nr * 32);  // (tap 0, pair 0)
         // fully unrolled taps: a taken branch every 64 MFMAs costs ~240 cycles of MFMA issue (measured on k = 11: K-loop
         // efficiency 0.871 -> 0.915); VITS_TAP_ROLLED keeps the rolled loop for comparison
-#ifdef VITS_TAP_ROLLED
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
+        VITS_ABL_TAP_UNROLL
         for (int j = 0; j < KT; ++j) {
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) {
                 {
                     const int nstep = gstep + 2 < total_steps ? gstep + 2 : total_steps - 1;  // clamp: stays in bounds
-#ifndef VAR_NOA
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = load_a(mr, nstep);
-#endif
+                    VITS_ABL_UNLESS_NOA(_Pragma("unroll") for (int mr = 0; mr < MR; ++mr) ring[(p4 + 2) & 3][mr] = load_a(mr, nstep);)
                 }
                 // pin the prefetch at the top of the step: hipcc otherwise sinks the loads next to their first use
                 // (vmcnt wait right behind the issue) and the L2 latency lands between MFMAs
@@ -538,20 +453,15 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
                         // reads a few floats past the row: still inside the tile, value unused)
                         const int pair = p4 * 4 + q;
                         LdsF nx = pair + 1 < CK / 2 ? xj + (2 * (pair + 1)) * xw : xj + dil;
-#ifndef VAR_NOB
-#pragma unroll
                         // (volatile: keeps one ds_read_b32 per value with a 16-bit immediate offset; merged into
                         // ds_read2_b32 — 8-bit offsets — every read needs a v_add_u32 for its base)
-                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = *(LdsVF)(nx + nr * 32);
-#endif
+                        VITS_ABL_UNLESS_NOB(_Pragma("unroll") for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = *(LdsVF)(nx + nr * 32);)
                     }
-#ifndef VAR_NOBPIN
                     // pin the LDS read of the NEXT k-step in front of this step's MFMAs: left alone, hipcc reuses the
                     // registers of b_cur for b_nxt and therefore sinks the ds_read behind the last MFMA that reads them —
                     // one MFMA (64 cycles) in front of the s_waitcnt, less than the LDS latency: measured 14 % of the
                     // K loop of the k = 11 kernel idle on lgkmcnt
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
+                    VITS_ABL_UNLESS_NOBPIN(__builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) {
                         const float4 a4 = ring[p4][mr];
@@ -559,10 +469,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
 #pragma unroll
                         for (int nr = 0; nr < NR; ++nr) {
                             acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[nr], acc[mr][nr], 0, 0, 0);
-#ifdef VAR_NOPS  // ablation: VAR_NOPS x 64 idle cycles behind every MFMA (the next block then launches as soon as this one's producer retires)
-#pragma unroll
-                            for (int z = 0; z < VAR_NOPS; ++z) asm volatile("s_nop 15");
-#endif
+                            VITS_ABL_NOPS();
                         }
                     }
                 }
@@ -580,9 +487,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
     constexpr int NK = DB ? 1 : CK / 4;
     float st[NK][NM];
     auto stage_load = [&](int c) __attribute__((always_inline)) {
-#ifdef VAR_NOSTAGE
-        return;
-#endif
+        VITS_ABL_NOSTAGE_RETURN();
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int ch = c * CK + wid + 4 * k;
@@ -598,9 +503,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         }
     };
     auto stage_store = [&](int buf) __attribute__((always_inline)) {
-#ifdef VAR_NOSTAGE
-        return;
-#endif
+        VITS_ABL_NOSTAGE_RETURN();
         float* dst = xs + buf * (CK * xw) + wid * xw + lane;
 #pragma unroll
         for (int k = 0; k < NK; ++k)
@@ -661,34 +564,18 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
         auto k_loop = [&](auto lr) __attribute__((always_inline)) {
             int buf = 0;
             for (int c = 0; c < p.nchunks; ++c) {
-#ifdef VAR_YIELD  // ablation: the compute waves sleep VAR_YIELD x 64 cycles in front of the last chunk (lets the next block launch there)
-                if (c + 1 == p.nchunks) __builtin_amdgcn_s_sleep(VAR_YIELD);
-#endif
+                VITS_ABL_YIELD(c + 1 == p.nchunks);
                 compute_chunk(xrow0 + buf * (CK * xw), lr);
                 buf = buf + 1 == p.nbuf ? 0 : buf + 1;
-#ifdef VITS_PHASE_TIMING
-                if (tid == 0 && c < 4) {
-                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
-                    if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c] = __builtin_amdgcn_s_memtime();
-                }
-#endif
+                VITS_CHUNK_STAMP(2 * c);
                 if (c + 1 < p.nchunks && !oneshot) __syncthreads();  // (see the producer: the last chunk needs no barrier)
-#ifdef VITS_PHASE_TIMING
-                if (tid == 0 && c < 4) {
-                    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
-                    if (lin < 65536) vits_chunk_buf[8 * lin + 2 * c + 1] = __builtin_amdgcn_s_memtime();
-                }
-#endif
+                VITS_CHUNK_STAMP(2 * c + 1);
             }
         };
-#ifdef VAR_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        VITS_ABL_SETPRIO(0);
         if (LRELU_AT_READ && p.pre_act) k_loop(std::true_type{});
         else k_loop(std::false_type{});
-#ifdef VAR_SETPRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        VITS_ABL_SETPRIO(3);
         VITS_STAMP(2);
     } else {
         // single LDS buffer (few chunks: nothing to overlap inside the block; other resident blocks hide the latency)
@@ -706,19 +593,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* xs, c
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
-#ifdef VAR_NOEPI  // ablation: keep the accumulators alive, store one value per lane
-    {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 12345.678f) p.y[tid] = sacc;
-        return;
-    }
-#endif
+    VITS_ABL_NOEPI_RETURN();
     VITS_ESTAMP(0);
     const int colbase = t0 + wn * (NR * 32) + (lane & 31);
     const int rowoff = 4 * (lane >> 5);

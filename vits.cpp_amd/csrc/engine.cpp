@@ -302,6 +302,7 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
             }
         }
     }
+    if (!lat16_ready_ && knobs.lat16_lazy_tokens > 0 && (int64_t)B * c.Tmax <= knobs.lat16_lazy_tokens && ensure_lat16(err)) return -1;
     if (c.Tmax > 2048) {
         err = "more than 2048 ids per utterance is not supported";
         return -1;

@@ -120,6 +120,8 @@ struct UpStageW {
 // not thread-safe against setenv, and a per-layer lookup is host time inside the caller's timed region). INTEGRATION.md §9.
 struct Knobs {
     int rb_streams = 3;          // VITS_RB_STREAMS (1 serialises the three resblocks of a stage on the main stream)
+    int lat16_lazy_tokens = 4096;  // VITS_LAT16_LAZY_TOKENS: a call of at most this many ids (batch x longest utterance) first makes the latency kernels' weight copy (0: never)
+    bool lat16_eager = false;      // VITS_LAT16_EAGER: make that copy at load
     int rb16_serial_max_frames = 1300;  // VITS_RB16_SERIAL_MAX_FRAMES: 16-bit vocoder windows of at most this many frames (all utterances) use one stream ...
     int rb16_serial_min_frames = 600;   // VITS_RB16_SERIAL_MIN_FRAMES: ... unless they have fewer than this (one or two 128-id utterances: kernels of 15-60 blocks, three of which side by side fill more of the chip than the fork / join costs — round 6, batch 1 / 2 / 4: 1.70 -> 1.60 / 1.77 -> 1.71 / 2.09 -> 2.17 ms with three streams)
     int lrelu_copy_minc = 128;   // VITS_LRELU_COPY_MINC: stages at least this wide also store leaky_relu(y)
@@ -238,6 +240,13 @@ class Engine {
         }
     };
     std::vector<PackSrc> packs_;
+    struct Lat16Lazy {
+        PackedConv* pc;
+        size_t n;  // floats of the packed array
+    };
+    std::vector<Lat16Lazy> lat16_lazy_;  // layers that get a wp_l16 copy at the first small call (ensure_lat16)
+    bool lat16_ready_ = false;
+    int ensure_lat16(std::string& err);
     Ref16 x16_[3];           // per-stream scratch for the 16-bit copy of a conv input (transparent 16-bit path)
     size_t x16_cap_[3] = {0, 0, 0};
     bool vocoder_group_ok_ = false;  // every vocoder channel count is a multiple of 8: group-layout fast path available

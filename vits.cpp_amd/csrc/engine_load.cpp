@@ -232,13 +232,9 @@ bool Engine::pack(const ModelFile& f, const std::string& wname, const std::strin
         packs_.push_back(std::move(ps));
     }
     out.wp = upload(packed);
-    if (!dry_run_ && conv_lat16_candidate(epi, out.kt, cin)) {  // second copy for the latency kernel (batch 1 / short inputs)
-        out.wp_l16 = upload(repack_conv_weights_l16(packed, out.mtiles, out.nchunks, out.kt));
-        if (!out.wp_l16) {
-            err = "hipMalloc failed for " + wname;
-            return false;
-        }
-    }
+    // the second copy of the weights for the latency kernels (batch 1 / short inputs: conv_lat16_kernel, stage1_lat.hip) is made by ensure_lat16() at the
+    // first SMALL call (or at load under VITS_LAT16_EAGER=1): a handle that only ever serves large batches keeps ONE fp32 copy of its weights
+    if (!dry_run_ && conv_lat16_candidate(epi, out.kt, cin)) lat16_lazy_.push_back({&out, packed.size()});
     out.bias = bias.empty() ? nullptr : upload(bias);
     out.bytes = (int64_t)packed.size() * 4;  // what ONE launch reads (a launch takes wp or wp_l16, never both; weight_bytes counts both copies)
     if (!out.wp) {
@@ -362,9 +358,9 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             pc.epi = EPI_STD;
             auto packed = pack_conv_weights(w.data(), 3 * H, H, 1, EPI_STD, 0, &pc.rows, &pc.mtiles_used, &pc.mtiles, &pc.nchunks);
             pc.wp = upload(packed);
-            if (!dry_run_ && conv_lat16_candidate(EPI_STD, 1, H)) pc.wp_l16 = upload(repack_conv_weights_l16(packed, pc.mtiles, pc.nchunks, 1));
+            if (!dry_run_ && conv_lat16_candidate(EPI_STD, 1, H)) lat16_lazy_.push_back({&pc, packed.size()});
             pc.bias = upload(bias);
-            pc.bytes = (int64_t)packed.size() * 4 * (pc.wp_l16 ? 2 : 1);
+            pc.bytes = (int64_t)packed.size() * 4;
             if (!pc.wp || !pc.bias) {
                 err = "hipMalloc failed for " + b + "attention";
                 return false;
@@ -502,8 +498,30 @@ bool Engine::load(const uint8_t* bytes, size_t size, std::string& err) {
             if (!s1 || t.name.find(".post_") != std::string::npos || t.name.rfind("duration_predictor.flows.1.", 0) == 0) continue;
             exact_src_.push_back(t);
         }
+        if (knobs.lat16_eager && ensure_lat16(err)) return false;
     }
     return true;
+}
+
+// conv_lat16_kernel's / stage1_lat.hip's A fragments (repack_conv_weights_l16) for every layer that may run on them: a second arrangement of the packed fp32
+// weights, built from the device copy (download, re-order on the host, upload: ~0.2 s for the full architecture, once per handle). Called at the first call small
+// enough to use the latency kernels; until then wp_l16 is null and the tile rules simply do not pick them (same bits either way).
+int Engine::ensure_lat16(std::string& err) {
+    if (lat16_ready_) return 0;
+    std::vector<float> host;
+    for (const Lat16Lazy& e : lat16_lazy_) {
+        if (e.pc->wp_l16 || !e.pc->wp) continue;
+        host.resize(e.n);
+        HIP_OK(hipMemcpy(host.data(), e.pc->wp, e.n * sizeof(float), hipMemcpyDeviceToHost));
+        float* d = upload(repack_conv_weights_l16(host, e.pc->mtiles, e.pc->nchunks, e.pc->kt));
+        if (!d) {
+            err = "hipMalloc failed for the latency kernels' weight copy";
+            return -1;
+        }
+        e.pc->wp_l16 = d;
+    }
+    lat16_ready_ = true;
+    return 0;
 }
 
 bool Engine::validate(const uint8_t* bytes, size_t size, std::string& err) {
