@@ -337,7 +337,7 @@ def test_16bit_kernel_choices_do_not_change_a_single_bit(name):
     for extra in ({"VITS_NO_CONVT16S": "1"}, {"VITS_NO_CONVT16L": "1"}, {"VITS_CONVT16S_ALL": "1"}, {"VITS_NO_RBBLOCK16": "1"}, {"VITS_RBB_C64K11": "1"}, {"VITS_RBB_C128": "0"},
                   {"VITS_NO_FUSE16": "1", "VITS_NO_CONVT16S": "1"}, {"VITS_RB_STREAMS": "1"}, {"VITS_NO_FLOW_FUSE": "1"}, {"VITS_FLOW_NCW": "1"},
                   {"VITS_NO_FLOW_FUSE": "1", "VITS_NO_WN_FUSE": "1"}, {"VITS_NO_FLOW_FUSE": "1", "VITS_WN16_NCW": "2"}, {"VITS_ATT_NW": "8"}, {"VITS_ATT_SHORT": "0"}, {"VITS_NO_LAT16": "1"}, {"VITS_FLOW_NARROW_MAX": "0"}, {"VITS_FLOW_NARROW_MAX": "100000"}, {"VITS_RB16_NARROW_MAX": "0"}, {"VITS_RB16_NARROW_MAX": "100000"}, {"VITS_CONVT16_SPLIT_MAX": "0"}, {"VITS_CONVT16_SPLIT_MAX": "100000"}, {"VITS_RB16_SERIAL_MAX_FRAMES": "0"}, {"VITS_RB16_SERIAL_MAX_FRAMES": "1000000"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "0"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000"}, {"VITS_KEEP_STAGE_SUM32": "1"},
-                  {"VITS_NO_DDS_LAT": "1"}, {"VITS_NO_LN_FUSE": "1"}, {"VITS_NO_DDS_LAT": "1", "VITS_NO_LN_FUSE": "1"}, {"VITS_DDS_LAT_MAX_BLOCKS": "2"},
+                  {"VITS_NO_RB_SUM3": "1"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000", "VITS_RB16_NARROW_MAX": "0"}, {"VITS_NO_DDS_LAT": "1"}, {"VITS_NO_LN_FUSE": "1"}, {"VITS_NO_DDS_LAT": "1", "VITS_NO_LN_FUSE": "1"}, {"VITS_DDS_LAT_MAX_BLOCKS": "2"},
                   {"VITS_KEEP_STAGE_SUM32": "1", "VITS_NO_RBBLOCK16": "1"}, {"VITS_NO_FUSE16": "1"},
                   # the flow as two chains of launches over halves of the batch (default only above 256 blocks per layer: forced here), and never
                   {"VITS_FLOW_CHAIN_MIN_BLOCKS": "0", "VITS_FLOW_NARROW_MAX": "0"}, {"VITS_FLOW_CHAIN_MIN_BLOCKS": "0", "VITS_FLOW_NARROW_MAX": "2"}, {"VITS_FLOW_CHAINS": "1"}):

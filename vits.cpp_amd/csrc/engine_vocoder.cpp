@@ -109,6 +109,10 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         // (small windows — up to four 128-id utterances — run the three resblocks one behind the other: a fork and a join cost ~11 us each per
         // stage, more than the overlap of these short kernels returns: f16 batch 4 2.33 -> 2.18 ms, batch 1 -1 %; from batch 8 on three streams win)
         const bool par = knobs.rb_streams > 1 && nk >= 2 && nk <= 3 && !prof.on && (w.ssum[0] > knobs.rb16_serial_max_frames || w.ssum[0] < knobs.rb16_serial_min_frames);
+        // one or two utterances, every resblock of the stage a whole-resblock kernel: the kernels do NOT chain through the shared sum — each writes its own fp32
+        // output side by side with the others and launch_rb_sum3 adds them in the reference's order (rbblock16.hip; same bits; the C = 32 stage at batch 1:
+        // three chained 15-25 us kernels + two event hand-overs = 105 us, side by side + the sum ~40)
+        const bool sum3 = par && all_block && nk >= 2 && !knobs.kernel.no_rb_sum3 && w.ssum[0] < knobs.rb16_serial_min_frames;
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
@@ -159,7 +163,14 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                     }
                     bytes += 2.0 * n_out;
                 }
-                if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));  // (the accumulation is inside the kernel: the resblocks chain)
+                if (sum3) {  // own output, no accumulation, no scale, no 16-bit copy: launch_rb_sum3 below does those
+                    f.yg = s2.by[q];
+                    f.accg = nullptr;
+                    f.scale = 1.f;
+                    f.scale_div = 0;
+                    f.y16 = Ref16();
+                } else if (par && j > 0)
+                    HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));  // (the accumulation is inside the kernel: the resblocks chain)
                 if (prof.on) {
                     char full[160];
                     std::snprintf(full, sizeof(full), "hifigan_resblock_block|k%d|d135|B%d|e0g|c%dx%d", R.k, C, C, C);
@@ -263,6 +274,14 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
             }
         }
         if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
+        if (sum3) {
+            for (size_t j = 1; j + 1 < nk; ++j) HIP_OK(hipStreamWaitEvent(stream, ev_done_[j], 0));  // (every chain, not only the last: they no longer wait for each other)
+            const bool div = !refmode;
+            prof.begin("hifigan_resblock_sum", 0, (4.0 * nk + 2.0) * n_out, stream);
+            HIP_OK(launch_rb_sum3(s2.by[0], s2.by[1], nk > 2 ? s2.by[2] : nullptr, C, g_bs, g_ts, d_len[st_out], B, smax[st_out], div ? (float)nk : (float)(1.0 / (double)nk), div ? 1 : 0,
+                                  knobs.keep_stage_sum32 ? s2.bs : nullptr, bsum16, i + 1 < n_up ? hp.lrelu : final_slope, arith_now_, stream));
+            prof.end(stream);
+        }
         cur16 = bsum16;
     }
     prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 2.0 * (dec_post_cin_ + 2) * (double)ssum[n_up], stream);

@@ -46,6 +46,7 @@ struct KernelKnobs {
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
     int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
+    bool no_rb_sum3 = false;     // VITS_NO_RB_SUM3: the resblocks of an all-whole-resblock stage always chained through the shared sum (no separate sum launch on small grids)
     int rb16_narrow_max = 128;   // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never; 64 until round 6: batch 4 / 6 -1 ... -2 % with 128)
     int flow_narrow_max = 96;    // VITS_FLOW_NARROW_MAX: 16-bit coupling-layer kernel on 16-frame blocks while the 48-frame tile would give at most this many blocks (0: never)
     bool no_ln_fuse = false;     // VITS_NO_LN_FUSE: the encoder's LayerNorms always as their own launches (never applied on load by the consuming conv_lat16_kernel)
@@ -62,6 +63,7 @@ struct KernelKnobs {
         num("VITS_NARROW_TILES", k.narrow_tiles);
         flag("VITS_NO_DDS_LAT", k.no_dds_lat);
         flag("VITS_NO_LN_FUSE", k.no_ln_fuse);
+        flag("VITS_NO_RB_SUM3", k.no_rb_sum3);
         num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
@@ -316,6 +318,10 @@ struct RbBlock16Call {
 };
 bool rbblock16_supported(int channels, int kt, const int* dils, int ndil);
 hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s);
+// ((y0 + y1) [+ y2]) * scale (or / scale) over fp32 group-layout tensors, in the order and with the expressions of the resblocks' chained accumulation; the fp32 sum
+// (optional) and / or its 16-bit copy behind leaky_relu(y16_slope) — small grids: the resblocks of a stage then need not run one behind the other
+hipError_t launch_rb_sum3(const float* y0, const float* y1, const float* y2, int channels, int64_t g_bs, int g_ts, const int* lens, int batch, int tmax, float scale, int scale_div,
+                          float* yg, Ref16 y16, float y16_slope, int arith, hipStream_t s);
 // fp32 ResBlock conv pair as one kernel (rbpair32.hip): y = x + conv2(leaky_relu(conv1(leaky_relu(x)) + b1)) + b2; y must not alias x
 struct RbPair32Call {
     TensorRef x, y, acc;

@@ -339,6 +339,58 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     RBB_STAMP(5);
 }
 
+// ---- the sum over a stage's resblocks as its own launch (small grids, round 6) ------------------------------------------------------------------------
+// The whole-resblock kernel carries the accumulation into the stage's shared sum itself, so the three resblocks of a narrow stage are a CHAIN of launches in
+// the reference's order of the additions (RB0, += RB1, (+= RB2) * 1/num_kernels: vits.cpp:622-635) — at batch 1 three 15-25 us kernels of 75-100 blocks and two
+// event hand-overs one behind the other (105 us for the C = 32 stage) on a chip that could run them side by side. Here every resblock writes its own fp32
+// output and this kernel adds them in that same order with the same expressions (a + v, then the scale, then leaky_relu and the rounding of the 16-bit copy
+// the next upsampler / conv_post reads): the same bits as the chained accumulation, element for element.
+template <bool BF>
+__global__ __launch_bounds__(256) void rb_sum3_kernel(const float* y0, const float* y1, const float* y2, int64_t g_bs, int g_ts, const int* lens, int tmax, float scale,
+                                                       int scale_div, float* yg, uint16_t* y16, int64_t y16_bs, int y16_ts, float y16_slope) {
+    const int b = blockIdx.z, grp = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    const int64_t go = (int64_t)b * g_bs + ((int64_t)grp * g_ts + t) * 8;
+    float v[8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const rbb::float4v a = *reinterpret_cast<const rbb::float4v*>(y0 + go + 4 * hh), b1 = *reinterpret_cast<const rbb::float4v*>(y1 + go + 4 * hh);
+        rbb::float4v c2 = {0.f, 0.f, 0.f, 0.f};
+        if (y2) c2 = *reinterpret_cast<const rbb::float4v*>(y2 + go + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = a[e] + b1[e];  // (the second resblock's a + v; its scale is 1: v * 1 = v)
+            if (y2) x = x + c2[e];
+            x = scale_div ? x / scale : x * scale;
+            v[4 * hh + e] = x;
+        }
+    }
+    if (yg) {
+        *reinterpret_cast<rbb::float4v*>(yg + go) = rbb::float4v{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<rbb::float4v*>(yg + go + 4) = rbb::float4v{v[4], v[5], v[6], v[7]};
+    }
+    if (y16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * y16_slope);
+        rbb::int4v w;
+        w.x = (int)rbb::pack16<BF>(v[0], v[1]);
+        w.y = (int)rbb::pack16<BF>(v[2], v[3]);
+        w.z = (int)rbb::pack16<BF>(v[4], v[5]);
+        w.w = (int)rbb::pack16<BF>(v[6], v[7]);
+        *reinterpret_cast<rbb::int4v*>(y16 + (int64_t)b * y16_bs + ((int64_t)grp * y16_ts + t) * 8) = w;
+    }
+}
+
+hipError_t launch_rb_sum3(const float* y0, const float* y1, const float* y2, int channels, int64_t g_bs, int g_ts, const int* lens, int batch, int tmax, float scale, int scale_div,
+                          float* yg, Ref16 y16, float y16_slope, int arith, hipStream_t s) {
+    if (!y0 || !y1 || (channels & 7) || (!yg && !y16.p)) return hipErrorInvalidValue;
+    dim3 grid((tmax + 255) / 256, channels / 8, batch);
+    if (arith == VITS_ARITH_BF16) VITS_KLAUNCH(rb_sum3_kernel<true>, grid, dim3(256), 0, s, y0, y1, y2, g_bs, g_ts, lens, tmax, scale, scale_div, yg, y16.p, y16.bs, y16.ts, y16_slope);
+    else VITS_KLAUNCH(rb_sum3_kernel<false>, grid, dim3(256), 0, s, y0, y1, y2, g_bs, g_ts, lens, tmax, scale, scale_div, yg, y16.p, y16.bs, y16.ts, y16_slope);
+    return hipGetLastError();
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
 static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
