@@ -4,7 +4,7 @@ sizes checks the properties the library promises, bit for bit —
   * windowed vocoder == whole vocoder, pipelined submit / wait == process_batch, a second handle == the first,
   * vits_model_process_batch split in two pipelined parts inside the call (the main handle is loaded with VITS_SPLIT_MIN_BATCH=2 and an
     uneven VITS_SPLIT_FIRST_PCT) == the unsplit call of a handle loaded with VITS_SPLIT_MIN_BATCH=0,
-  * 16-bit modes (default scope): durations and frame counts == the fp32 run,
+  * 16-bit modes (default scope) and the split arithmetic (VITS_ARITH_F32_SPLIT): durations and frame counts == the fp32 run,
 and, for the small architecture, float parity with the oracle in the same arithmetic (waveform <= tol x RMS, durations exact).
 usage: python tests/fuzz_identity.py [--trials N] [--seed S] [--no-oracle]"""
 import argparse, os, sys, time
@@ -23,8 +23,8 @@ if not args.no_oracle:
     import oracle_lib as oracle
     oracle.lib()
 rng = np.random.default_rng(args.seed)
-ARITH = {"f32": pkg.ARITH_F32, "f16": pkg.ARITH_F16, "bf16": pkg.ARITH_BF16}
-ORACLE_ARITH = {"f32": 0, "bf16": 1, "f16": 2}  # == oracle_lib.ARITH_*
+ARITH = {"f32": pkg.ARITH_F32, "f16": pkg.ARITH_F16, "bf16": pkg.ARITH_BF16, "f32split": pkg.ARITH_F32_SPLIT}
+ORACLE_ARITH = {"f32": 0, "bf16": 1, "f16": 2, "f32split": 0}  # == oracle_lib.ARITH_*; the split arithmetic (round 6) is held to the fp32 oracle
 models, oracles = {}, {}
 
 
@@ -68,7 +68,7 @@ counts = {"trials": 0, "single": 0, "windowed": 0, "pipelined": 0, "split": 0, "
 worst = 0.0
 for trial in range(args.trials):
     arch = pkg.SYNTH_TINY if rng.random() < 0.4 else pkg.SYNTH_FULL
-    arith = ["f32", "f16", "bf16"][int(rng.integers(3))]
+    arith = ["f32", "f16", "bf16", "f32split"][int(rng.integers(4))]
     mode = int(rng.integers(2))
     B = int(rng.integers(1, 9))
     L = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 40, 64, 130, 300, 700], p=[.05, .05, .05, .1, .15, .2, .15, .1, .08, .04, .02, .01]))
@@ -123,7 +123,7 @@ for trial in range(args.trials):
         assert int(ref["durations"].sum()) == A[2][b], ("frames vs oracle", ctx)
         e = rel_err(A[0][b], ref["waveform"])
         worst = max(worst, e)
-        tol = {"f32": 1e-4, "f16": 5e-3, "bf16": 8e-2}[arith]  # (tests/test_gpu_arith16.py: where a 16-bit rounding flips, the error is one ulp of the 16-bit type)
+        tol = {"f32": 1e-4, "f32split": 1e-4, "f16": 5e-3, "bf16": 8e-2}[arith]  # (tests/test_gpu_arith16.py: where a 16-bit rounding flips, the error is one ulp of the 16-bit type)
         if e >= tol:
             d = np.abs(A[0][b].astype(np.float64) - ref["waveform"].astype(np.float64))
             rms = np.sqrt((ref["waveform"].astype(np.float64) ** 2).mean())
@@ -131,7 +131,7 @@ for trial in range(args.trials):
                   "argmax", int(d.argmax()), ctx, flush=True)
             # a 16-bit rounding that flips between the two implementations moves a handful of samples by up to a few 16-bit ulps of an
             # activation; anything systematic shows in the RMS
-            assert arith != "f32" and e < 3 * tol and np.sqrt((d ** 2).mean()) / rms < tol / 5, ("waveform vs oracle", e, ctx)
+            assert arith not in ("f32", "f32split") and e < 3 * tol and np.sqrt((d ** 2).mean()) / rms < tol / 5, ("waveform vs oracle", e, ctx)
             counts["oracle_isolated_flips"] = counts.get("oracle_isolated_flips", 0) + 1
         counts["oracle"] += 1
     counts["trials"] += 1
