@@ -339,6 +339,11 @@ def test_16bit_kernel_choices_do_not_change_a_single_bit(name):
                   {"VITS_NO_FLOW_FUSE": "1", "VITS_NO_WN_FUSE": "1"}, {"VITS_NO_FLOW_FUSE": "1", "VITS_WN16_NCW": "2"}, {"VITS_ATT_NW": "8"}, {"VITS_ATT_SHORT": "0"}, {"VITS_NO_LAT16": "1"}, {"VITS_FLOW_NARROW_MAX": "0"}, {"VITS_FLOW_NARROW_MAX": "100000"}, {"VITS_RB16_NARROW_MAX": "0"}, {"VITS_RB16_NARROW_MAX": "100000"}, {"VITS_CONVT16_SPLIT_MAX": "0"}, {"VITS_CONVT16_SPLIT_MAX": "100000"}, {"VITS_RB16_SERIAL_MAX_FRAMES": "0"}, {"VITS_RB16_SERIAL_MAX_FRAMES": "1000000"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "0"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000"}, {"VITS_KEEP_STAGE_SUM32": "1"},
                   {"VITS_NO_RB_SUM3": "1"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000", "VITS_RB16_NARROW_MAX": "0"}, {"VITS_NO_DDS_LAT": "1"}, {"VITS_NO_LN_FUSE": "1"}, {"VITS_NO_DDS_LAT": "1", "VITS_NO_LN_FUSE": "1"}, {"VITS_DDS_LAT_MAX_BLOCKS": "2"},
                   {"VITS_KEEP_STAGE_SUM32": "1", "VITS_NO_RBBLOCK16": "1"}, {"VITS_NO_FUSE16": "1"},
+                  # whole-resblock kernels walking segments of 2 / 3 / 8 tiles with the left halo taken from the previous tile (default: per shape and only
+                  # on grids of thousands of blocks — forced here on every shape and from two tiles up), and never
+                  {"VITS_RBB_STREAM_MIN_BLOCKS": "1", "VITS_RBB_STREAM_TILES": "2"}, {"VITS_RBB_STREAM_MIN_BLOCKS": "1", "VITS_RBB_STREAM_TILES": "3"},
+                  {"VITS_RBB_STREAM_MIN_BLOCKS": "1", "VITS_RBB_STREAM_TILES": "8"}, {"VITS_RBB_STREAM_MIN_BLOCKS": "1", "VITS_RBB_STREAM_TILES": "5", "VITS_RBB_C64K11": "1"},
+                  {"VITS_RBB_STREAM_MIN_BLOCKS": "1"}, {"VITS_RBB_STREAM_TILES": "0"},
                   # the flow as two chains of launches over halves of the batch (default only above 256 blocks per layer: forced here), and never
                   {"VITS_FLOW_CHAIN_MIN_BLOCKS": "0", "VITS_FLOW_NARROW_MAX": "0"}, {"VITS_FLOW_CHAIN_MIN_BLOCKS": "0", "VITS_FLOW_NARROW_MAX": "2"}, {"VITS_FLOW_CHAINS": "1"}):
         assert run(extra) == base, extra

@@ -68,7 +68,7 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         bool all_block = nk <= 3;
         for (size_t j = 0; j < nk && j < 3; ++j) {
             const ResBlockW& R = U.rbs[j];
-            bool f = c.fuse16 && !knobs.no_rbblock16 && rbblock16_supported(C, R.k, R.dil.data(), (int)R.dil.size());
+            bool f = c.fuse16 && !knobs.no_rbblock16 && rbblock16_supported(C, R.k, R.dil.data(), (int)R.dil.size(), B, smax[st_out]);
             for (size_t d = 0; d < R.dil.size() && f; ++d) f = R.c1[d].bias && R.c2[d].bias && R.c1[d].wp16 && R.c2[d].wp16;
             blockrb[j] = f;
             all_block = all_block && f;

@@ -39,7 +39,9 @@ struct KernelKnobs {
     int att_short = 512;         // VITS_ATT_SHORT: longest sequence (tokens) for the short-sequence attention variant (0: off)
     int ln_tw = 32;              // VITS_LN_TW=64: LayerNorm tiles of 64 time steps (sixteen waves)
     bool rbb_c128 = true;        // VITS_RBB_C128=0: C = 128, k = 3 resblocks as fused pairs instead of rbblock16
-    bool rbb_c64k11 = false;     // VITS_RBB_C64K11: C = 64, k = 11 resblocks through rbblock16 as well
+    int rbb_c64k11 = -1;         // VITS_RBB_C64K11: C = 64, k = 11 resblocks through rbblock16 as well: 1 always, 0 never (three fused pairs), -1 where the grid is large enough for segments of tiles (VITS_RBB_STREAM_*)
+    int rbb_stream_tiles = -1;   // VITS_RBB_STREAM_TILES: tiles a block of rbblock16 walks with the left halo taken from the previous tile (-1: per shape, see launch_rbb; 0 / 1: always one tile per block, both halos recomputed; N: N for every shape)
+    int rbb_stream_min_blocks = 1536;  // VITS_RBB_STREAM_MIN_BLOCKS: ... while the segments still number at least this many blocks (two rounds of 3 x 256)
     int fuse16_maxc = 256;       // VITS_FUSE16_MAXC: widest stage whose 16-bit conv pairs are fused
     bool fuse32_c128 = true;     // VITS_FUSE32_C128=0: fp32 k = 3 pairs at C = 128 as two launches
     int wn16_ncw = 1;            // VITS_WN16_NCW=2: 16-bit WaveNet layer with six waves, both column tiles each
@@ -81,7 +83,9 @@ struct KernelKnobs {
         num("VITS_ATT_SHORT", k.att_short);
         num("VITS_LN_TW", k.ln_tw);
         if (const char* e = getenv("VITS_RBB_C128")) k.rbb_c128 = atoi(e) != 0;
-        flag("VITS_RBB_C64K11", k.rbb_c64k11);
+        num("VITS_RBB_C64K11", k.rbb_c64k11);
+        num("VITS_RBB_STREAM_TILES", k.rbb_stream_tiles);
+        num("VITS_RBB_STREAM_MIN_BLOCKS", k.rbb_stream_min_blocks);
         num("VITS_FUSE16_MAXC", k.fuse16_maxc);
         if (const char* e = getenv("VITS_FUSE32_C128")) k.fuse32_c128 = atoi(e) != 0;
         num("VITS_WN16_NCW", k.wn16_ncw);
@@ -316,7 +320,7 @@ struct RbBlock16Call {
     float scale = 1.f;
     int scale_div = 0;
 };
-bool rbblock16_supported(int channels, int kt, const int* dils, int ndil);
+bool rbblock16_supported(int channels, int kt, const int* dils, int ndil, int batch, int tmax);  // (batch x tmax: the launch's grid — C = 64, k = 11 only where it is cut into segments)
 hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s);
 // ((y0 + y1) [+ y2]) * scale (or / scale) over fp32 group-layout tensors, in the order and with the expressions of the resblocks' chained accumulation; the fp32 sum
 // (optional) and / or its 16-bit copy behind leaky_relu(y16_slope) — small grids: the resblocks of a stage then need not run one behind the other

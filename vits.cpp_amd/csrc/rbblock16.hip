@@ -13,6 +13,9 @@
 // tiles on four waves, 1.10 / 1.39 x, so that two blocks share a CU: see launch_rbblock16).
 // Same operands, rounding points and k-order of accumulation (chunk, tap, k-half) as rbpair16_kernel / conv16_kernel: bit-identical to
 // the pair path (GPU test), which stays for C >= 128 (MFMA-bound: the halo would cost more than the bytes) and behind VITS_NO_RBBLOCK16=1.
+// Round 6: on grids of thousands of tiles a block walks a SEGMENT of tiles and takes the halo on its left from the tile before
+// (template parameter STREAM; rbb_stream_tiles_for() says where): 1.19 x instead of 1.45 x the MFMA work at k = 11, which also brings the
+// C = 64 / k = 11 resblocks to this kernel.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -71,6 +74,7 @@ struct RbBlockParams {
     float y16_slope;
     float scale;
     int scale_div;
+    int nt;  // STREAM: tiles a block walks (its segment = W - 2 H + (nt - 1) (W - H) output columns)
 };
 
 #ifdef VITS_PHASE_TIMING  // developer instrumentation (tools/rb16_micro.hip)
@@ -88,34 +92,86 @@ __device__ unsigned long long vits_rbb_phase[16 * 65536];
 
 // Block = NSTRIP column strips x C / (32 MRW) row groups of waves; wave (strip, rg) owns the MRW row tiles [MRW rg, MRW rg + MRW) (32 rows each)
 // of the NRW 32-column tiles of its strip.
-template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF>
+// STREAM (round 6; large grids): the block WALKS a segment of p.nt tiles from left to right and the halo on the LEFT of every tile but the
+// first is not recomputed: each of the six convs finds the columns in front of the tile — P2 D_p of x_p, P2 of t_p — where the previous
+// tile left them (`hist`, copied out of the LDS tile while that stage was in it and into the padding in front of the tile when the stage is
+// written again). A tile then yields W - H outputs instead of W - 2 H (k = 11 at W = 384: 1.19 x the algorithmic MFMA work instead of
+// 1.45 x; k = 7: 1.10 / 1.23). The halo on the right stays: without it the fp32 stream in the registers would have to lag from pair to pair
+// (a 32-column tile handed from wave to wave through LDS per pair: 16-28 KB, one block per CU fewer). Every element is the same chain of
+// operations on the same operands whichever tile computes it, and a history column is the value its tile computed: bit-identical to the
+// one-tile form (GPU test), which stays for grids too small to be cut into segments.
+template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF, bool STREAM>
 __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : (C / (32 * MRW) * NSTRIP <= 4 ? 2 : 1)) void rbblock16_kernel(const RbBlockParams p) {
     using namespace rbb;
     constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
     constexpr int P2 = (KT - 1) / 2;
     constexpr int DMAX = D0 > D1 ? (D0 > D2 ? D0 : D2) : (D1 > D2 ? D1 : D2);
     constexpr int H = P2 * (3 + D0 + D1 + D2);  // halo per side: every pair costs P2 (second conv) + P2 * D_p (first conv)
-    constexpr int BO = W - 2 * H;               // output columns per block
+    constexpr int BO = W - 2 * H;               // output columns of a (first) tile
+    constexpr int ADV = W - H;                  // STREAM: distance between the tiles of a segment = output columns of every later tile
     constexpr int PADX = P2 * DMAX;             // the first conv of a pair reads up to P2 * D_p columns beyond a tile column
     constexpr int PITCH = (W + 2 * PADX + 7) / 8 * 8;
     constexpr int STEPS = 2 * KT, TOTAL = NCH * STEPS;
+    constexpr int G = C / 8;
     static_assert(BO > 0, "tile too narrow for this kernel size");
     extern __shared__ __attribute__((aligned(16))) int4v tile[];  // [G][PITCH] slots of 8 x 16 bit: x_p, then t_p, then x_{p+1}, ...
     // behind the tile: the biases of the six convs, [pair][b1 | b2][C] fp32 — read from LDS where they are added (fetched from memory
     // behind each conv they cost an exposed L2 round trip per conv: six per block, which the short k = 3 blocks notice)
-    float* lbias = reinterpret_cast<float*>(tile + (C / 8) * PITCH);
+    float* lbias = reinterpret_cast<float*>(tile + G * PITCH);
+    // STREAM: behind the biases the histories, [x_0 | t_0 | x_1 | t_1 | x_2 | t_2], stage q as [G][h_q] slots
+    int4v* hist = tile + G * PITCH + 6 * C * (int)sizeof(float) / 16;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: strip / row group live in scalar registers)
     const int strip = wid % NSTRIP, rt0 = (wid / NSTRIP) * MRW;
     const int b = blockIdx.y;
     const int len = p.lens ? p.lens[b] : p.tmax;
-    const int t0 = blockIdx.x * BO;
-    if (t0 >= len) return;
+    const int nt = STREAM ? p.nt : 1;
+    const int seg0 = blockIdx.x * (BO + (nt - 1) * ADV);
+    if (seg0 >= len) return;
     RBB_STAMP(0);
-    const int h = lane >> 5, col = lane & 31;
-    const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
-    const int tg0 = t0 - H;                   // global time of tile column 0
     typedef const __attribute__((address_space(3))) int4v* LdsV;
+    typedef __attribute__((address_space(3))) int4v* LdsS;
+    // (the biases: requested in front of the first stream loads, so that the two round trips overlap)
+    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
+        const int pi = i / (2 * C), r = i - pi * 2 * C;
+        lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
+    }
+    constexpr int HX0 = 0, HT0 = HX0 + P2 * D0, HX1 = HT0 + P2, HT1 = HX1 + P2 * D1, HX2 = HT1 + P2, HT2 = HX2 + P2 * D2;  // column offsets of the histories
+    static_assert(HT2 + P2 == H, "the histories are the halo of one side");
+    static_assert(!STREAM || G * P2 * DMAX <= C / (32 * MRW) * NSTRIP * 64, "one history slot per thread");
+
+  for (int it = 0; it < nt; ++it) {
+    // (STREAM: every per-lane address below is derived from an opaque copy of the lane id — left to itself the compiler hoists the
+    // invariant halves of ~50 addresses out of the tile loop and spills 120 registers to keep them)
+    int lane_v = lane;
+    if constexpr (STREAM) asm volatile("" : "+v"(lane_v));
+    const int h = lane_v >> 5, col = lane_v & 31;
+    const int tid = wid * 64 + lane_v;
+    const int u0 = strip * (NRW * 32) + col;  // this lane's tile column of column tile nr: u0 + 32 nr
+    const int tg0 = seg0 - H + it * ADV;  // global time of tile column 0
+    // history of a stage: `hq` columns in front of the NEXT tile (tile columns [ADV - hq, ADV)) out of the LDS tile, once the stage is
+    // complete in it; and back in front of the tile (slots [PADX - hq, PADX)) when the next tile writes that stage
+    auto hist_save = [&](const int off, const int hq) __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            if (tid < G * hq) {
+                const int g = tid / hq, c = tid - g * hq;
+                const int4v v = *((LdsV)(tile + g * PITCH + PADX + ADV - hq + c));
+                *((LdsS)(hist + G * off + tid)) = v;
+            }
+        }
+    };
+    auto hist_restore = [&](const int off, const int hq, const bool on) __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            if (on && tid < G * hq) {
+                const int g = tid / hq, c = tid - g * hq;
+                const int4v v = *((LdsV)(hist + G * off + tid));
+                *((LdsS)(tile + g * PITCH + PADX - hq + c)) = v;
+            }
+        }
+    };
+    const int ulo = it == 0 ? H : 0;      // the tile's own outputs: columns [ulo, ADV)
+    if (tg0 + ulo >= len) break;
+    if (it > 0) __syncthreads();  // every wave is done with the previous tile's t_2
 
     // ---- the fp32 stream of this wave's rows x columns, in the MFMA C layout: register 4 g + e of yv[m][nr] = channel 32 (rt0 + m) + 8 g + 4 h + e ----
     floatx16 yv[MRW][NRW];
@@ -136,14 +192,8 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                 }
             }
     }
-    // (the biases: requested behind the stream loads, so that the two round trips overlap)
-    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
-        const int pi = i / (2 * C), r = i - pi * 2 * C;
-        lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
-    }
     // round(leaky_relu(src + bias)) of this wave's rows x columns into the LDS tile as whole 16-byte slots, zero outside the sequence (what a
     // conv sees as padding): x_p from the stream (bias = nullptr), t_p from the first conv's accumulators
-    typedef __attribute__((address_space(3))) int4v* LdsS;
     auto write_tile = [&](const floatx16 (&src)[MRW][NRW], const float* bias_p) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MRW; ++m)
@@ -195,7 +245,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
         int wvoff[MRW];
 #pragma unroll
-        for (int m = 0; m < MRW; ++m) wvoff[m] = (int)(((size_t)(rt0 + m) * TOTAL * 64 + lane) * 16);
+        for (int m = 0; m < MRW; ++m) wvoff[m] = (int)(((size_t)(rt0 + m) * TOTAL * 64 + lane_v) * 16);
         auto load_a = [&](int m, int step) __attribute__((always_inline)) -> int4v {
             return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff[m], step * 1024, 0));
         };
@@ -240,12 +290,16 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
         }
     };
 
-    auto pair = [&](const int pi, const int dil, const bool last) __attribute__((always_inline)) {
+    // (hx / ht: history offsets of x_p and t_p; hxn, dn: offset and dilation of the next pair's x)
+    auto pair = [&](const int pi, const int dil, const bool last, const int hx, const int ht, const int hxn, const int dn) __attribute__((always_inline)) {
+        hist_save(hx, P2 * dil);  // (x_p is complete in the tile: what the next tile's first conv reads in front of its columns)
         // conv 1 over x_p: t column u reads x columns u - P2 dil + j dil
         conv(p.w1[pi], -P2 * dil, dil);
         __syncthreads();  // every wave is done with x_p: t_p takes its place
         write_tile(acc, lbias + pi * 2 * C);  // t = round(leaky_relu(conv1 + b1)), zero outside the sequence (the second conv's padding)
+        hist_restore(ht, P2, it > 0);
         __syncthreads();
+        hist_save(ht, P2);
         // conv 2 over t_p: y column u reads t columns u - P2 + j
         conv(p.w2[pi], -P2, 1);
         // the stream: y_{p+1} = y_p + (conv2 + b2)
@@ -266,18 +320,20 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
         if (!last) {
             __syncthreads();  // every wave is done with t_p: x_{p+1} takes its place
             write_tile(yv, nullptr);
+            hist_restore(hxn, P2 * dn, it > 0);
             __syncthreads();
         }
     };
 
     write_tile(yv, nullptr);
+    hist_restore(HX0, P2 * D0, it > 0);
     __syncthreads();
     RBB_STAMP(1);
-    pair(0, D0, false);
+    pair(0, D0, false, HX0, HT0, HX1, D1);
     RBB_STAMP(2);
-    pair(1, D1, false);
+    pair(1, D1, false, HX1, HT1, HX2, D2);
     RBB_STAMP(3);
-    pair(2, D2, true);
+    pair(2, D2, true, HX2, HT2, 0, 1);
     RBB_STAMP(4);
 
     // ---- epilogue (as the last pair's in rbpair16_kernel): resblock sum / scale, fp32 output + 16-bit copy, the BO owned columns only ----
@@ -285,11 +341,23 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     // dependent HBM round trips — the compiler may not move a later load above an earlier store that could alias it (the WaveNet kernels
     // spent 15 of 48 us that way). All addends first (the conv accumulators are dead: their registers hold them), then every store.
     {
+        // (STREAM: addresses from a second opaque copy of the lane id — shared with the loads at the top of the tile they would be kept, and spilled, across the six convs)
+        int lane_e = lane;
+        if constexpr (STREAM) asm volatile("" : "+v"(lane_e));
+        const int h = lane_e >> 5, u0 = strip * (NRW * 32) + (lane_e & 31);
         float* yg = p.yg ? p.yg + (int64_t)b * p.g_bs : nullptr;  // (null: only the 16-bit copy is wanted — the last resblock of a stage)
         const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
         uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
         float4v av[MRW][4][NRW];
         __builtin_amdgcn_sched_barrier(0);  // (not above the last conv: its accumulators have to be dead for these registers)
+        if constexpr (STREAM) {  // (defined on every path: left undefined without an accumulator they become loop-carried values of the tile loop, 40 spilled registers)
+#pragma unroll
+            for (int m = 0; m < MRW; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int nr = 0; nr < NRW; ++nr) av[m][g][nr] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
         if (ag) {
 #pragma unroll
             for (int m = 0; m < MRW; ++m)
@@ -300,7 +368,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                     for (int nr = 0; nr < NRW; ++nr) {
                         const int u = u0 + 32 * nr, t = tg0 + u;
                         av[m][g][nr] = float4v{0.f, 0.f, 0.f, 0.f};
-                        if (u >= H && u < H + BO && t < len) av[m][g][nr] = *reinterpret_cast<const float4v*>(ag + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
+                        if (u >= ulo && u < ADV && t < len) av[m][g][nr] = *reinterpret_cast<const float4v*>(ag + ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7));
                     }
                 }
         }
@@ -312,7 +380,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
 #pragma unroll
                 for (int nr = 0; nr < NRW; ++nr) {
                     const int u = u0 + 32 * nr, t = tg0 + u;
-                    if (u < H || u >= H + BO || t >= len) continue;
+                    if (u < ulo || u >= ADV || t >= len) continue;
                     const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
                     float v[4];
 #pragma unroll
@@ -336,6 +404,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
                 }
             }
     }
+  }  // (tiles of the segment)
     RBB_STAMP(5);
 }
 
@@ -392,30 +461,55 @@ hipError_t launch_rb_sum3(const float* y0, const float* y1, const float* y2, int
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
-static hipError_t launch_rbb(const RbBlockParams& p, int batch, hipStream_t s) {
+template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF, bool STREAM>
+static hipError_t launch_rbb_grid(const RbBlockParams& p, int seg_out, int batch, hipStream_t s) {
     constexpr int D0 = 1, D1 = 3, D2 = 5;
-    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), BO = W - 2 * H, PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
-    const size_t lds = (size_t)(C / 8) * PITCH * 16 + (size_t)6 * C * sizeof(float);
+    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * (3 + D0 + D1 + D2), PADX = P2 * D2, PITCH = (W + 2 * PADX + 7) / 8 * 8;
+    const size_t lds = (size_t)(C / 8) * PITCH * 16 + (size_t)6 * C * sizeof(float) + (STREAM ? (size_t)(C / 8) * H * 16 : 0);
     static BigLdsOnce big_lds_set;
     if (lds > 64 * 1024 && big_lds_set.needed()) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF, STREAM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return ea;
         big_lds_set.done();
     }
-    dim3 grid((p.tmax + BO - 1) / BO, batch);
-    VITS_KLAUNCH((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
+    dim3 grid((p.tmax + seg_out - 1) / seg_out, batch);
+    VITS_KLAUNCH((rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF, STREAM>), grid, dim3(C / (32 * MRW) * NSTRIP * 64), lds, s, p);
     return hipGetLastError();
 }
+// Tiles per block for a launch of `batch` sequences of up to `tmax` columns on tiles of W columns.
+// Segments of several tiles (STREAM) once the one-tile grid is many rounds of the chip: a segment's first tile pays the halo of both sides,
+// and the blocks of the last round run on a partly empty chip — nt grows with the grid up to the shape's limit.
+// Which shapes: measured per kernel on the benchmark batch (64 x 128 ids: 10-14 thousand tiles, i.e. 13-18 per resident block, so that long
+// segments cost in balance what they save in halo — tools/rbb_micro.hip, profiles/round6_rbb_stream_micro.txt): k = 11 at C = 32
+// 1.000 -> 0.892 ms with 6 tiles, k = 7 at C = 64 1.138 -> 1.040 with 3, k = 11 at C = 64 1.584 -> 1.396 with 4; k = 3 (a halo of 12
+// columns) and k = 7 at C = 32 lose 0-25 %: one tile per block there.
+static int rbb_stream_tiles_for(int kt, int C, int W, int batch, int tmax) {
+    const KernelKnobs& kn = kernel_knobs();
+    const int H = (kt - 1) / 2 * 12, BO = W - 2 * H;
+    const long blocks1 = (long)((tmax + BO - 1) / BO) * batch;
+    int want = kn.rbb_stream_tiles;
+    if (want < 0) want = (kt == 11 && C == 32) ? 6 : (kt == 7 && C == 64) ? 3 : (kt == 11 && C == 64) ? 4 : 0;
+    if (want <= 1 || kn.rbb_stream_min_blocks <= 0 || blocks1 < 2L * kn.rbb_stream_min_blocks) return 1;
+    return (int)(blocks1 / kn.rbb_stream_min_blocks < want ? blocks1 / kn.rbb_stream_min_blocks : want);
+}
+template <int KT, int C, int NSTRIP, int NRW, int MRW, bool BF>
+static hipError_t launch_rbb(RbBlockParams p, int batch, hipStream_t s) {
+    constexpr int P2 = (KT - 1) / 2, W = NSTRIP * NRW * 32, H = P2 * 12, BO = W - 2 * H, ADV = W - H;
+    const int nt = rbb_stream_tiles_for(KT, C, W, batch, p.tmax);
+    p.nt = nt;
+    if (nt > 1) return launch_rbb_grid<KT, C, NSTRIP, NRW, MRW, BF, true>(p, BO + (nt - 1) * ADV, batch, s);
+    return launch_rbb_grid<KT, C, NSTRIP, NRW, MRW, BF, false>(p, BO, batch, s);
+}
 
-bool rbblock16_supported(int channels, int kt, const int* dils, int ndil) {
+bool rbblock16_supported(int channels, int kt, const int* dils, int ndil, int batch, int tmax) {
     const bool c128 = kernel_knobs().rbb_c128;
     if (channels == 128) return c128 && kt == 3 && ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
     if (!(channels == 32 || channels == 64) || !(kt == 3 || kt == 7 || kt == 11)) return false;
-    // C = 64, k = 11: with 1.45 x the MFMA work the whole-resblock kernel is bound by the matrix cores (at the clock the power budget
-    // leaves them) and loses to three fused pairs, 1.59 against 1.45 ms per step (batch 64 x 128 ids); VITS_RBB_C64K11=1 runs it anyway
-    const bool c64k11 = kernel_knobs().rbb_c64k11;
-    if (channels == 64 && kt == 11 && !c64k11) return false;
+    // C = 64, k = 11: on one tile per block (1.45 x the MFMA work) the whole-resblock kernel is bound by the matrix cores (at the clock
+    // the power budget leaves them) and loses to three fused pairs, 1.59 against 1.45 ms per step (batch 64 x 128 ids); on segments of four
+    // tiles (1.19 x; round 6) it wins, 13.31 -> 13.19 ms per pipelined batch. VITS_RBB_C64K11=1 runs it on every grid, =0 on none.
+    const int c64k11 = kernel_knobs().rbb_c64k11;
+    if (channels == 64 && kt == 11 && !(c64k11 > 0 || (c64k11 < 0 && rbb_stream_tiles_for(11, 64, 384, batch, tmax) > 1))) return false;
     return ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
 }
 
@@ -432,7 +526,7 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
         p.b2[i] = c2[i]->bias;
     }
     const int dils[3] = {1, 3, 5};
-    if (!rbblock16_supported(C, kt, dils, 3) || !c.y0 || (!c.yg && !c.y16.p)) return hipErrorInvalidValue;
+    if (!rbblock16_supported(C, kt, dils, 3, c.batch, c.tmax) || !c.y0 || (!c.yg && !c.y16.p)) return hipErrorInvalidValue;
     p.y0 = c.y0;
     p.lens = c.lens;
     p.tmax = c.tmax;
