@@ -3,7 +3,8 @@ sizes checks the properties the library promises, bit for bit —
   * a row of a ragged batch == the same utterance alone (noise stream keyed by seed + row),
   * windowed vocoder == whole vocoder, pipelined submit / wait == process_batch, a second handle == the first,
   * vits_model_process_batch split in two pipelined parts inside the call (the main handle is loaded with VITS_SPLIT_MIN_BATCH=2 and an
-    uneven VITS_SPLIT_FIRST_PCT) == the unsplit call of a handle loaded with VITS_SPLIT_MIN_BATCH=0,
+    uneven VITS_SPLIT_FIRST_PCT) == the unsplit call of a handle loaded with VITS_SPLIT_MIN_BATCH=0 — whose whole-resblock kernels also walk
+    segments of three tiles (VITS_RBB_STREAM_*: random lengths put the sequence end anywhere in a segment),
   * 16-bit modes (default scope) and the split arithmetic (VITS_ARITH_F32_SPLIT): durations and frame counts == the fp32 run,
 and, for the small architecture, float parity with the oracle in the same arithmetic (waveform <= tol x RMS, durations exact).
 usage: python tests/fuzz_identity.py [--trials N] [--seed S] [--no-oracle]"""
@@ -36,10 +37,13 @@ def model(arch, arith, ref=False):
         # (knobs are read when a model is loaded) main handle: every batch of two or more is split 37 : 63; ref / "unsplit" handles: never
         os.environ["VITS_SPLIT_MIN_BATCH"] = "0" if ref else "2"
         os.environ["VITS_SPLIT_FIRST_PCT"] = "37"
+        if ref == "unsplit":  # ... and its whole-resblock kernels (16-bit modes) walk segments of three tiles from two tiles up, the main handle's one tile per block at these sizes
+            os.environ["VITS_RBB_STREAM_MIN_BLOCKS"], os.environ["VITS_RBB_STREAM_TILES"] = "1", "3"
         try:
             models[key] = [pkg.Model(pkg.synth_model_bytes(0x5EED, arch)), "f32", False]
         finally:
             del os.environ["VITS_SPLIT_MIN_BATCH"], os.environ["VITS_SPLIT_FIRST_PCT"]
+            os.environ.pop("VITS_RBB_STREAM_MIN_BLOCKS", None), os.environ.pop("VITS_RBB_STREAM_TILES", None)
     e = models[key]
     if e[1] != arith:
         e[0].set_arith(ARITH[arith])
@@ -97,8 +101,8 @@ for trial in range(args.trials):
         same(([A[0][b]], A[1][b:b + 1], A[2][b:b + 1]), one, "row alone", ctx)
         counts["single"] += 1
     # the call split in two pipelined parts (this handle, B >= 2) == the unsplit call
-    if B >= 2:
-        same(A, unsplit.process_batch(ids, **kw), "split in two", ctx)
+    if B >= 2 or arith in ("f16", "bf16"):
+        same(A, unsplit.process_batch(ids, **kw), "split in two / segments of tiles", ctx)
         counts["split"] += 1
     # windowed vocoder
     same(A, m.process_batch(ids, vocoder_chunk_frames=chunk, **kw), "windowed", ctx)

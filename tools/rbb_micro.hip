@@ -59,6 +59,26 @@ int main() {
     f.g_bs = (int64_t)C * ts;
     f.g_ts = ts;
     f.scale = 1.f;
+#ifdef RB2_  // the LAST resblock of a stage: sum so far read, scaled by 1 / num_kernels, only the 16-bit copy written
+    f.yg = nullptr;
+    f.y16.p = dy16;
+    f.y16.bs = (int64_t)C * ts;
+    f.y16.ts = ts;
+    f.y16_slope = 0.1f;
+    f.scale = 3.f;
+    f.scale_div = 1;
+#endif
+#ifdef RB0_  // the FIRST resblock of a stage: no sum to read
+    f.accg = nullptr;
+#endif
+#ifdef RAGGED_  // lengths between 60 and 100 % of T (the benchmark batch's predicted durations spread like that)
+    std::vector<int> hl(B);
+    for (int i = 0; i < B; ++i) hl[i] = (int)((0.6 + 0.4 * ((i * 37) % B) / (double)(B - 1)) * T);
+    int* dl;
+    hipMalloc(&dl, B * 4);
+    hipMemcpy(dl, hl.data(), B * 4, hipMemcpyHostToDevice);
+    f.lens = dl;
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
