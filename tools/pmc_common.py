@@ -12,8 +12,9 @@ _CONV16 = re.compile(r"conv16_kernel<(-?\d+), (-?\d+), (\d+), (\d+), (\d+), (\d+
 _WAVENET16 = re.compile(r"wavenet16_kernel<(\d+), (\d+), (\w+)(?:, \d+)?>")
 _COUPLE16 = re.compile(r"flow_couple16_kernel<(\w+)(?:, \d+)*>")
 _WAVENET32 = re.compile(r"wavenet32_kernel<(\d+), (\d+)>")
-# rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF> (block-shape parameters between C and the dilations: any number of them)
-_RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+)(?:, \d+)*?, (\d+), (\d+), (\d+), (\w+)>")
+# rbblock16_kernel<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF[, STREAM]> (block-shape parameters between C and the dilations: any number of them)
+_RBBLOCK16 = re.compile(r"rbblock16_kernel<(-?\d+), (\d+)(?:, \d+)*?, (\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>")
+_SPLIT = re.compile(r"conv_split_kernel<(-?\d+), (-?\d+), (\d+)>")
 _CONVT16 = re.compile(r"convt16_kernel<(\d+), (\d+), (\d+), (\w+)>")
 _CONVT16L = re.compile(r"convt16_lines_kernel<(\d+), (\w+)>")
 _RBBLOCK32 = re.compile(r"rbblock32_kernel<(\d+), (\d+)>")
@@ -55,6 +56,10 @@ def bench_key(kernel_name):
     if m:  # `rbblock16_kernel<11, 32, 4, 3, 1, 1, 3, 5, false>` -> `k11|d135|B32|e0g`
         kt, c, d0, d1, d2, _ = m.groups()
         return f"k{kt}|d{d0}{d1}{d2}|B{c}|e0g"
+    m = _SPLIT.search(kernel_name)
+    if m:  # `conv_split_kernel<11, 1, 4>` -> `k11|d1|S128|e0` (VITS_ARITH_F32_SPLIT: 128-row tiles; the engine prints the same tag)
+        kt, dil, wm = m.groups()
+        return f"k{kt}|d{dil}|S128|e0" if int(wm) == 4 else None
     m = _RBBLOCK32.search(kernel_name)
     if m:  # `rbblock32_kernel<32, 2>` -> `k3|d135|b32|e0` (whole 3-tap resblock, fp32)
         return f"k3|d135|b{m.group(1)}|e0"
