@@ -823,6 +823,7 @@ int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int ba
 
 hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
     if (!w.wp16) return hipErrorInvalidValue;
+    if (conv16_lat_wanted(w, c)) return launch_conv16_lat(w, c, arith, s);  // (small grids of the wide vocoder stages: conv16_lat.hip)
     Conv16Params p;
     p.x = c.x.p;
     p.x_bs = c.x.bs;

@@ -1,0 +1,308 @@
+// conv16_lat.hip — the 16-bit-operand ResBlock convs of the WIDE vocoder stages (C = 128 / 256) on SMALL grids (batch 1 ... 4: config 2, the
+// reference's own use), round 6.
+//     t = round(leaky_relu(Conv_{k,d}(x) + b1))            (group epilogue, 16-bit output)      (/root/reference/src/vits.cpp:556-567)
+//     y' = y + Conv_{k,1}(t) + b2 [, resblock sum / scale]  (group epilogue, fp32 stream + copy)  (vits.cpp:568-581, 622-635)
+// Why: at one utterance a C = 256 stage is 1,792 columns. As ONE fused kernel per pair (rbpair16.hip) that is 28-32 blocks, each of which
+// pulls both convs' weights — 2.9 MB at k = 11 — through ONE compute unit's path to L2 at 57-75 GB/s: 40-48 us per pair, three pairs per
+// resblock one behind the other, 220 of the chip's 256 CUs idle (profiles/round6_b1_f16_timeline.txt). conv16_kernel (the throughput
+// kernel: LDS ring, producer wave, a barrier per 32-channel chunk) takes 17-21 us per conv on such a grid. Here a conv is dealt out as
+// (row tile pair, 32 or 64 columns) blocks — 224-448 of them — so that every CU streams 90-360 KB of weights instead of 2.9 MB:
+//   * the whole input tile [C/8 groups][32 NR + (k-1) d slots] goes to LDS in ONE shot (LDS-DMA, all waves), no barrier inside the K loop;
+//   * a wave owns one 32-row tile x NR 32-column tiles; its A fragments come straight from memory through a ring of 16 (fetched 14 steps
+//     ahead: the weights of a batch-1 step are not in L2);
+//   * K order = (chunk, tap, k-half) on v_mfma_f32_32x32x16_{f16,bf16}, epilogue = conv16_kernel's group epilogue expression for
+//     expression: bit-identical to conv16_kernel / rbpair16_kernel / rbblock16_kernel (kernel-choice test).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/vits.h"
+#include "kernels.h"
+
+namespace vits {
+
+namespace c16l {
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ unsigned pack16(float a, float b) {
+    float2v f = {a, b};
+    if constexpr (BF) return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2v));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, half2v));
+}
+}  // namespace c16l
+
+struct Conv16LatParams {
+    const uint16_t* x;  // group layout [b][C/8][x_ts][8], already activated
+    int64_t x_bs;
+    int x_ts;
+    const uint16_t* wp;  // A fragments (pack_conv_weights16)
+    const float* bias;
+    const int* lens;
+    int tmax;
+    int dil, pad_l, pitch;
+    float* yg;
+    const float* resg;
+    const float* accg;
+    int64_t g_bs;
+    int g_ts;
+    uint16_t* y16;
+    int64_t y16_bs;
+    int y16_ts;
+    float y16_slope;
+    float scale;
+    int scale_div;
+};
+
+// Block = WM waves = WM consecutive 32-row tiles of the same 32 NR columns.
+template <int KT, int C, int WM, int NR, bool BF>
+__global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatParams p) {
+    using namespace c16l;
+    constexpr int G = C / 8, NCH = C / 32, STEPS = 2 * KT, TOTAL = NCH * STEPS, BN = 32 * NR;
+    extern __shared__ __attribute__((aligned(16))) int4v xs[];  // [G][pitch] slots of 8 x 16 bit; slot s of a row <-> time t0 - pad_l + s
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z, t0 = blockIdx.x * BN;
+    const int len = p.lens ? p.lens[b] : p.tmax;
+    if (t0 >= len) return;
+    const int rt = blockIdx.y * WM + wid;  // this wave's 32-row tile
+    const int h = lane >> 5;
+    const int pitch = p.pitch, dil = p.dil;
+    typedef const __attribute__((address_space(3))) int4v* LdsV;
+
+    // ---- the weight stream: requested first, so that its first round trip and the fill's are one ----
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = (int)(((size_t)rt * TOTAL * 64 + lane) * 16);
+    auto load_a = [&](int step) __attribute__((always_inline)) -> int4v {
+        return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, step * 1024, 0));
+    };
+    constexpr int RS = 16, RD = RS - 2;
+    int4v ring[RS];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) ring[i] = load_a(i < TOTAL ? i : TOTAL - 1);
+
+    // ---- the epilogue's operands — residual, resblock sum, bias — requested NOW: behind the K loop they were a second exposed round trip ----
+    const int colbase = t0 + (lane & 31);
+    const int rowoff = 4 * h;
+    float* yg = p.yg ? p.yg + (int64_t)b * p.g_bs : nullptr;
+    const float* rg = p.resg ? p.resg + (int64_t)b * p.g_bs : nullptr;
+    const float* ag = p.accg ? p.accg + (int64_t)b * p.g_bs : nullptr;
+    uint16_t* y16 = p.y16 ? p.y16 + (int64_t)b * p.y16_bs : nullptr;
+    float4v rv[4][NR], av[4][NR], bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch0 = rt * 32 + 8 * g + rowoff;
+        bias4[g] = float4v{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4[g] = *reinterpret_cast<const float4v*>(p.bias + ch0);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int t = colbase + nr * 32;
+            rv[g][nr] = float4v{0.f, 0.f, 0.f, 0.f};
+            av[g][nr] = float4v{0.f, 0.f, 0.f, 0.f};
+            const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+            if (rg && t < len) rv[g][nr] = *reinterpret_cast<const float4v*>(rg + go);
+            if (ag && t < len) av[g][nr] = *reinterpret_cast<const float4v*>(ag + go);
+        }
+    }
+
+    // ---- the input tile, all groups, straight into LDS ----
+    {
+        const uint16_t* xb = p.x + (int64_t)b * p.x_bs;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, 0x7fffffff, 0x00020000);
+        const int tx0 = t0 - p.pad_l;
+        const int xw = BN + (KT - 1) * dil;  // slots a row holds (<= pitch)
+        constexpr int NP = 2;  // 64-slot pieces per row: (k - 1) d <= 50. (A literal: hipcc 7.2 drops the kernel's host stub when an array sized by a template-dependent expression meets the LDS-DMA builtin.)
+        static_assert((BN + 50 + 63) / 64 <= NP, "row pieces");
+        int voff[NP];
+        bool in[NP], oob[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int t = tx0 + lane + 64 * m;
+            const int tc = t < 0 ? 0 : (t < len ? t : len - 1);
+            voff[m] = tc * 16;
+            in[m] = 64 * m + lane < xw;
+            oob[m] = t != tc;
+        }
+#pragma unroll
+        for (int gi = 0; gi < G / WM; ++gi) {
+            const int g = wid + WM * gi;
+            const unsigned soff = (unsigned)g * (unsigned)p.x_ts * 16u;
+#pragma unroll
+            for (int m = 0; m < NP; ++m)
+                if (in[m]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(xs + g * pitch + 64 * m), 16, voff[m], (int)soff, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tx0 < 0 || tx0 + xw > len) {  // sequence ends: the conv's zero padding
+            const int4v z = {0, 0, 0, 0};
+#pragma unroll
+            for (int gi = 0; gi < G / WM; ++gi) {
+                const int g = wid + WM * gi;
+#pragma unroll
+                for (int m = 0; m < NP; ++m)
+                    if (in[m] && oob[m]) xs[g * pitch + 64 * m + lane] = z;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    auto mfma = [&](int4v a, int4v bq, floatx16 c) __attribute__((always_inline)) -> floatx16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, bq), c, 0, 0, 0);
+    };
+    floatx16 acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // output column u reads slots u + j dil of group rows (4 c + 2 kk + h): the (chunk, tap, k-half) nest of conv16_kernel / rbpair16_kernel
+    {
+        LdsV base = (LdsV)(xs + h * pitch + (lane & 31));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            LdsV xb = base + c * 4 * pitch;
+            int4v b_nxt[NR];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[nr * 32];
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int s = c * STEPS + j * 2 + kk;  // compile time after unrolling
+                    ring[(s + RD) % RS] = load_a(s + RD < TOTAL ? s + RD : TOTAL - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    int4v b_cur[NR];
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) b_cur[nr] = b_nxt[nr];
+                    {
+                        // next step: the other k-half of this tap, or k-half 0 of the next tap (past the last tap of a chunk: a slot a little further on, unused)
+                        const int noff = kk == 0 ? 2 * pitch + j * dil : (j + 1) * dil;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) b_nxt[nr] = xb[noff + nr * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[nr] = mfma(ring[s % RS], b_cur[nr], acc[nr]);
+                }
+        }
+    }
+
+    // ---- epilogue: conv16_kernel's group epilogue (MR = 1): this lane owns channels ch0 .. ch0 + 3 of one time step per group ----
+    // (no block of this launch reads what another writes: the residual / sum may alias the output element for element only)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch0 = rt * 32 + 8 * g + rowoff;
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int t = colbase + nr * 32;
+            if (t >= len) continue;
+            const int64_t go = ((int64_t)(ch0 >> 3) * p.g_ts + t) * 8 + (ch0 & 7);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[nr][4 * g + e] + bias4[g][e];
+                if (rg) v[e] = rv[g][nr][e] + v[e];
+            }
+            if (ag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = av[g][nr][e] + v[e];
+                    v[e] = p.scale_div ? v[e] / p.scale : v[e] * p.scale;
+                }
+            }
+            if (yg) *reinterpret_cast<float4v*>(yg + go) = float4v{v[0], v[1], v[2], v[3]};
+            if (y16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.y16_slope);  // slope 1 = identity
+                int2v w2;
+                w2.x = (int)pack16<BF>(v[0], v[1]);
+                w2.y = (int)pack16<BF>(v[2], v[3]);
+                *reinterpret_cast<int2v*>(y16 + ((int64_t)(ch0 >> 3) * p.y16_ts + t) * 8 + (ch0 & 7)) = w2;
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+// Which convs: the group-layout ResBlock convs (same length in and out, bias, no activation of the stored value) of a C = 128 / 256
+// stage with k = 3 / 7 / 11, while the launch has at most VITS_LAT16H_MAX_TILES (C = 256) / VITS_LAT16H_MAX_TILES_C128 32 x 32 output tiles (one to four utterances).
+// Measured (f16, ms per batch of 1 / 2 / 3 / 4 x 128 ids; fused pairs -> this kernel): 1.485 -> 1.428, 1.596 -> 1.553, 1.826 -> 1.780, 1.974 -> 1.939; C = 128 at batch 1 (1792 tiles): + 6 ... 12 us.
+bool conv16_lat_shape_ok(int channels, int kt, int dil, int batch, int tmax) {
+    const KernelKnobs& kn = kernel_knobs();
+    if (kn.no_lat16h) return false;
+    if (!(channels == 128 || channels == 256) || !(kt == 3 || kt == 7 || kt == 11) || dil < 1 || (kt - 1) * dil > 50) return false;
+    const int64_t tiles = (int64_t)((tmax + 31) / 32) * (channels / 32) * batch;
+    return tiles <= (channels == 256 ? kn.lat16h_max_tiles : kn.lat16h_max_tiles_c128);
+}
+bool conv16_lat_wanted(const PackedConv& w, const Conv16Call& c) {
+    if (c.tile >= 0 || w.cin != w.cout || !conv16_lat_shape_ok(w.cin, w.kt, c.dil, c.batch, c.t_out)) return false;
+    if (w.epi != EPI_STD || !(c.yg || c.y16.p) || !w.wp16 || !w.bias) return false;
+    if (c.len_in != c.len_out || c.t_in != c.t_out || c.post_act != 0 || c.ct_crop != 0 || c.pad_l != (w.kt - 1) * c.dil / 2) return false;
+    return !(c.y.p || c.res.p || c.acc.p || c.y2);
+}
+
+template <int KT, int C, int WM, int NR, bool BF>
+static hipError_t launch_c16l(const Conv16LatParams& p, int batch, hipStream_t s) {
+    const size_t lds = (size_t)(C / 8) * p.pitch * 16 + 8 * 16;  // (+ the slots the look-ahead of the last tap reads past the tile, value unused)
+    static BigLdsOnce big;
+    if (lds > 64 * 1024 && big.needed()) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_lat_kernel<KT, C, WM, NR, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+        big.done();
+    }
+    dim3 grid((p.tmax + 32 * NR - 1) / (32 * NR), C / 32 / WM, batch);
+    VITS_KLAUNCH((conv16_lat_kernel<KT, C, WM, NR, BF>), grid, dim3(WM * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
+    if (!conv16_lat_wanted(w, c)) return hipErrorInvalidValue;
+    Conv16LatParams p;
+    p.x = c.x.p;
+    p.x_bs = c.x.bs;
+    p.x_ts = c.x.ts;
+    p.wp = w.wp16;
+    p.bias = w.bias;
+    p.lens = c.len_out;
+    p.tmax = c.t_out;
+    p.dil = c.dil;
+    p.pad_l = c.pad_l;
+    p.yg = c.yg;
+    p.resg = c.resg;
+    p.accg = c.accg;
+    p.g_bs = c.g_bs;
+    p.g_ts = c.g_ts;
+    p.y16 = c.y16.p;
+    p.y16_bs = c.y16.bs;
+    p.y16_ts = c.y16.ts;
+    p.y16_slope = c.y16_slope;
+    p.scale = c.scale;
+    p.scale_div = c.scale_div;
+    const bool bf = arith == VITS_ARITH_BF16;
+    // shape (VITS_LAT16H_SHAPE = 10 WM + NR): two row tiles x 32 columns per block by default (batch 1: 1.483 ms against 1.498 with 64 columns and 1.492 with four row tiles x 64)
+    const int shape = kernel_knobs().lat16h_shape;
+    const int wm = shape / 10, nr = shape % 10;
+    p.pitch = (32 * nr + (w.kt - 1) * c.dil + 7) / 8 * 8;
+#define VITS_C16L_GO(K, CC, WM_, NR_)                                                                                                           \
+    if (w.kt == K && w.cin == CC && wm == WM_ && nr == NR_) return bf ? launch_c16l<K, CC, WM_, NR_, true>(p, c.batch, s) : launch_c16l<K, CC, WM_, NR_, false>(p, c.batch, s)
+#define VITS_C16L_SHAPES(K, CC) \
+    VITS_C16L_GO(K, CC, 2, 1);  \
+    VITS_C16L_GO(K, CC, 2, 2);  \
+    VITS_C16L_GO(K, CC, 4, 2)
+    VITS_C16L_SHAPES(3, 128);
+    VITS_C16L_SHAPES(7, 128);
+    VITS_C16L_SHAPES(11, 128);
+    VITS_C16L_SHAPES(3, 256);
+    VITS_C16L_SHAPES(7, 256);
+    VITS_C16L_SHAPES(11, 256);
+#undef VITS_C16L_SHAPES
+#undef VITS_C16L_GO
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vits

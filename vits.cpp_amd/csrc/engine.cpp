@@ -10,7 +10,7 @@ namespace vits {
 hipError_t Engine::conv16(const char* name, const PackedConv& w, const Conv16Call& c, hipStream_t stream, double bytes) {
     if (prof.on) {
         const int ncols = w.epi == EPI_CONVT ? c.t_in + 1 : c.t_out;
-        const int tile = c.tile >= 0 ? c.tile : choose_conv16_tile(w.rows, w.epi, ncols, w.mtiles_used, c.batch);
+        const int tile = c.tile >= 0 ? c.tile : (conv16_lat_wanted(w, c) ? 7 : choose_conv16_tile(w.rows, w.epi, ncols, w.mtiles_used, c.batch));
         const bool group = c.yg || c.y16.p;
         char full[160];
         std::snprintf(full, sizeof(full), "%s|k%d|d%d|T%d|e%d%s|c%dx%d", name, w.kt, w.epi == EPI_CONVT ? -1 : (w.kt == 1 ? 1 : c.dil), tile, w.epi, group ? "g" : "", w.cin,

@@ -112,15 +112,19 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         // one or two utterances, every resblock of the stage a whole-resblock kernel: the kernels do NOT chain through the shared sum — each writes its own fp32
         // output side by side with the others and launch_rb_sum3 adds them in the reference's order (rbblock16.hip; same bits; the C = 32 stage at batch 1:
         // three chained 15-25 us kernels + two event hand-overs = 105 us, side by side + the sum ~40)
-        const bool sum3 = par && all_block && nk >= 2 && !knobs.kernel.no_rb_sum3 && w.ssum[0] < knobs.rb16_serial_min_frames;
+        const bool sum3 = par && (all_block || !knobs.kernel.rb_sum3_block_only) && nk >= 2 && !knobs.kernel.no_rb_sum3 && w.ssum[0] < knobs.rb16_serial_min_frames;
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
         }
-        for (size_t j = 0; j < nk; ++j) {
+        // (side-by-side resblocks — sum3 — need no order: the LAST one, the longest chain (k = 11), is enqueued first and on the main stream, where it starts
+        // without the fork's cross-queue hand-over (10-40 us later on the side streams at batch 1); the short k = 3 chain takes the last side stream)
+        const bool longest_first = sum3 && !knobs.kernel.rb_sum3_in_order;
+        for (size_t jj = 0; jj < nk; ++jj) {
+            const size_t j = longest_first ? nk - 1 - jj : jj;
             const ResBlockW& R = U.rbs[j];
             const size_t nd = R.dil.size();
-            hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
+            hipStream_t sj = par && jj > 0 ? side_[jj - 1] : stream;
             const int q = par ? (int)j : 0;
             const Ref16 byl16 = R16(s2.byl[q], C, sts[st_out]), bt16 = R16(s2.bt[q], C, sts[st_out]);
             // narrow stages: each pair runs as ONE kernel and t stays in LDS (rbpair16.hip; bit-identical to the two-kernel path).
@@ -184,6 +188,13 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
             }
             bool fuse_rb = c.fuse16;
             for (size_t d = 0; d < nd; ++d) fuse_rb = fuse_rb && rbpair16_supported(C, R.k, R.dil[d]) && R.c1[d].bias && R.c2[d].bias;
+            // one or a few utterances on a wide stage: a fused pair is 28-32 blocks that each stream both convs' weights through one CU; two launches of
+            // conv16_lat_kernel deal the rows out over the chip (conv16_lat.hip; same bits)
+            if (fuse_rb && C >= 128) {
+                bool lat = true;
+                for (size_t d = 0; d < nd; ++d) lat = lat && conv16_lat_shape_ok(C, R.k, R.dil[d], B, smax[st_out]);
+                if (lat) fuse_rb = false;
+            }
             for (size_t d = 0; d < nd; ++d) {
                 const Ref16 in16 = d == 0 ? bul16 : (fuse_rb && (d & 1) == 0 ? bt16 : byl16);
                 const Ref16 out16 = fuse_rb && (d & 1) ? bt16 : byl16;  // the stream buffer this pair writes
@@ -214,6 +225,9 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                     c2.y16 = out16;  // next pair's input
                     c2.y16_slope = hp.lrelu;
                     bytes2 += 2.0 * n_out;
+                } else if (sum3) {
+                    c2.yg = s2.by[q];  // the resblock's own output; launch_rb_sum3 below adds the three in the reference's order, scales, writes the 16-bit copy
+                    c2.scale = 1.f;
                 } else {
                     c2.yg = s2.bs;  // sum over the resblocks and the 1/num_kernels scale (vits.cpp:622-635)
                     if (j > 0) {
@@ -242,7 +256,7 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
                     }
                 }
                 const bool last = d + 1 == nd;
-                if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                if (par && last && j > 0 && !sum3) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
                 if (fuse) {
                     RbPair16Call f;
                     f.x = c1.x;
@@ -275,7 +289,7 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         }
         if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
         if (sum3) {
-            for (size_t j = 1; j + 1 < nk; ++j) HIP_OK(hipStreamWaitEvent(stream, ev_done_[j], 0));  // (every chain, not only the last: they no longer wait for each other)
+            for (size_t j = 0; j + 1 < nk; ++j) HIP_OK(hipStreamWaitEvent(stream, ev_done_[j], 0));  // (every chain, not only the last: they no longer wait for each other)
             const bool div = !refmode;
             prof.begin("hifigan_resblock_sum", 0, (4.0 * nk + 2.0) * n_out, stream);
             HIP_OK(launch_rb_sum3(s2.by[0], s2.by[1], nk > 2 ? s2.by[2] : nullptr, C, g_bs, g_ts, d_len[st_out], B, smax[st_out], div ? (float)nk : (float)(1.0 / (double)nk), div ? 1 : 0,

@@ -48,12 +48,18 @@ struct KernelKnobs {
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
     int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
+    bool rb_sum3_in_order = false;    // VITS_RB_SUM3_IN_ORDER: side-by-side resblocks enqueued first to last, the first on the main stream (until round 6's last step; default: the last — longest — first and on the main stream)
+    bool rb_sum3_block_only = false;  // VITS_RB_SUM3_BLOCK_ONLY: the separate sum launch only for stages whose resblocks are all whole-resblock kernels (until round 6's last step: every small-grid stage)
     bool no_rb_sum3 = false;     // VITS_NO_RB_SUM3: the resblocks of an all-whole-resblock stage always chained through the shared sum (no separate sum launch on small grids)
     int rb16_narrow_max = 128;   // VITS_RB16_NARROW_MAX: 16-bit fused pairs at C >= 128 on 64-column blocks while the 128-column tile would give at most this many blocks (0: never; 64 until round 6: batch 4 / 6 -1 ... -2 % with 128)
     int flow_narrow_max = 96;    // VITS_FLOW_NARROW_MAX: 16-bit coupling-layer kernel on 16-frame blocks while the 48-frame tile would give at most this many blocks (0: never)
     bool no_ln_fuse = false;     // VITS_NO_LN_FUSE: the encoder's LayerNorms always as their own launches (never applied on load by the consuming conv_lat16_kernel)
     bool no_dds_lat = false;     // VITS_NO_DDS_LAT: the duration predictor's DDS layers always on dds_layer_kernel (no 16-token latency kernel, no fused 1x1 convs around it)
     int dds_lat_max_blocks = 96; // VITS_DDS_LAT_MAX_BLOCKS: the latency kernel is taken while batch x ceil(tokens / 16) is at most this
+    bool no_lat16h = false;      // VITS_NO_LAT16H: 16-bit modes: the wide stages' resblock convs on small grids as fused pairs (rbpair16) / conv16_kernel, never conv16_lat_kernel
+    int lat16h_max_tiles = 2048; // VITS_LAT16H_MAX_TILES: ... while a C = 256 conv has at most this many 32 x 32 output tiles (batch 1 ... 4 x 128 ids)
+    int lat16h_max_tiles_c128 = 0;  // VITS_LAT16H_MAX_TILES_C128: the same for C = 128 (batch 1 = 1792 tiles measured + 6 ... 12 us against the fused pairs: off)
+    int lat16h_shape = 21;       // VITS_LAT16H_SHAPE: 10 x waves per block + 32-column tiles per wave of conv16_lat_kernel (21, 22, 42)
     bool no_lat16 = false;       // VITS_NO_LAT16: tiny grids with long K chains on the 128 x 32 tile of conv_mfma instead of conv_lat16_kernel
     int lat16_max_waves = 768;   // VITS_LAT16_MAX_WAVES: standard convs with at most this many 32 x 32 output tiles take conv_lat16_kernel (0: tiny grids only)
     static KernelKnobs from_env() {
@@ -66,6 +72,8 @@ struct KernelKnobs {
         flag("VITS_NO_DDS_LAT", k.no_dds_lat);
         flag("VITS_NO_LN_FUSE", k.no_ln_fuse);
         flag("VITS_NO_RB_SUM3", k.no_rb_sum3);
+        flag("VITS_RB_SUM3_BLOCK_ONLY", k.rb_sum3_block_only);
+        flag("VITS_RB_SUM3_IN_ORDER", k.rb_sum3_in_order);
         num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
@@ -95,6 +103,10 @@ struct KernelKnobs {
         num("VITS_CONVT16_SPLIT_MAX", k.convt16_split_max);
         num("VITS_CONVT16_R128", k.convt16_r128);
         flag("VITS_NO_LAT16", k.no_lat16);
+        flag("VITS_NO_LAT16H", k.no_lat16h);
+        num("VITS_LAT16H_MAX_TILES", k.lat16h_max_tiles);
+        num("VITS_LAT16H_MAX_TILES_C128", k.lat16h_max_tiles_c128);
+        num("VITS_LAT16H_SHAPE", k.lat16h_shape);
         num("VITS_LAT16_MAX_WAVES", k.lat16_max_waves);
         return k;
     }
@@ -375,6 +387,10 @@ hipError_t launch_rbpair32(const PackedConv& c1, const PackedConv& c2, const RbP
 hipError_t launch_rbpair16(const PackedConv& c1, const PackedConv& c2, const RbPair16Call& c, int arith, hipStream_t s);
 std::vector<uint16_t> pack_conv_weights16(const float* w, int cout, int cin, int k, int epi, int ct_stride, int arith);
 int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int batch);
+// conv16_lat.hip: the wide stages' group-layout resblock convs on small grids (batch 1 ... 4); launch_conv16 routes to it (profile tile tag T7)
+bool conv16_lat_shape_ok(int channels, int kt, int dil, int batch, int tmax);
+bool conv16_lat_wanted(const PackedConv& w, const Conv16Call& c);
+hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
 hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
 // ConvTranspose1d (kernel = 2 x stride) in the group layout as a streaming kernel (convt16.hip): all stride x c_out rows of a tile of input
 // positions per block; bit-identical to launch_conv16 on the same call
