@@ -376,10 +376,19 @@ int Engine::process_impl(const int32_t* ids, const int32_t* id_lens, int B, int 
         HIP_OK(hipEventSynchronize(pend->s1_done));
         std::copy(pend->frames_pinned, pend->frames_pinned + B, frames.begin());
     } else {
-        HIP_OK(hipMemcpyAsync(frames.data(), c.s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+        // (pinned destination, owned by the engine: into the caller-side std::vector the copy went through the runtime's staging buffer, + 15 us per batch-1 call)
+        if (frames_host_cap_ < (size_t)B) {
+            if (frames_host_) hipHostFree(frames_host_);
+            frames_host_ = nullptr;
+            frames_host_cap_ = 0;
+            HIP_OK(hipHostMalloc((void**)&frames_host_, sizeof(int) * ((size_t)B + 64), hipHostMallocDefault));
+            frames_host_cap_ = (size_t)B + 64;
+        }
+        HIP_OK(hipMemcpyAsync(frames_host_, c.s1.frames, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
         prof.fence();
         HIP_OK(hipStreamSynchronize(stream));
         prof.fence();
+        std::copy(frames_host_, frames_host_ + B, frames.begin());
     }
     if (overlap) {
         // stage two runs on the main stream, behind this batch's stage one (pinned durations: no host read ordered them yet)

@@ -295,6 +295,8 @@ class Engine {
     hipEvent_t ev_fork_ = nullptr, ev_done_[3] = {nullptr, nullptr, nullptr};
     int halo_frames_ = 0;      // receptive field of the vocoder in frames, one side (computed at load)
     void* pinned_ = nullptr;   // grow-only pinned staging for streamed PCM
+    int* frames_host_ = nullptr;  // pinned [frames_host_cap_]: destination of a synchronous call's frame-count copy (into pageable memory the copy went through a staging buffer: + 15 us at batch 1)
+    size_t frames_host_cap_ = 0;
     size_t pinned_cap_ = 0;
     // arithmetic of the convolutions being queued right now: `arith`, or fp32 while stage one runs under
     // VITS_ARITH_SCOPE_FLOW_VOCODER (every conv wrapper and fused kernel reads this one, never `arith` itself)

@@ -25,6 +25,7 @@ Engine::~Engine() {
             if (ps.pc->wp16) hipFree(ps.pc->wp16);
     }
     if (pinned_) hipHostFree(pinned_);
+    if (frames_host_) hipHostFree(frames_host_);
     for (HStage& hs : hstage_) {
         if (hs.p) hipHostFree(hs.p);
         if (hs.ev) hipEventDestroy(hs.ev);

@@ -34,6 +34,7 @@ struct KernelKnobs {
     bool no_convt16s = false;    // VITS_NO_CONVT16S: 16-bit transposed convs through conv16's polyphase epilogue
     bool convt16s_all = false;   // VITS_CONVT16S_ALL: the one-row-tile streaming kernel also for stride 8
     bool no_convt16l = false;    // VITS_NO_CONVT16L: no four-phase lines kernel for strides that are multiples of 4
+    bool no_att_lat = false;     // VITS_NO_ATT_LAT: small attention grids (at most 128 blocks) without the operand prefetch across phases (the eight-wave kernel of round 6's first step)
     bool att_valu = false;       // VITS_ATT_VALU: attention without the matrix cores
     int att_nw = 0;              // VITS_ATT_NW=4|8: waves per attention block (0: by LDS footprint)
     int att_short = 512;         // VITS_ATT_SHORT: longest sequence (tokens) for the short-sequence attention variant (0: off)
@@ -87,6 +88,7 @@ struct KernelKnobs {
         flag("VITS_CONVT16S_ALL", k.convt16s_all);
         flag("VITS_NO_CONVT16L", k.no_convt16l);
         flag("VITS_ATT_VALU", k.att_valu);
+        flag("VITS_NO_ATT_LAT", k.no_att_lat);
         num("VITS_ATT_NW", k.att_nw);
         num("VITS_ATT_SHORT", k.att_short);
         num("VITS_LN_TW", k.ln_tw);

@@ -315,8 +315,12 @@ __device__ unsigned long long vits_att_phase[8 * 65536];
 // MAXS: k-steps of head_dim the register arrays are sized for (24: head_dim <= 96, the MMS-TTS architecture; 32: <= 128). SHORT: sequences of
 // at most a few key tiles per wave (the 128-token utterances of a batch): ONE key tile of look-ahead instead of two and at most 128 VGPRs, so
 // that four blocks of four waves share a CU instead of three — 1024 blocks are then one round of the chip instead of 1.33.
-template <int NW, int MAXS, bool SHORT>
-__global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
+// LAT (latency-bound launches: at most 128 blocks, round 6): every operand that does not depend on an earlier phase is REQUESTED at the top of the phase
+// before — the wave's first K tile and the relative-key embeddings beside the Q tile, the first four V groups and the relative-value embeddings before
+// the softmax — so that a block pays three memory round trips instead of six (per-block stamps at 128 tokens: 13.9 -> see launch_rel_attention). The
+// MFMA sequences, and with them every sum, are those of the other variants.
+template <int NW, int MAXS, bool SHORT, bool LAT = false>
+__global__ __launch_bounds__(64 * NW, LAT ? 2 : (SHORT ? 4 : 3)) void rel_attention_mfma_kernel(const float* q, int64_t q_bs, int q_cs, const float* k, int64_t k_bs, int k_cs, const float* v,
                                                                      int64_t v_bs, int v_cs, const float* rel_k, const float* rel_v, float* out, int64_t o_bs,
                                                                      int o_cs, const int* lens, int head_dim, int tmax, int window, float q_scale, int v16, const uint16_t* exp_tab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -342,6 +346,24 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
     const float* qb = q + (int64_t)b * q_bs + (int64_t)h * hd * q_cs;
     const float* kb = k + (int64_t)b * k_bs + (int64_t)h * hd * k_cs;
     const float* vb = v + (int64_t)b * v_bs + (int64_t)h * hd * v_cs;
+    const int nsteps = hd >> 2;
+    const int ntiles = (len + 15) >> 4;
+    float k0[MAXS], k1[MAXS], k2[MAXS];  // K operands of this wave's current / next key tiles (scores phase)
+    auto load_tile = [&](int n, float* dst) __attribute__((always_inline)) {
+        const int nc = n < ntiles ? n : ntiles - 1;  // (past the last tile: a valid address, values unused)
+        const int key = nc * 16 + ln;
+        const float* kp = kb + (int64_t)lk * k_cs + (key < len ? key : len - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < MAXS; ++s2) dst[s2] = s2 < nsteps ? kp[(int64_t)(4 * s2) * k_cs] : 0.f;
+    };
+    float bvp[MAXS];  // LAT: the relative-key operands of this wave's tile of relative positions
+    if constexpr (LAT) {
+        load_tile(wid, k0);
+        const int rcol = wid * 16 + ln;
+        const float* rp = rel_k + (int64_t)(rcol < nrel ? rcol : 0) * hd + lk;
+#pragma unroll
+        for (int s2 = 0; s2 < MAXS; ++s2) bvp[s2] = (wid * 16 < nrel && s2 < nsteps && rcol < nrel) ? rp[4 * s2] : 0.f;
+    }
     {
         float tq[8];  // (head_dim <= 128: at most 8 elements per thread, all loads in flight)
 #pragma unroll
@@ -355,8 +377,6 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
             if (tid + u * NT < ATT_Q * hd) qt[tid + u * NT] = tq[u];  // (idx = d * 16 + qi is the Q^T index)
     }
     __syncthreads();
-    const int nsteps = hd >> 2;
-    const int ntiles = (len + 15) >> 4;
     // this lane's Q operands for every k-step (A[m = ln][k = 4s + lk]): the same for every key tile and for the relative-key product
     float qa[MAXS];
 #pragma unroll
@@ -371,7 +391,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
         for (int s0 = 0; s0 < MAXS; s0 += 8) {
             float bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bv[u] = (s0 + u < nsteps && rcol < nrel) ? rp[4 * (s0 + u)] : 0.f;
+            for (int u = 0; u < 8; ++u) {
+                if (LAT && ct == wid) bv[u] = s0 + u < MAXS ? bvp[s0 + u < MAXS ? s0 + u : 0] : 0.f;
+                else bv[u] = (s0 + u < nsteps && rcol < nrel) ? rp[4 * (s0 + u)] : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s0 + u], bv[u], acc, 0, 0, 0);
@@ -381,23 +404,18 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
             for (int r = 0; r < 4; ++r) qe[(4 * lk + r) * nrel + rcol] = acc[r];
         }
     }
-    __syncthreads();
+    if constexpr (!LAT) __syncthreads();  // (LAT: behind the first tile's MFMA chain, below)
     ATT_STAMP(1);
     // ---- scores: S[16 q][16 keys] per key tile, K = hd; the K operands of this wave's next two tiles are in flight ----
     {
-        float k0[MAXS], k1[MAXS], k2[MAXS];
-        auto load_tile = [&](int n, float* dst) __attribute__((always_inline)) {
-            const int nc = n < ntiles ? n : ntiles - 1;  // (past the last tile: a valid address, values unused)
-            const int key = nc * 16 + ln;
-            const float* kp = kb + (int64_t)lk * k_cs + (key < len ? key : len - 1);
-#pragma unroll
-            for (int s2 = 0; s2 < MAXS; ++s2) dst[s2] = s2 < nsteps ? kp[(int64_t)(4 * s2) * k_cs] : 0.f;
-        };
-        auto tile = [&](int n, const float* kop) __attribute__((always_inline)) {
+        auto tile_chain = [&](const float* kop) __attribute__((always_inline)) -> att_float4v {
             att_float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < MAXS; ++s2)
                 if (s2 < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s2], kop[s2], acc, 0, 0, 0);
+            return acc;
+        };
+        auto tile_store = [&](int n, const att_float4v acc) __attribute__((always_inline)) {
             const int key = n * 16 + ln;
             if (key < len) {
 #pragma unroll
@@ -410,7 +428,30 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
                 }
             }
         };
+        auto tile = [&](int n, const float* kop) __attribute__((always_inline)) { tile_store(n, tile_chain(kop)); };
         int n = wid;
+        if constexpr (LAT) {
+            // the first tile's MFMA chain runs BESIDE wave 0's relative-key product: the barrier that publishes q.Ek stands behind the chain, in front of the
+            // first store (the other variants have it in front of the phase)
+            if (n + NW < ntiles) load_tile(n + NW, k1);
+            att_float4v a0 = {0.f, 0.f, 0.f, 0.f};
+            if (n < ntiles) a0 = tile_chain(k0);
+            __syncthreads();
+            if (n < ntiles) tile_store(n, a0);
+            n += NW;
+            // (further tiles — sequences of more than 16 NW tokens on a small grid — one tile of look-ahead, k1 / k0 in turn)
+            while (n < ntiles) {
+                if (n + NW < ntiles) load_tile(n + NW, k0);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(n, k1);
+                n += NW;
+                if (n >= ntiles) break;
+                if (n + NW < ntiles) load_tile(n + NW, k1);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(n, k0);
+                n += NW;
+            }
+        } else
         if constexpr (SHORT) {
             if (n < ntiles) load_tile(n, k0);
             while (n < ntiles) {
@@ -447,6 +488,41 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
         }
         }
     }
+    // LAT: the first four V groups of this wave's first d tile and its relative-value embeddings, requested before the softmax
+    const int ndt = hd >> 4;
+    const int ng = (len + 15) >> 4;
+    const int klast4 = (len - 1) & ~3;  // the last 16-byte piece of a row that starts inside the sequence (rows are padded to x4)
+    auto load_v = [&](int g, const float* vrow, att_float4v& vv) __attribute__((always_inline)) {
+        const int gc = g < ng ? g : ng - 1;
+        const int key0 = 16 * gc + 4 * lk;
+        if (v16) {
+            const att_float4v t = *reinterpret_cast<const att_float4v*>(vrow + (key0 < klast4 ? key0 : klast4));
+            vv[0] = key0 < len ? t[0] : 0.f;
+            vv[1] = key0 + 1 < len ? t[1] : 0.f;
+            vv[2] = key0 + 2 < len ? t[2] : 0.f;
+            vv[3] = key0 + 3 < len ? t[3] : 0.f;
+        } else {  // rows not 16-byte aligned (never in the engine; the operator entry point takes any stride): same values, four loads
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = vrow[key0 + e < len ? key0 + e : len - 1];
+                vv[e] = key0 + e < len ? t : 0.f;
+            }
+        }
+    };
+    att_float4v vpre[4];
+    float evp[4];
+    if constexpr (LAT) {
+        if (wid < ndt) {
+            const float* vrow = vb + (int64_t)(wid * 16 + ln) * v_cs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_v(i, vrow, vpre[i]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int r = 4 * s2 + lk;
+                evp[s2] = r < nrel ? rel_v[(int64_t)r * hd + wid * 16 + ln] : 0.f;
+            }
+        }
+    }
     __syncthreads();
     ATT_STAMP(2);
     // ---- softmax per query: 16 lanes per query; the padding columns of P are zeroed (the MFMA k-steps run over whole groups) ----
@@ -458,9 +534,6 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
     __syncthreads();
     ATT_STAMP(3);
     // ---- O[16 q][hd] = P V: d tile dt, K = keys in groups of 16 (see the head comment), four groups in flight ----
-    const int ndt = hd >> 4;
-    const int ng = (len + 15) >> 4;
-    const int klast4 = (len - 1) & ~3;  // the last 16-byte piece of a row that starts inside the sequence (rows are padded to x4)
     att_float4v oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d tiles wid and wid + NW (NW >= 4, head_dim <= 128)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -472,23 +545,17 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
             auto load_group = [&](int g, att_float4v& pa, att_float4v& vv) __attribute__((always_inline)) {
                 const int gc = g < ng ? g : ng - 1;
                 pa = *reinterpret_cast<const att_float4v*>(prow + 16 * gc);
-                const int key0 = 16 * gc + 4 * lk;
-                if (v16) {
-                    const att_float4v t = *reinterpret_cast<const att_float4v*>(vrow + (key0 < klast4 ? key0 : klast4));
-                    vv[0] = key0 < len ? t[0] : 0.f;
-                    vv[1] = key0 + 1 < len ? t[1] : 0.f;
-                    vv[2] = key0 + 2 < len ? t[2] : 0.f;
-                    vv[3] = key0 + 3 < len ? t[3] : 0.f;
-                } else {  // rows not 16-byte aligned (never in the engine; the operator entry point takes any stride): same values, four loads
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = vrow[key0 + e < len ? key0 + e : len - 1];
-                        vv[e] = key0 + e < len ? t : 0.f;
-                    }
-                }
+                load_v(g, vrow, vv);
             };
 #pragma unroll
-            for (int i = 0; i < 4; ++i) load_group(i, pr[i], vr[i]);
+            for (int i = 0; i < 4; ++i) {
+                if (LAT && u == 0) {  // (V requested before the softmax; P exists only now)
+                    pr[i] = *reinterpret_cast<const att_float4v*>(prow + 16 * (i < ng ? i : ng - 1));
+                    vr[i] = vpre[i];
+                } else {
+                    load_group(i, pr[i], vr[i]);
+                }
+            }
             att_float4v a4 = oacc[u];
             for (int g = 0; g < ng; g += 4) {
 #pragma unroll
@@ -518,7 +585,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 4 : 3) void rel_attention_mfma_ker
                     const int r = 4 * s + lk;
                     const int j = i0 + ln + r - window;
                     const float pw = (r < nrel && j >= 0 && j < len && i0 + ln < len) ? sc[ln * lp + j] : 0.f;
-                    const float ev = r < nrel ? rel_v[(int64_t)r * hd + dt * 16 + ln] : 0.f;
+                    const float ev = (LAT && u == 0 && s < 4) ? evp[s < 4 ? s : 0] : (r < nrel ? rel_v[(int64_t)r * hd + dt * 16 + ln] : 0.f);
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw, ev, a4, 0, 0, 0);
                 }
                 oacc[u] = a4;
@@ -567,12 +634,24 @@ hipError_t launch_rel_attention(TensorRef q, TensorRef k, TensorRef v, const flo
         VITS_KLAUNCH((rel_attention_mfma_kernel<NW, MS, SH>), gridm, dim3(64 * NW), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
                            out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0, tabs.exp);                                            \
     } while (0)
+#define VITS_ATTM_LAUNCH_LAT()                                                                                                                          \
+    do {                                                                                                                                         \
+        if (ldsm > 64 * 1024) {                                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rel_attention_mfma_kernel<8, 24, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
+            if (e != hipSuccess) return e;                                                                                                       \
+        }                                                                                                                                        \
+        VITS_KLAUNCH((rel_attention_mfma_kernel<8, 24, false, true>), gridm, dim3(512), ldsm, s, q.p, q.bs, q.cs, k.p, k.bs, k.cs, v.p, v.bs, v.cs, rel_k, rel_v, out.p, \
+                           out.bs, out.cs, lens, head_dim, tmax, window, q_scale, v_aligned ? 1 : 0, tabs.exp);                                            \
+    } while (0)
             const int short_max = kernel_knobs().att_short;  // tokens; 0 disables the short variant
             // (the long variants keep their arrays at 32 k-steps: sized for 24 the four-wave kernel measured 0.22 against 0.18 ms at 1024 tokens)
-            if (nw == 4 && head_dim <= 96 && tmax <= short_max) VITS_ATTM_LAUNCH(4, 24, true);
+            const bool lat = !kernel_knobs().no_att_lat && nw == 8 && head_dim <= 96 && (int64_t)gridm.x * gridm.y * gridm.z <= 128;
+            if (lat) VITS_ATTM_LAUNCH_LAT();
+            else if (nw == 4 && head_dim <= 96 && tmax <= short_max) VITS_ATTM_LAUNCH(4, 24, true);
             else if (nw == 4) VITS_ATTM_LAUNCH(4, 32, false);
             else VITS_ATTM_LAUNCH(8, 32, false);
 #undef VITS_ATTM_LAUNCH
+#undef VITS_ATTM_LAUNCH_LAT
             return hipGetLastError();
         }
     }
