@@ -956,6 +956,30 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
     float4 ar[R];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) ar[i] = load_q(i);  // (in front of the fill: one memory latency for both)
+    // the epilogue's operands — bias, residual, accumulator of a sum — requested with everything else (behind the K loop they were one more exposed
+    // round trip per launch: 1-1.5 us of a 7-10 us conv, forty to sixty such launches per batch-1 utterance)
+    float ep_bias[4], ep_res[4], ep_acc[4], ep_b1[4];
+    {
+        const int t_e = t0 + col;
+        const float* rb_e = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+        const float* ab_e = p.acc ? p.acc + (int64_t)b * p.a_bs : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (EPI == EPI_STD) {
+                const int co = mtile * 32 + 16 * half + 4 * jg + r;
+                const bool ok = co < p.cout && t_e < ncols;
+                ep_bias[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+                ep_res[r] = (rb_e && ok) ? rb_e[(int64_t)co * p.r_cs + t_e] : 0.f;
+                ep_acc[r] = (ab_e && ok) ? ab_e[(int64_t)co * p.a_cs + t_e] : 0.f;
+                ep_b1[r] = 0.f;
+            } else {
+                const int ch = (int)blockIdx.y * 32 + 16 * half + 4 * jg + r, halfc = p.cout / 2;
+                ep_bias[r] = (p.bias && ch < halfc) ? p.bias[ch] : 0.f;
+                ep_b1[r] = (p.bias && ch < halfc) ? p.bias[ch + halfc] : 0.f;
+                ep_res[r] = ep_acc[r] = 0.f;
+            }
+        }
+    }
     float lng[3], lnb[3];  // LayerNorm on load: this thread's share of gamma / beta (c_in <= 768), requested with everything else
     if (p.ln_gamma) {
 #pragma unroll
@@ -1161,11 +1185,11 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
         for (int r = 0; r < 4; ++r) {
             const int co = mtile * 32 + 16 * half + 4 * jg + r;
             if (co >= p.cout || t >= ncols) continue;
-            float v = acc[r] + (p.bias ? p.bias[co] : 0.f);
+            float v = acc[r] + ep_bias[r];
             if (p.post_act == 1) v = v > 0.f ? v : 0.f;
-            if (rb) v = rb[(int64_t)co * p.r_cs + t] + v;
+            if (rb) v = ep_res[r] + v;
             if (ab) {
-                v = ab[(int64_t)co * p.a_cs + t] + v;
+                v = ep_acc[r] + v;
                 v = p.scale_div ? v / p.scale : v * p.scale;
             }
             if (p.post_act == 2) v = fmaxf(v, v * p.post_slope);
@@ -1189,8 +1213,7 @@ __global__ __launch_bounds__(256) void conv_lat16_kernel(const ConvParams p) {
         for (int r = 0; r < 4; ++r) {
             const int ch = (int)blockIdx.y * 32 + 16 * half + 4 * jg + r;
             if (ch >= halfc || t >= ncols) continue;
-            const float b0 = p.bias ? p.bias[ch] : 0.f, b1 = p.bias ? p.bias[ch + halfc] : 0.f;
-            yb[(int64_t)ch * p.y_cs + t] = wavenet_gate(acc[r] + b0, ex[r * 64 + lane] + b1);
+            yb[(int64_t)ch * p.y_cs + t] = wavenet_gate(acc[r] + ep_bias[r], ex[r * 64 + lane] + ep_b1[r]);
         }
     }
 }
