@@ -40,11 +40,12 @@ def model(arch, arith, ref=False):
         if ref == "unsplit":  # ... and its whole-resblock kernels (16-bit modes) walk segments of three tiles from two tiles up, the main handle's one tile per block at these sizes
             os.environ["VITS_RBB_STREAM_MIN_BLOCKS"], os.environ["VITS_RBB_STREAM_TILES"] = "1", "3"
             os.environ["VITS_NO_LAT16H"] = "1"  # ... and the wide stages' resblock convs never take conv16_lat_kernel (the main handle's do on small grids)
+            os.environ["VITS_NO_RB_SUM3_F32"] = "1"  # ... and the fp32 vocoder's resblocks always chain through the shared sum (the main handle's run side by side on small grids)
         try:
             models[key] = [pkg.Model(pkg.synth_model_bytes(0x5EED, arch)), "f32", False]
         finally:
             del os.environ["VITS_SPLIT_MIN_BATCH"], os.environ["VITS_SPLIT_FIRST_PCT"]
-            os.environ.pop("VITS_RBB_STREAM_MIN_BLOCKS", None), os.environ.pop("VITS_RBB_STREAM_TILES", None), os.environ.pop("VITS_NO_LAT16H", None)
+            os.environ.pop("VITS_RBB_STREAM_MIN_BLOCKS", None), os.environ.pop("VITS_RBB_STREAM_TILES", None), os.environ.pop("VITS_NO_LAT16H", None), os.environ.pop("VITS_NO_RB_SUM3_F32", None)
     e = models[key]
     if e[1] != arith:
         e[0].set_arith(ARITH[arith])
@@ -102,7 +103,7 @@ for trial in range(args.trials):
         same(([A[0][b]], A[1][b:b + 1], A[2][b:b + 1]), one, "row alone", ctx)
         counts["single"] += 1
     # the call split in two pipelined parts (this handle, B >= 2) == the unsplit call
-    if B >= 2 or arith in ("f16", "bf16"):
+    if B >= 2 or arith in ("f16", "bf16", "f32"):
         same(A, unsplit.process_batch(ids, **kw), "split in two / segments of tiles", ctx)
         counts["split"] += 1
     # windowed vocoder

@@ -429,6 +429,9 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             HIP_OK(launch_split_planes(bu, C, d_len[st_out], B, smax[st_out], hp.lrelu, SR(s2.sp_u), stream));
             prof.end(stream);
         }
+        // (small grids, set below: every resblock writes its own output — s2.by[j] — and launch_rb_sum3_std adds them in the reference's order: no resblock's last
+        // launch waits for the previous resblock's; same bits)
+        bool sum3 = false;
         auto run_block = [&](size_t j, hipStream_t sj) -> int {
             const ResBlockW& R = U.rbs[j];
             const PackedConv* w1[3] = {&R.c1[0], &R.c1[1], &R.c1[2]};
@@ -455,6 +458,13 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
                 }
             } else {
                 f.scale = 1.f;
+            }
+            if (sum3) {
+                f.y = TR(s2.by[j], C, sts[st_out]);
+                f.acc = TensorRef();
+                f.scale = 1.f;
+                f.scale_div = 0;
+                f.post_act = 0;
             }
             if (prof.on) {
                 char full[160];
@@ -575,6 +585,13 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
                     c2.post_act = 2;
                     c2.post_slope = hp.lrelu;
                 }
+                if (sum3) {
+                    c2.y = by;
+                    c2.acc = TensorRef();
+                    c2.scale = 1.f;
+                    c2.scale_div = 0;
+                    c2.post_act = 0;
+                }
             }
             return c2;
         };
@@ -613,6 +630,13 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
                     }
                 } else {
                     f.scale = 1.f;
+                }
+                if (sum3) {
+                    f.y = by;  // (the last pair's input is bt: nd is odd)
+                    f.acc = TensorRef();
+                    f.scale = 1.f;
+                    f.scale_div = 0;
+                    f.post_act = 0;
                 }
             }
             if (prof.on) {
@@ -685,18 +709,25 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             continue;
         }
         // ---- separate schedule: resblock j on its own stream (engine.h), the last launches chained j-1 -> j by events ---------------
+        // one or two utterances: side-by-side resblocks (see `sum3` above), the last — longest — chain enqueued first and on the main stream (as the 16-bit path)
+        {
+            bool odd = true;
+            for (size_t j = 0; j < nk; ++j) odd = odd && (U.rbs[j].dil.size() & 1);
+            sum3 = par && odd && !any_split && !knobs.kernel.no_rb_sum3 && !knobs.kernel.no_rb_sum3_f32 && w.ssum[0] < knobs.rb16_serial_min_frames;
+        }
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));
         }
-        for (size_t j = 0; j < nk; ++j) {
+        for (size_t jj = 0; jj < nk; ++jj) {
+            const size_t j = sum3 ? nk - 1 - jj : jj;
             const ResBlockW& R = U.rbs[j];
             const size_t nd = R.dil.size();
-            hipStream_t sj = par && j > 0 ? side_[j - 1] : stream;
+            hipStream_t sj = par && jj > 0 ? side_[jj - 1] : stream;
             const bool fuse_rb = j < 3 ? fusedrb[j] : false;
             if (j < 3 && blockrb[j]) {
                 // (the kernel adds into the shared sum: it takes the place of the resblock's last launch in the chain of additions)
-                if (par && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                if (par && j > 0 && !sum3) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
                 if (run_block(j, sj)) return -1;
                 if (par) HIP_OK(hipEventRecord(ev_done_[j], sj));
                 continue;
@@ -704,7 +735,7 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             for (size_t d = 0; d < nd; ++d) {
                 const bool last = d + 1 == nd;
                 if (!fuse_rb) HIP_OK(conv("hifigan_resblock_conv", R.c1[d], mk_c1(j, d), sj));
-                if (par && last && j > 0) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
+                if (par && last && j > 0 && !sum3) HIP_OK(hipStreamWaitEvent(sj, ev_done_[j - 1], 0));
                 if (fuse_rb) {
                     if (run_fused(j, d, sj)) return -1;
                 } else {
@@ -714,6 +745,15 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             }
         }
         if (par) HIP_OK(hipStreamWaitEvent(stream, ev_done_[nk - 1], 0));
+        if (sum3) {
+            for (size_t j = 0; j + 1 < nk; ++j) HIP_OK(hipStreamWaitEvent(stream, ev_done_[j], 0));
+            const bool div = !refmode;
+            const bool act = i + 1 < n_up;  // (the next upsampler wants leaky_relu of the stage output, vits.cpp:613: where the last resblock's epilogue applied it)
+            prof.begin("hifigan_resblock_sum", 0, 4.0 * (nk + 1) * (double)C * (double)ssum[st_out], stream);
+            HIP_OK(launch_rb_sum3_std(TR(s2.by[0], C, sts[st_out]), TR(s2.by[1], C, sts[st_out]), nk > 2 ? TR(s2.by[2], C, sts[st_out]) : TensorRef(), bsum, C, d_len[st_out], B, smax[st_out],
+                                      div ? (float)nk : (float)(1.0 / (double)nk), div ? 1 : 0, act ? 2 : 0, hp.lrelu, stream));
+            prof.end(stream);
+        }
         cur = bsum;
     }
     prof.begin("hifigan_conv_post_tanh", 2.0 * dec_post_cin_ * dec_post_k_ * (double)ssum[n_up], 4.0 * (dec_post_cin_ + 1) * (double)ssum[n_up], stream);

@@ -49,6 +49,7 @@ struct KernelKnobs {
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
     int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
+    bool no_rb_sum3_f32 = false;      // VITS_NO_RB_SUM3_F32: fp32 path: the resblocks of a small-grid stage always chained through the shared sum
     bool rb_sum3_in_order = false;    // VITS_RB_SUM3_IN_ORDER: side-by-side resblocks enqueued first to last, the first on the main stream (until round 6's last step; default: the last — longest — first and on the main stream)
     bool rb_sum3_block_only = false;  // VITS_RB_SUM3_BLOCK_ONLY: the separate sum launch only for stages whose resblocks are all whole-resblock kernels (until round 6's last step: every small-grid stage)
     bool no_rb_sum3 = false;     // VITS_NO_RB_SUM3: the resblocks of an all-whole-resblock stage always chained through the shared sum (no separate sum launch on small grids)
@@ -75,6 +76,7 @@ struct KernelKnobs {
         flag("VITS_NO_RB_SUM3", k.no_rb_sum3);
         flag("VITS_RB_SUM3_BLOCK_ONLY", k.rb_sum3_block_only);
         flag("VITS_RB_SUM3_IN_ORDER", k.rb_sum3_in_order);
+        flag("VITS_NO_RB_SUM3_F32", k.no_rb_sum3_f32);
         num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
@@ -474,6 +476,8 @@ hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, i
 hipError_t launch_zp(TensorRef mean, TensorRef logvar, const int* cum, int cum_stride, const int* tok_lens, const int* frames, TensorRef noise, int noise_kind,
                      uint64_t seed, const int* seed_off, float noise_scale, TensorRef zp, int batch, int channels, int lmax, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_rb_sum3_std(TensorRef y0, TensorRef y1, TensorRef y2, TensorRef out, int channels, const int* lens, int batch, int tmax, float scale, int scale_div, int post_act,
+                              float post_slope, hipStream_t s);  // fp32 [b][c][t]: ((y0 + y1) [+ y2]) scaled [+ leaky_relu]: side-by-side resblocks of the fp32 path (small grids)
 hipError_t launch_fill_rows(TensorRef x, int channels, float v, int batch, int tmax, hipStream_t s);
 // fp32 -> int16 PCM rows on the device (test/main.cpp:31-33); lens (device, optional) limits each row
 hipError_t launch_pcm16(const float* src, int64_t src_stride, int16_t* dst, int64_t dst_stride, const int64_t* lens, int rows, int64_t cols, hipStream_t s);

@@ -1633,6 +1633,31 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* logw, int64
     }
 }
 
+// ---- ((y0 + y1) [+ y2]) * scale over fp32 [b][c][t] tensors: the sum over a stage's resblocks as its own launch (fp32 path, small grids) -------------
+// The fp32 resblock kernels carry the accumulation into the stage's shared sum in their last launch, so resblock j's last launch waits for resblock
+// j - 1's (vits.cpp:622-635's order of the additions). With one or two utterances the three chains are a few dozen blocks per kernel and the waits are
+// idle chip: here every resblock writes its own output and this kernel adds them in that order with the epilogue's expressions (a + v; the second
+// resblock's scale is 1: v * 1 = v; then the scale; then the next upsampler's leaky_relu where the last resblock's epilogue applied it): same bits.
+__global__ __launch_bounds__(256) void rb_sum3_std_kernel(const float* y0, const float* y1, const float* y2, int64_t bs, int cs, const int* lens, int tmax, float scale, int scale_div,
+                                                           int post_act, float post_slope, float* out, int64_t o_bs, int o_cs) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    const int len = lens ? lens[b] : tmax;
+    if (t >= len) return;
+    const int64_t go = (int64_t)b * bs + (int64_t)c * cs + t;
+    float x = y0[go] + y1[go];
+    if (y2) x = x + y2[go];
+    x = scale_div ? x / scale : x * scale;
+    if (post_act == 2) x = fmaxf(x, x * post_slope);
+    out[(int64_t)b * o_bs + (int64_t)c * o_cs + t] = x;
+}
+hipError_t launch_rb_sum3_std(TensorRef y0, TensorRef y1, TensorRef y2, TensorRef out, int channels, const int* lens, int batch, int tmax, float scale, int scale_div, int post_act,
+                              float post_slope, hipStream_t s) {
+    if (!y0.p || !y1.p || !out.p || y0.bs != y1.bs || y0.cs != y1.cs || (y2.p && (y2.bs != y0.bs || y2.cs != y0.cs))) return hipErrorInvalidValue;
+    dim3 grid((tmax + 255) / 256, channels, batch);
+    VITS_KLAUNCH(rb_sum3_std_kernel, grid, dim3(256), 0, s, y0.p, y1.p, y2.p, y0.bs, y0.cs, lens, tmax, scale, scale_div, post_act, post_slope, out.p, out.bs, out.cs);
+    return hipGetLastError();
+}
+
 hipError_t launch_durations(TensorRef logw, int c, const int* lens, int batch, int tmax, float length_scale, int fixed, float* dur, int* cum, int* frames,
                             int* stage_lens, int n_stage, const int* stage_mul, const int* stage_add, hipStream_t s, bool exact) {
     VITS_KLAUNCH(durations_kernel, dim3(batch), dim3(256), 0, s, logw.p, logw.bs, logw.cs, c, lens, tmax, length_scale, fixed, dur, cum, frames, stage_lens,
