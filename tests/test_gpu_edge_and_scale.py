@@ -225,8 +225,8 @@ def test_tuning_knobs_do_not_change_a_single_bit():
     for extra in ({"VITS_RB_STREAMS": "1"}, {"VITS_DB_MIN": "2", "VITS_NBUF": "3"}, {"VITS_TILE128": "0", "VITS_NARROW_TILES": "0"},
                   {"VITS_MIN_BLOCKS": "100000", "VITS_LRELU_COPY_MINC": "32"}, {"VITS_NO_ONESHOT": "1"}, {"VITS_NO_NARROW": "1"},
                   {"VITS_ATT_NW": "8"}, {"VITS_ATT_SHORT": "0"}, {"VITS_NO_ATT_LAT": "1"}, {"VITS_NO_ATT_LAT": "1", "VITS_ATT_NW": "4"},
-                  # fp32 vocoder on small grids: the resblocks of a stage side by side + one sum launch (default below 600 frames) never, on every grid, and with every pair as two launches
-                  {"VITS_NO_RB_SUM3_F32": "1"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000", "VITS_NO_FUSE32": "1"}, {"VITS_RB16_SERIAL_MIN_FRAMES": "1000000", "VITS_NO_RBBLOCK32": "1"}, {"VITS_LN_TW": "64"}, {"VITS_NO_LAT16": "1"}, {"VITS_LAT16_MAX_WAVES": "0"}, {"VITS_LAT16_MAX_WAVES": "100000"}, {"VITS_FUSE32_C128": "0"}, {"VITS_NO_RBBLOCK32": "1"}, {"VITS_NO_RBBLOCK32": "1", "VITS_RB_GROUP": "1"}, {"VITS_NARROW_K1": "0", "VITS_MIN_BLOCKS": "512"}, {"VITS_RB_GROUP": "1"}, {"VITS_MIN_BLOCKS": "1", "VITS_RB_GROUP": "1"}, {"VITS_MIN_BLOCKS": "1", "VITS_NO_RB_GROUP": "1"},
+                  # fp32 vocoder on small grids: the resblocks of a stage side by side + one sum launch (default below 2000 frames) never, on every grid, and with every pair as two launches
+                  {"VITS_NO_RB_SUM3_F32": "1"}, {"VITS_RB32_SUM3_MAX_FRAMES": "1000000"}, {"VITS_RB32_SUM3_MAX_FRAMES": "1000000", "VITS_NO_FUSE32": "1"}, {"VITS_RB32_SUM3_MAX_FRAMES": "1000000", "VITS_NO_RBBLOCK32": "1"}, {"VITS_RB32_SUM3_MAX_FRAMES": "0"}, {"VITS_LN_TW": "64"}, {"VITS_NO_LAT16": "1"}, {"VITS_LAT16_MAX_WAVES": "0"}, {"VITS_LAT16_MAX_WAVES": "100000"}, {"VITS_FUSE32_C128": "0"}, {"VITS_NO_RBBLOCK32": "1"}, {"VITS_NO_RBBLOCK32": "1", "VITS_RB_GROUP": "1"}, {"VITS_NARROW_K1": "0", "VITS_MIN_BLOCKS": "512"}, {"VITS_RB_GROUP": "1"}, {"VITS_MIN_BLOCKS": "1", "VITS_RB_GROUP": "1"}, {"VITS_MIN_BLOCKS": "1", "VITS_NO_RB_GROUP": "1"},
                   {"VITS_MIN_BLOCKS": "1", "VITS_RB_GROUP": "1", "VITS_LRELU_COPY_MINC": "1000"},
                   {"VITS_NO_ONESHOT": "1", "VITS_NO_NARROW": "1", "VITS_NO_DDS_FUSE": "1", "VITS_NO_FUSE32": "1", "VITS_NO_WN_FUSE": "1"}):
         assert run(extra) == base, extra

@@ -123,6 +123,7 @@ struct Knobs {
     int lat16_lazy_tokens = 4096;  // VITS_LAT16_LAZY_TOKENS: a call of at most this many ids (batch x longest utterance) first makes the latency kernels' weight copy (0: never)
     bool lat16_eager = false;      // VITS_LAT16_EAGER: make that copy at load
     int rb16_serial_max_frames = 1300;  // VITS_RB16_SERIAL_MAX_FRAMES: 16-bit vocoder windows of at most this many frames (all utterances) use one stream ...
+    int rb32_sum3_max_frames = 2000;   // VITS_RB32_SUM3_MAX_FRAMES: fp32 vocoder: the resblocks of a stage side by side + one sum launch while the call has fewer frames than this (batch 1 ... 8 x 128 ids: 2.80 -> 2.65, 5.06 -> 4.85 (3), 6.14 -> 5.89 (4), 10.82 -> 10.76 ms (8); 0: never)
     int rb16_serial_min_frames = 600;   // VITS_RB16_SERIAL_MIN_FRAMES: ... unless they have fewer than this (one or two 128-id utterances: kernels of 15-60 blocks, three of which side by side fill more of the chip than the fork / join costs — round 6, batch 1 / 2 / 4: 1.70 -> 1.60 / 1.77 -> 1.71 / 2.09 -> 2.17 ms with three streams)
     int lrelu_copy_minc = 128;   // VITS_LRELU_COPY_MINC: stages at least this wide also store leaky_relu(y)
     bool no_dds_fuse = false;    // VITS_NO_DDS_FUSE: DDS layer as three launches

@@ -33,6 +33,7 @@ void Knobs::read() {
     if (const char* e = std::getenv("VITS_LRELU_COPY_MINC")) lrelu_copy_minc = std::atoi(e);
     if (const char* e = std::getenv("VITS_RB16_SERIAL_MAX_FRAMES")) rb16_serial_max_frames = std::atoi(e);
     if (const char* e = std::getenv("VITS_RB16_SERIAL_MIN_FRAMES")) rb16_serial_min_frames = std::atoi(e);
+    if (const char* e = std::getenv("VITS_RB32_SUM3_MAX_FRAMES")) rb32_sum3_max_frames = std::atoi(e);
     if (const char* e = std::getenv("VITS_LAT16_LAZY_TOKENS")) lat16_lazy_tokens = std::atoi(e);
     lat16_eager = flag("VITS_LAT16_EAGER");
     no_dds_fuse = flag("VITS_NO_DDS_FUSE");

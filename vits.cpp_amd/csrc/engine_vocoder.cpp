@@ -709,11 +709,11 @@ int Engine::run_vocoder_window32(Call& c, WinCtx& w) {
             continue;
         }
         // ---- separate schedule: resblock j on its own stream (engine.h), the last launches chained j-1 -> j by events ---------------
-        // one or two utterances: side-by-side resblocks (see `sum3` above), the last — longest — chain enqueued first and on the main stream (as the 16-bit path)
+        // up to eight 128-id utterances: side-by-side resblocks (see `sum3` above), the last — longest — chain enqueued first and on the main stream (as the 16-bit path)
         {
             bool odd = true;
             for (size_t j = 0; j < nk; ++j) odd = odd && (U.rbs[j].dil.size() & 1);
-            sum3 = par && odd && !any_split && !knobs.kernel.no_rb_sum3 && !knobs.kernel.no_rb_sum3_f32 && w.ssum[0] < knobs.rb16_serial_min_frames;
+            sum3 = par && odd && !any_split && !knobs.kernel.no_rb_sum3 && !knobs.kernel.no_rb_sum3_f32 && w.ssum[0] < knobs.rb32_sum3_max_frames;
         }
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
