@@ -43,6 +43,9 @@ struct Conv16LatParams {
     const uint16_t* x;  // group layout [b][C/8][x_ts][8], already activated
     int64_t x_bs;
     int x_ts;
+    const float* xf;  // XF32: the input as fp32 [b][c][t] instead — rounded on its way into LDS (launch_to_group16's expression: the conv_pre of the vocoder)
+    int64_t xf_bs;
+    int xf_cs;
     const uint16_t* wp;  // A fragments (pack_conv_weights16)
     const float* bias;
     const int* lens;
@@ -62,7 +65,7 @@ struct Conv16LatParams {
 };
 
 // Block = WM waves = WM consecutive 32-row tiles of the same 32 NR columns.
-template <int KT, int C, int WM, int NR, bool BF>
+template <int KT, int C, int WM, int NR, bool BF, bool XF32 = false>  // C: input channels (= output channels for the resblock convs; the launch's grid says how many row tiles)
 __global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatParams p) {
     using namespace c16l;
     constexpr int G = C / 8, NCH = C / 32, STEPS = 2 * KT, TOTAL = NCH * STEPS, BN = 32 * NR;
@@ -112,7 +115,30 @@ __global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatPara
     }
 
     // ---- the input tile, all groups, straight into LDS ----
-    {
+    if constexpr (XF32) {
+        // fp32 [c][t] -> rounded 16-byte slots (8 channels of one time step), launch_to_group16's expression with slope 1; zero outside the sequence
+        const float* xb = p.xf + (int64_t)b * p.xf_bs;
+        const int tx0 = t0 - p.pad_l;
+        const int xw = BN + (KT - 1) * dil;
+        for (int idx = (int)threadIdx.x; idx < G * xw; idx += WM * 64) {
+            const int g = idx / xw, sl = idx - g * xw;
+            const int t = tx0 + sl;
+            int4v o = {0, 0, 0, 0};
+            if (t >= 0 && t < len) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = xb[(int64_t)(g * 8 + e) * p.xf_cs + t];
+                    v[e] = fmaxf(f, f * 1.0f);
+                }
+                o.x = (int)pack16<BF>(v[0], v[1]);
+                o.y = (int)pack16<BF>(v[2], v[3]);
+                o.z = (int)pack16<BF>(v[4], v[5]);
+                o.w = (int)pack16<BF>(v[6], v[7]);
+            }
+            xs[g * pitch + sl] = o;
+        }
+    } else {
         const uint16_t* xb = p.x + (int64_t)b * p.x_bs;
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xb), 0, 0x7fffffff, 0x00020000);
         const int tx0 = t0 - p.pad_l;
@@ -260,9 +286,44 @@ static hipError_t launch_c16l(const Conv16LatParams& p, int batch, hipStream_t s
     return hipGetLastError();
 }
 
+// The vocoder's conv_pre (F -> up_init channels, k = 7, vits.cpp:601) on a small grid, straight from the fp32 flow output: the converter launch
+// (launch_to_group16) and the throughput kernel's 14 us become one launch of this kernel (batch 1: - 15 us). Same rounding expression, same K order,
+// same group epilogue: same bits.
+bool conv16_lat_pre_wanted(const PackedConv& w, int batch, int tmax) {
+    const KernelKnobs& kn = kernel_knobs();
+    if (kn.no_lat16h || kn.no_lat16h_pre || !w.wp16 || !w.bias || w.epi != EPI_STD) return false;
+    if (w.cin != 192 || w.kt != 7 || (w.cout % 64) != 0) return false;
+    const int64_t tiles = (int64_t)((tmax + 31) / 32) * (w.cout / 32) * batch;
+    return tiles <= kn.lat16h_max_tiles;
+}
+hipError_t launch_conv16_lat_pre(const PackedConv& w, TensorRef x, const int* lens, int batch, int tmax, Ref16 y16, float y16_slope, int arith, hipStream_t s) {
+    if (!conv16_lat_pre_wanted(w, batch, tmax) || !x.p || !y16.p) return hipErrorInvalidValue;
+    Conv16LatParams p = {};
+    p.xf = x.p;
+    p.xf_bs = x.bs;
+    p.xf_cs = x.cs;
+    p.wp = w.wp16;
+    p.bias = w.bias;
+    p.lens = lens;
+    p.tmax = tmax;
+    p.dil = 1;
+    p.pad_l = (w.kt - 1) / 2;
+    p.pitch = (32 + (w.kt - 1) + 7) / 8 * 8;
+    p.y16 = y16.p;
+    p.y16_bs = y16.bs;
+    p.y16_ts = y16.ts;
+    p.y16_slope = y16_slope;
+    p.scale = 1.f;
+    const size_t lds = (size_t)(192 / 8) * p.pitch * 16 + 8 * 16;
+    dim3 grid((tmax + 31) / 32, w.cout / 32 / 2, batch);
+    if (arith == VITS_ARITH_BF16) VITS_KLAUNCH((conv16_lat_kernel<7, 192, 2, 1, true, true>), grid, dim3(128), lds, s, p);
+    else VITS_KLAUNCH((conv16_lat_kernel<7, 192, 2, 1, false, true>), grid, dim3(128), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
     if (!conv16_lat_wanted(w, c)) return hipErrorInvalidValue;
-    Conv16LatParams p;
+    Conv16LatParams p = {};
     p.x = c.x.p;
     p.x_bs = c.x.bs;
     p.x_ts = c.x.ts;

@@ -36,11 +36,17 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
     Ref16 z16 = x16_[0];
     z16.ts = round_up(Lw, 8);
     z16.bs = (int64_t)(F / 8) * z16.ts * 8;
-    prof.begin("to_group16", 0, 6.0 * F * (double)ssum[0], stream, true);
-    HIP_OK(launch_to_group16(zwin, d_len[0], B, F, Lw, 1.0f, z16, arith_now_, stream));
-    prof.end(stream);
     Ref16 cur16 = R16(s2.h0, hp.up_init, lws);
-    {
+    // one to four utterances: conv_pre reads the fp32 flow output itself and runs on conv16_lat_kernel (conv16_lat.hip: no converter launch; same bits)
+    const bool pre_lat = !prof.on && F == dec_pre_.cin && conv16_lat_pre_wanted(dec_pre_, B, Lw);
+    if (pre_lat) {
+        HIP_OK(launch_conv16_lat_pre(dec_pre_, zwin, d_len[0], B, Lw, cur16, hp.lrelu, arith_now_, stream));
+    } else {
+        prof.begin("to_group16", 0, 6.0 * F * (double)ssum[0], stream, true);
+        HIP_OK(launch_to_group16(zwin, d_len[0], B, F, Lw, 1.0f, z16, arith_now_, stream));
+        prof.end(stream);
+    }
+    if (!pre_lat) {
         Conv16Call c;
         c.x = z16;
         c.len_in = c.len_out = d_len[0];

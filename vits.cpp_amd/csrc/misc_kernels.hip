@@ -509,13 +509,13 @@ __global__ __launch_bounds__(64 * NW, LAT ? 2 : (SHORT ? 4 : 3)) void rel_attent
             }
         }
     };
-    att_float4v vpre[4];
+    att_float4v vpre[8];  // (eight groups = 128 keys: the whole row of a 128-token utterance)
     float evp[4];
     if constexpr (LAT) {
         if (wid < ndt) {
             const float* vrow = vb + (int64_t)(wid * 16 + ln) * v_cs;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) load_v(i, vrow, vpre[i]);
+            for (int i = 0; i < 8; ++i) load_v(i, vrow, vpre[i]);
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
                 const int r = 4 * s2 + lk;
@@ -561,7 +561,12 @@ __global__ __launch_bounds__(64 * NW, LAT ? 2 : (SHORT ? 4 : 3)) void rel_attent
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const att_float4v pa = pr[i], vv = vr[i];
-                    load_group(g + 4 + i, pr[i], vr[i]);
+                    if (LAT && u == 0 && g == 0) {  // (groups 4-7: V came with the first four)
+                        pr[i] = *reinterpret_cast<const att_float4v*>(prow + 16 * (4 + i < ng ? 4 + i : ng - 1));
+                        vr[i] = vpre[4 + i];
+                    } else {
+                        load_group(g + 4 + i, pr[i], vr[i]);
+                    }
                     if (g + i < ng) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], vv[e], a4, 0, 0, 0);
