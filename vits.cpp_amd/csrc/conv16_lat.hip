@@ -64,14 +64,15 @@ struct Conv16LatParams {
     int scale_div;
 };
 
-// Block = WM waves = WM consecutive 32-row tiles of the same 32 NR columns.
-template <int KT, int C, int WM, int NR, bool BF, bool XF32 = false>  // C: input channels (= output channels for the resblock convs; the launch's grid says how many row tiles)
-__global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatParams p) {
+// Block = WM waves = WM consecutive 32-row tiles of the same 32 NR columns. (The body as a device function: conv16_lat_kernel runs it for one conv,
+// conv16_lat_group_kernel for the same-position convs of a stage's three resblocks in ONE launch.)
+template <int KT, int C, int WM, int NR, bool BF, bool XF32>  // C: input channels (= output channels for the resblock convs; the launch's grid says how many row tiles)
+__device__ __forceinline__ void conv16_lat_body(const Conv16LatParams& p, c16l::int4v* xs, const int b) {
     using namespace c16l;
     constexpr int G = C / 8, NCH = C / 32, STEPS = 2 * KT, TOTAL = NCH * STEPS, BN = 32 * NR;
-    extern __shared__ __attribute__((aligned(16))) int4v xs[];  // [G][pitch] slots of 8 x 16 bit; slot s of a row <-> time t0 - pad_l + s
+    // xs: [G][pitch] slots of 8 x 16 bit; slot s of a row <-> time t0 - pad_l + s
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, t0 = blockIdx.x * BN;
+    const int t0 = blockIdx.x * BN;
     const int len = p.lens ? p.lens[b] : p.tmax;
     if (t0 >= len) return;
     const int rt = blockIdx.y * WM + wid;  // this wave's 32-row tile
@@ -255,6 +256,27 @@ __global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatPara
     }
 }
 
+template <int KT, int C, int WM, int NR, bool BF, bool XF32 = false>
+__global__ __launch_bounds__(WM * 64) void conv16_lat_kernel(const Conv16LatParams p) {
+    extern __shared__ __attribute__((aligned(16))) c16l::int4v xs_dyn16[];
+    conv16_lat_body<KT, C, WM, NR, BF, XF32>(p, xs_dyn16, (int)blockIdx.z);
+}
+
+// The same-position convs of a stage's three resblocks (k = 3 / 7 / 11, equal dilation) in ONE launch: blockIdx.z = 3 x utterance + member. At one to four
+// utterances the three chains of a stage ran on three streams — a fork and a join of 20-45 us of queue hand-over each per stage; as six grouped launches (+ the
+// sum launch) on the main stream there is neither (batch 1: the C = 256 stage 106 -> see DESIGN 9). A member is the body above, instruction for instruction.
+struct Conv16LatGroupParams {
+    Conv16LatParams m[3];  // members in the order k = 3, 7, 11
+};
+template <int C, int WM, int NR, bool BF>
+__global__ __launch_bounds__(WM * 64) void conv16_lat_group_kernel(const Conv16LatGroupParams gp) {
+    extern __shared__ __attribute__((aligned(16))) c16l::int4v xs_dyn16g[];
+    const int member = (int)blockIdx.z % 3, b = (int)blockIdx.z / 3;
+    if (member == 0) conv16_lat_body<3, C, WM, NR, BF, false>(gp.m[0], xs_dyn16g, b);
+    else if (member == 1) conv16_lat_body<7, C, WM, NR, BF, false>(gp.m[1], xs_dyn16g, b);
+    else conv16_lat_body<11, C, WM, NR, BF, false>(gp.m[2], xs_dyn16g, b);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 // Which convs: the group-layout ResBlock convs (same length in and out, bias, no activation of the stored value) of a C = 128 / 256
 // stage with k = 3 / 7 / 11, while the launch has at most VITS_LAT16H_MAX_TILES (C = 256) / VITS_LAT16H_MAX_TILES_C128 32 x 32 output tiles (one to four utterances).
@@ -321,8 +343,7 @@ hipError_t launch_conv16_lat_pre(const PackedConv& w, TensorRef x, const int* le
     return hipGetLastError();
 }
 
-hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
-    if (!conv16_lat_wanted(w, c)) return hipErrorInvalidValue;
+static Conv16LatParams c16l_params(const PackedConv& w, const Conv16Call& c, int nr) {
     Conv16LatParams p = {};
     p.x = c.x.p;
     p.x_bs = c.x.bs;
@@ -344,11 +365,54 @@ hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith
     p.y16_slope = c.y16_slope;
     p.scale = c.scale;
     p.scale_div = c.scale_div;
+    p.pitch = (32 * nr + (w.kt - 1) * c.dil + 7) / 8 * 8;
+    return p;
+}
+
+// the group launch: members k = 3, 7, 11 of one stage (C = 256), equal shapes; two row tiles x 32 columns per block
+bool conv16_lat_group_wanted(const PackedConv* const* w, const Conv16Call* c) {
+    if (kernel_knobs().no_lat16h_group) return false;
+    static const int kts[3] = {3, 7, 11};
+    for (int i = 0; i < 3; ++i) {
+        if (!conv16_lat_wanted(*w[i], c[i]) || w[i]->kt != kts[i] || w[i]->cin != 256) return false;
+        if (c[i].batch != c[0].batch || c[i].t_out != c[0].t_out || c[i].len_out != c[0].len_out || c[i].dil != c[0].dil) return false;
+    }
+    return true;
+}
+hipError_t launch_conv16_lat_group(const PackedConv* const* w, const Conv16Call* c, int arith, hipStream_t s) {
+    if (!conv16_lat_group_wanted(w, c)) return hipErrorInvalidValue;
+    Conv16LatGroupParams gp;
+    const int shape = kernel_knobs().lat16h_group_shape;  // 10 WM + NR
+    const int wm = shape / 10, nr = shape % 10;
+    int pitch = 0;
+    for (int i = 0; i < 3; ++i) {
+        gp.m[i] = c16l_params(*w[i], c[i], nr);
+        pitch = gp.m[i].pitch > pitch ? gp.m[i].pitch : pitch;
+    }
+    const size_t lds = (size_t)(256 / 8) * pitch * 16 + 8 * 16;
+    dim3 grid((c[0].t_out + 32 * nr - 1) / (32 * nr), 256 / 32 / wm, 3 * c[0].batch);
+    const bool bf = arith == VITS_ARITH_BF16;
+#define VITS_C16LG(WM_, NR_)                                                                                                                        \
+    if (wm == WM_ && nr == NR_) {                                                                                                                   \
+        if (bf) VITS_KLAUNCH((conv16_lat_group_kernel<256, WM_, NR_, true>), grid, dim3(64 * WM_), lds, s, gp);                                      \
+        else VITS_KLAUNCH((conv16_lat_group_kernel<256, WM_, NR_, false>), grid, dim3(64 * WM_), lds, s, gp);                                        \
+        return hipGetLastError();                                                                                                                   \
+    }
+    VITS_C16LG(2, 1)
+    VITS_C16LG(4, 1)
+    VITS_C16LG(2, 2)
+    VITS_C16LG(4, 2)
+#undef VITS_C16LG
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s) {
+    if (!conv16_lat_wanted(w, c)) return hipErrorInvalidValue;
     const bool bf = arith == VITS_ARITH_BF16;
     // shape (VITS_LAT16H_SHAPE = 10 WM + NR): two row tiles x 32 columns per block by default (batch 1: 1.483 ms against 1.498 with 64 columns and 1.492 with four row tiles x 64)
     const int shape = kernel_knobs().lat16h_shape;
     const int wm = shape / 10, nr = shape % 10;
-    p.pitch = (32 * nr + (w.kt - 1) * c.dil + 7) / 8 * 8;
+    const Conv16LatParams p = c16l_params(w, c, nr);
 #define VITS_C16L_GO(K, CC, WM_, NR_)                                                                                                           \
     if (w.kt == K && w.cin == CC && wm == WM_ && nr == NR_) return bf ? launch_c16l<K, CC, WM_, NR_, true>(p, c.batch, s) : launch_c16l<K, CC, WM_, NR_, false>(p, c.batch, s)
 #define VITS_C16L_SHAPES(K, CC) \

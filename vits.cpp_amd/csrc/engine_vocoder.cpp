@@ -119,6 +119,66 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         // output side by side with the others and launch_rb_sum3 adds them in the reference's order (rbblock16.hip; same bits; the C = 32 stage at batch 1:
         // three chained 15-25 us kernels + two event hand-overs = 105 us, side by side + the sum ~40)
         const bool sum3 = par && (all_block || !knobs.kernel.rb_sum3_block_only) && nk >= 2 && !knobs.kernel.no_rb_sum3 && w.ssum[0] < knobs.rb16_serial_min_frames;
+        // Side-by-side resblocks whose convs all run on conv16_lat_kernel (the C = 256 stage at one to four utterances): the same-position convs of the three
+        // resblocks as ONE launch each (conv16_lat_group_kernel), six launches + the sum on the main stream — no fork, no join (each was 20-45 us of queue
+        // hand-over per stage at batch 1). Same kernels' bodies on the same operands: same bits.
+        if (sum3 && nk == 3) {
+            auto mk16 = [&](size_t j, size_t d, Conv16Call& c1, Conv16Call& c2) {
+                const ResBlockW& R = U.rbs[j];
+                const size_t nd = R.dil.size();
+                const int q = (int)j;
+                const Ref16 byl16 = R16(s2.byl[q], C, sts[st_out]), bt16 = R16(s2.bt[q], C, sts[st_out]);
+                c1 = Conv16Call();
+                c1.x = d == 0 ? bul16 : byl16;
+                c1.len_in = c1.len_out = d_len[st_out];
+                c1.batch = B;
+                c1.t_in = c1.t_out = smax[st_out];
+                c1.sum_in = c1.sum_out = ssum[st_out];
+                c1.dil = R.dil[d];
+                c1.pad_l = (R.k * R.dil[d] - R.dil[d]) / 2;
+                c1.y16 = bt16;
+                c1.y16_slope = hp.lrelu;
+                c2 = c1;
+                c2.x = bt16;
+                c2.dil = 1;
+                c2.pad_l = (R.k - 1) / 2;
+                c2.g_bs = g_bs;
+                c2.g_ts = g_ts;
+                c2.resg = d == 0 ? s2.bu : s2.by[q];
+                c2.yg = s2.by[q];  // the stream; behind the last pair the resblock's own output (launch_rb_sum3 adds the three)
+                c2.y16 = Ref16();
+                c2.y16_slope = 1.f;
+                c2.scale = 1.f;
+                if (d + 1 < nd) {
+                    c2.y16 = byl16;  // next pair's input
+                    c2.y16_slope = hp.lrelu;
+                }
+            };
+            bool group = c.fuse16 && !blockrb[0] && !blockrb[1] && !blockrb[2] && U.rbs[0].dil == U.rbs[1].dil && U.rbs[0].dil == U.rbs[2].dil;
+            const size_t nd = U.rbs[0].dil.size();
+            for (size_t d = 0; d < nd && group; ++d) {
+                const PackedConv* w1[3] = {&U.rbs[0].c1[d], &U.rbs[1].c1[d], &U.rbs[2].c1[d]};
+                const PackedConv* w2[3] = {&U.rbs[0].c2[d], &U.rbs[1].c2[d], &U.rbs[2].c2[d]};
+                Conv16Call a[3], bb[3];
+                for (size_t j = 0; j < 3; ++j) mk16(j, d, a[j], bb[j]);
+                group = conv16_lat_group_wanted(w1, a) && conv16_lat_group_wanted(w2, bb);
+            }
+            if (group) {
+                for (size_t d = 0; d < nd; ++d) {
+                    const PackedConv* w1[3] = {&U.rbs[0].c1[d], &U.rbs[1].c1[d], &U.rbs[2].c1[d]};
+                    const PackedConv* w2[3] = {&U.rbs[0].c2[d], &U.rbs[1].c2[d], &U.rbs[2].c2[d]};
+                    Conv16Call a[3], bb[3];
+                    for (size_t j = 0; j < 3; ++j) mk16(j, d, a[j], bb[j]);
+                    HIP_OK(launch_conv16_lat_group(w1, a, arith_now_, stream));
+                    HIP_OK(launch_conv16_lat_group(w2, bb, arith_now_, stream));
+                }
+                const bool div = !refmode;
+                HIP_OK(launch_rb_sum3(s2.by[0], s2.by[1], s2.by[2], C, g_bs, g_ts, d_len[st_out], B, smax[st_out], div ? (float)nk : (float)(1.0 / (double)nk), div ? 1 : 0,
+                                      knobs.keep_stage_sum32 ? s2.bs : nullptr, bsum16, i + 1 < n_up ? hp.lrelu : final_slope, arith_now_, stream));
+                cur16 = bsum16;
+                continue;
+            }
+        }
         if (par) {
             HIP_OK(hipEventRecord(ev_fork_, stream));
             for (size_t j = 1; j < nk; ++j) HIP_OK(hipStreamWaitEvent(side_[j - 1], ev_fork_, 0));

@@ -58,6 +58,8 @@ struct KernelKnobs {
     bool no_ln_fuse = false;     // VITS_NO_LN_FUSE: the encoder's LayerNorms always as their own launches (never applied on load by the consuming conv_lat16_kernel)
     bool no_dds_lat = false;     // VITS_NO_DDS_LAT: the duration predictor's DDS layers always on dds_layer_kernel (no 16-token latency kernel, no fused 1x1 convs around it)
     int dds_lat_max_blocks = 96; // VITS_DDS_LAT_MAX_BLOCKS: the latency kernel is taken while batch x ceil(tokens / 16) is at most this
+    int lat16h_group_shape = 21;  // VITS_LAT16H_GROUP_SHAPE: 10 x row tiles + column tiles per block of conv16_lat_group_kernel (21, 41, 22, 42)
+    bool no_lat16h_group = false; // VITS_NO_LAT16H_GROUP: the C = 256 stage's latency convs as 18 launches on three streams (not six grouped launches on one)
     bool no_lat16h_pre = false;  // VITS_NO_LAT16H_PRE: 16-bit modes: the vocoder's conv_pre always as converter launch + conv16_kernel
     bool no_lat16h = false;      // VITS_NO_LAT16H: 16-bit modes: the wide stages' resblock convs on small grids as fused pairs (rbpair16) / conv16_kernel, never conv16_lat_kernel
     int lat16h_max_tiles = 2048; // VITS_LAT16H_MAX_TILES: ... while a C = 256 conv has at most this many 32 x 32 output tiles (batch 1 ... 4 x 128 ids)
@@ -110,6 +112,8 @@ struct KernelKnobs {
         flag("VITS_NO_LAT16", k.no_lat16);
         flag("VITS_NO_LAT16H", k.no_lat16h);
         flag("VITS_NO_LAT16H_PRE", k.no_lat16h_pre);
+        flag("VITS_NO_LAT16H_GROUP", k.no_lat16h_group);
+        num("VITS_LAT16H_GROUP_SHAPE", k.lat16h_group_shape);
         num("VITS_LAT16H_MAX_TILES", k.lat16h_max_tiles);
         num("VITS_LAT16H_MAX_TILES_C128", k.lat16h_max_tiles_c128);
         num("VITS_LAT16H_SHAPE", k.lat16h_shape);
@@ -397,6 +401,8 @@ int choose_conv16_tile(int rows, int epi, int ncols_max, int mtiles_used, int ba
 bool conv16_lat_shape_ok(int channels, int kt, int dil, int batch, int tmax);
 bool conv16_lat_wanted(const PackedConv& w, const Conv16Call& c);
 hipError_t launch_conv16_lat(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
+bool conv16_lat_group_wanted(const PackedConv* const* w, const Conv16Call* c);  // the same-position convs of a stage's three resblocks (k = 3, 7, 11) as ONE launch
+hipError_t launch_conv16_lat_group(const PackedConv* const* w, const Conv16Call* c, int arith, hipStream_t s);
 bool conv16_lat_pre_wanted(const PackedConv& w, int batch, int tmax);  // the vocoder's conv_pre on a small grid, straight from the fp32 flow output (no converter launch)
 hipError_t launch_conv16_lat_pre(const PackedConv& w, TensorRef x, const int* lens, int batch, int tmax, Ref16 y16, float y16_slope, int arith, hipStream_t s);
 hipError_t launch_conv16(const PackedConv& w, const Conv16Call& c, int arith, hipStream_t s);
