@@ -40,12 +40,13 @@ def model(arch, arith, ref=False):
         if ref == "unsplit":  # ... and its whole-resblock kernels (16-bit modes) walk segments of three tiles from two tiles up, the main handle's one tile per block at these sizes
             os.environ["VITS_RBB_STREAM_MIN_BLOCKS"], os.environ["VITS_RBB_STREAM_TILES"] = "1", "3"
             os.environ["VITS_NO_LAT16H"] = "1"  # ... and the wide stages' resblock convs never take conv16_lat_kernel (the main handle's do on small grids)
+            os.environ["VITS_NO_RBB_GROUP3"] = "1"  # ... and the narrow 16-bit stages' whole-resblock kernels are three launches on three streams (the main handle: one grouped launch on small grids)
             os.environ["VITS_NO_RB_SUM3_F32"] = "1"  # ... and the fp32 vocoder's resblocks always chain through the shared sum (the main handle's run side by side on small grids)
         try:
             models[key] = [pkg.Model(pkg.synth_model_bytes(0x5EED, arch)), "f32", False]
         finally:
             del os.environ["VITS_SPLIT_MIN_BATCH"], os.environ["VITS_SPLIT_FIRST_PCT"]
-            os.environ.pop("VITS_RBB_STREAM_MIN_BLOCKS", None), os.environ.pop("VITS_RBB_STREAM_TILES", None), os.environ.pop("VITS_NO_LAT16H", None), os.environ.pop("VITS_NO_RB_SUM3_F32", None)
+            os.environ.pop("VITS_RBB_STREAM_MIN_BLOCKS", None), os.environ.pop("VITS_RBB_STREAM_TILES", None), os.environ.pop("VITS_NO_LAT16H", None), os.environ.pop("VITS_NO_RB_SUM3_F32", None), os.environ.pop("VITS_NO_RBB_GROUP3", None)
     e = models[key]
     if e[1] != arith:
         e[0].set_arith(ARITH[arith])

@@ -346,6 +346,7 @@ def test_16bit_kernel_choices_do_not_change_a_single_bit(name):
                   {"VITS_RBB_STREAM_MIN_BLOCKS": "1"}, {"VITS_RBB_STREAM_TILES": "0"},
                   # the wide stages' resblock convs on small grids: conv16_lat_kernel (default up to 2048 tiles at C = 256) in its three block shapes, on every
                   # grid and at C = 128 as well, never; the side-by-side resblock sum only for whole-resblock stages / in the old enqueue order
+                  {"VITS_NO_RBB_GROUP3": "1"}, {"VITS_NO_RBB_GROUP3_C64": "1"}, {"VITS_NO_RBB_GROUP3": "1", "VITS_NO_LAT16H_GROUP": "1"},
                   {"VITS_NO_LAT16H": "1"}, {"VITS_NO_LAT16H_PRE": "1"}, {"VITS_NO_LAT16H_GROUP": "1"}, {"VITS_LAT16H_GROUP_SHAPE": "42"}, {"VITS_LAT16H_GROUP_SHAPE": "22", "VITS_LAT16H_MAX_TILES": "1000000"}, {"VITS_LAT16H_SHAPE": "22"}, {"VITS_LAT16H_SHAPE": "42"}, {"VITS_LAT16H_MAX_TILES": "1000000", "VITS_LAT16H_MAX_TILES_C128": "1000000"},
                   {"VITS_LAT16H_MAX_TILES": "1000000", "VITS_LAT16H_MAX_TILES_C128": "1000000", "VITS_LAT16H_SHAPE": "42", "VITS_RB16_SERIAL_MIN_FRAMES": "1000000"},
                   {"VITS_NO_ATT_LAT": "1"}, {"VITS_RB_SUM3_BLOCK_ONLY": "1"}, {"VITS_RB_SUM3_IN_ORDER": "1"}, {"VITS_NO_LAT16H": "1", "VITS_RB_SUM3_BLOCK_ONLY": "1", "VITS_RB_SUM3_IN_ORDER": "1"},

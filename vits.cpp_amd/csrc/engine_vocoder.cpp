@@ -119,6 +119,36 @@ int Engine::run_vocoder_window16(Call& c, WinCtx& w) {
         // output side by side with the others and launch_rb_sum3 adds them in the reference's order (rbblock16.hip; same bits; the C = 32 stage at batch 1:
         // three chained 15-25 us kernels + two event hand-overs = 105 us, side by side + the sum ~40)
         const bool sum3 = par && (all_block || !knobs.kernel.rb_sum3_block_only) && nk >= 2 && !knobs.kernel.no_rb_sum3 && w.ssum[0] < knobs.rb16_serial_min_frames;
+        // Side-by-side whole-resblock kernels (the C = 32 and C = 64 stages, k = 3 / 7 / 11) as ONE launch (rbblock16_group3_kernel) + the sum, on the main stream:
+        // no fork, no join (10-30 us of queue hand-over each at batch 1). The members are the kernels' bodies on the same operands: same bits.
+        if (sum3 && nk == 3 && c.fuse16 && !knobs.no_rbblock16 && blockrb[0] && blockrb[1]) {
+            const int kts[3] = {U.rbs[0].k, U.rbs[1].k, U.rbs[2].k};
+            bool dils135 = true;
+            for (int m = 0; m < 3; ++m) dils135 = dils135 && U.rbs[m].dil.size() == 3 && U.rbs[m].dil[0] == 1 && U.rbs[m].dil[1] == 3 && U.rbs[m].dil[2] == 5;
+            if (dils135 && rbblock16_group3_supported(C, kts, B, smax[st_out])) {
+                const PackedConv* w1[3][3];
+                const PackedConv* w2[3][3];
+                RbBlock16Call f[3];
+                for (int m = 0; m < 3; ++m) {
+                    for (int d = 0; d < 3; ++d) w1[m][d] = &U.rbs[m].c1[d], w2[m][d] = &U.rbs[m].c2[d];
+                    f[m].y0 = s2.bu;
+                    f[m].lens = d_len[st_out];
+                    f[m].batch = B;
+                    f[m].tmax = smax[st_out];
+                    f[m].slope = hp.lrelu;
+                    f[m].yg = s2.by[m];  // own output: launch_rb_sum3 adds the three in the reference's order, scales, writes the 16-bit copy
+                    f[m].g_bs = g_bs;
+                    f[m].g_ts = g_ts;
+                    f[m].scale = 1.f;
+                }
+                HIP_OK(launch_rbblock16_group3(w1, w2, f, arith_now_, stream));
+                const bool div = !refmode;
+                HIP_OK(launch_rb_sum3(s2.by[0], s2.by[1], s2.by[2], C, g_bs, g_ts, d_len[st_out], B, smax[st_out], div ? (float)nk : (float)(1.0 / (double)nk), div ? 1 : 0,
+                                      knobs.keep_stage_sum32 ? s2.bs : nullptr, bsum16, i + 1 < n_up ? hp.lrelu : final_slope, arith_now_, stream));
+                cur16 = bsum16;
+                continue;
+            }
+        }
         // Side-by-side resblocks whose convs all run on conv16_lat_kernel (the C = 256 stage at one to four utterances): the same-position convs of the three
         // resblocks as ONE launch each (conv16_lat_group_kernel), six launches + the sum on the main stream — no fork, no join (each was 20-45 us of queue
         // hand-over per stage at batch 1). Same kernels' bodies on the same operands: same bits.

@@ -49,6 +49,8 @@ struct KernelKnobs {
     int flow_ncw = 2;            // VITS_FLOW_NCW=1: 16-bit coupling-layer kernel with one column tile per wave
     int convt16_r128 = 0;        // VITS_CONVT16_R128: developer override of the streaming transposed conv's shape for 128-row layers (the 128 -> 64 stride-2 upsampler): nr * 100 + csplit * 10 + (rs == 16), e.g. 211 = <2, 1, 16>; 0 = default <4, 1, 16>
     int convt16_split_max = 64;  // VITS_CONVT16_SPLIT_MAX: 16-bit stride-8 upsamplers deal the units of a position tile out over up to four blocks while the launch has at most this many tiles (0: never)
+    bool no_rbb_group3_c64 = false;   // VITS_NO_RBB_GROUP3_C64: ... only the C = 32 stage grouped
+    bool no_rbb_group3 = false;       // VITS_NO_RBB_GROUP3: the C = 32 stage's three whole-resblock kernels always as three launches (small grids: not one grouped launch)
     bool no_rb_sum3_f32 = false;      // VITS_NO_RB_SUM3_F32: fp32 path: the resblocks of a small-grid stage always chained through the shared sum
     bool rb_sum3_in_order = false;    // VITS_RB_SUM3_IN_ORDER: side-by-side resblocks enqueued first to last, the first on the main stream (until round 6's last step; default: the last — longest — first and on the main stream)
     bool rb_sum3_block_only = false;  // VITS_RB_SUM3_BLOCK_ONLY: the separate sum launch only for stages whose resblocks are all whole-resblock kernels (until round 6's last step: every small-grid stage)
@@ -80,6 +82,8 @@ struct KernelKnobs {
         flag("VITS_RB_SUM3_BLOCK_ONLY", k.rb_sum3_block_only);
         flag("VITS_RB_SUM3_IN_ORDER", k.rb_sum3_in_order);
         flag("VITS_NO_RB_SUM3_F32", k.no_rb_sum3_f32);
+        flag("VITS_NO_RBB_GROUP3", k.no_rbb_group3);
+        flag("VITS_NO_RBB_GROUP3_C64", k.no_rbb_group3_c64);
         num("VITS_DDS_LAT_MAX_BLOCKS", k.dds_lat_max_blocks);
         num("VITS_TILE128", k.tile128);
         num("VITS_MIN_BLOCKS", k.min_blocks);
@@ -344,6 +348,9 @@ struct RbBlock16Call {
 };
 bool rbblock16_supported(int channels, int kt, const int* dils, int ndil, int batch, int tmax);  // (batch x tmax: the launch's grid — C = 64, k = 11 only where it is cut into segments)
 hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s);
+// the three resblocks (k = 3, 7, 11) of a C = 32 stage as ONE launch (small grids, side-by-side resblocks): c1[m] / c2[m] = member m's three conv pairs
+bool rbblock16_group3_supported(int channels, const int* kts, int batch, int tmax);
+hipError_t launch_rbblock16_group3(const PackedConv* const (*c1)[3], const PackedConv* const (*c2)[3], const RbBlock16Call* c, int arith, hipStream_t s);
 // ((y0 + y1) [+ y2]) * scale (or / scale) over fp32 group-layout tensors, in the order and with the expressions of the resblocks' chained accumulation; the fp32 sum
 // (optional) and / or its 16-bit copy behind leaky_relu(y16_slope) — small grids: the resblocks of a stage then need not run one behind the other
 hipError_t launch_rb_sum3(const float* y0, const float* y1, const float* y2, int channels, int64_t g_bs, int g_ts, const int* lens, int batch, int tmax, float scale, int scale_div,

@@ -100,8 +100,9 @@ __device__ unsigned long long vits_rbb_phase[16 * 65536];
 // (a 32-column tile handed from wave to wave through LDS per pair: 16-28 KB, one block per CU fewer). Every element is the same chain of
 // operations on the same operands whichever tile computes it, and a history column is the value its tile computed: bit-identical to the
 // one-tile form (GPU test), which stays for grids too small to be cut into segments.
+// (The body as a device function: rbblock16_kernel runs it for one resblock, rbblock16_group3_kernel for the three resblocks of a stage in ONE launch.)
 template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF, bool STREAM>
-__global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : (C / (32 * MRW) * NSTRIP <= 4 ? 2 : 1)) void rbblock16_kernel(const RbBlockParams p) {
+__device__ __forceinline__ void rbblock16_body(const RbBlockParams& p, const int b) {
     using namespace rbb;
     constexpr int NCH = C / 32, W = NSTRIP * NRW * 32;  // (LDS tile: C / 8 channel groups x PITCH slots)
     constexpr int P2 = (KT - 1) / 2;
@@ -123,7 +124,6 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
 
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: strip / row group live in scalar registers)
     const int strip = wid % NSTRIP, rt0 = (wid / NSTRIP) * MRW;
-    const int b = blockIdx.y;
     const int len = p.lens ? p.lens[b] : p.tmax;
     const int nt = STREAM ? p.nt : 1;
     const int seg0 = blockIdx.x * (BO + (nt - 1) * ADV);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
     typedef const __attribute__((address_space(3))) int4v* LdsV;
     typedef __attribute__((address_space(3))) int4v* LdsS;
     // (the biases: requested in front of the first stream loads, so that the two round trips overlap)
-    for (int i = threadIdx.x; i < 6 * C; i += (int)blockDim.x) {
+    for (int i = threadIdx.x; i < 6 * C; i += C / (32 * MRW) * NSTRIP * 64) {  // (the body's own thread count: in a group launch the block may be larger)
         const int pi = i / (2 * C), r = i - pi * 2 * C;
         lbias[i] = r < C ? p.b1[pi][r] : p.b2[pi][r - C];
     }
@@ -407,6 +407,35 @@ __global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP ==
   }  // (tiles of the segment)
     RBB_STAMP(5);
 }
+template <int KT, int C, int NSTRIP, int NRW, int MRW, int D0, int D1, int D2, bool BF, bool STREAM>
+__global__ __launch_bounds__(C / (32 * MRW) * NSTRIP * 64, (C == 32 && NSTRIP == 4 && NRW <= 3) ? 3 : (C / (32 * MRW) * NSTRIP <= 4 ? 2 : 1)) void rbblock16_kernel(const RbBlockParams p) {
+    rbblock16_body<KT, C, NSTRIP, NRW, MRW, D0, D1, D2, BF, STREAM>(p, (int)blockIdx.y);
+}
+// The three resblocks of a narrow stage (k = 3, 7, 11; equal block shapes) in ONE launch: blockIdx.y = 3 x utterance + member; blocks past a member's last
+// tile leave at once. One or two utterances, side-by-side resblocks (launch_rb_sum3 adds their outputs): one launch on the main stream instead of three on three
+// streams behind a fork and in front of a join of 10-30 us each (the C = 32 stage at batch 1: 63 -> see DESIGN 9). A member is the kernel's body.
+struct RbBlockGroup3Params {
+    RbBlockParams m[3];
+};
+// member shapes (column strips, 32-column tiles per wave): those of launch_rbblock16 — C = 32: 4 x 3 for every k; C = 64: 2 x 4 for k = 3 / 7 (four waves), 4 x 3 for
+// k = 11 (eight waves: the block is eight waves and a four-wave member's upper four leave before its first barrier)
+template <int C, bool BF>
+__global__ __launch_bounds__(C == 32 ? 256 : 512, C == 32 ? 3 : 2) void rbblock16_group3_kernel(const RbBlockGroup3Params gp) {
+    const int member = (int)blockIdx.y % 3, b = (int)blockIdx.y / 3;
+    if constexpr (C == 32) {
+        if (member == 0) rbblock16_body<3, C, 4, 3, 1, 1, 3, 5, BF, false>(gp.m[0], b);
+        else if (member == 1) rbblock16_body<7, C, 4, 3, 1, 1, 3, 5, BF, false>(gp.m[1], b);
+        else rbblock16_body<11, C, 4, 3, 1, 1, 3, 5, BF, false>(gp.m[2], b);
+    } else {
+        if (member == 2) {
+            rbblock16_body<11, C, 4, 3, 1, 1, 3, 5, BF, false>(gp.m[2], b);
+        } else {
+            if (threadIdx.x >= 256) return;
+            if (member == 0) rbblock16_body<3, C, 2, 4, 1, 1, 3, 5, BF, false>(gp.m[0], b);
+            else rbblock16_body<7, C, 2, 4, 1, 1, 3, 5, BF, false>(gp.m[1], b);
+        }
+    }
+}
 
 // ---- the sum over a stage's resblocks as its own launch (small grids, round 6) ------------------------------------------------------------------------
 // The whole-resblock kernel carries the accumulation into the stage's shared sum itself, so the three resblocks of a narrow stage are a CHAIN of launches in
@@ -513,9 +542,8 @@ bool rbblock16_supported(int channels, int kt, const int* dils, int ndil, int ba
     return ndil == 3 && dils[0] == 1 && dils[1] == 3 && dils[2] == 5;
 }
 
-hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s) {
+static hipError_t rbb_params(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, RbBlockParams& p) {
     const int C = c1[0]->cin, kt = c1[0]->kt;
-    RbBlockParams p;
     for (int i = 0; i < 3; ++i) {
         if (!c1[i]->wp16 || !c2[i]->wp16 || !c1[i]->bias || !c2[i]->bias || c1[i]->cin != C || c1[i]->cout != C || c2[i]->cin != C || c2[i]->cout != C || c1[i]->kt != kt ||
             c2[i]->kt != kt)
@@ -541,6 +569,53 @@ hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const
     p.y16_slope = c.y16_slope;
     p.scale = c.scale;
     p.scale_div = c.scale_div;
+    p.nt = 1;
+    return hipSuccess;
+}
+
+// the three resblocks (k = 3, 7, 11) of a C = 32 stage as one launch (small grids: one tile per block); c1[m] / c2[m]: member m's three conv pairs
+bool rbblock16_group3_supported(int channels, const int* kts, int batch, int tmax) {
+    if (kernel_knobs().no_rbb_group3 || !(channels == 32 || (channels == 64 && !kernel_knobs().no_rbb_group3_c64)) || kts[0] != 3 || kts[1] != 7 || kts[2] != 11) return false;
+    const int dils[3] = {1, 3, 5};
+    for (int m = 0; m < 2; ++m)
+        if (!rbblock16_supported(channels, kts[m], dils, 3, batch, tmax)) return false;
+    // (k = 11 at C = 64 is a whole-resblock kernel here whatever VITS_RBB_C64K11 says for the single launches: measured in the group)
+    if (channels == 32 && !rbblock16_supported(channels, 11, dils, 3, batch, tmax)) return false;
+    return (long)((tmax + 183) / 184) * batch <= 3072;  // (one tile per block: well below rbb_stream_tiles_for's threshold for segments)
+}
+hipError_t launch_rbblock16_group3(const PackedConv* const (*c1)[3], const PackedConv* const (*c2)[3], const RbBlock16Call* c, int arith, hipStream_t s) {
+    RbBlockGroup3Params gp;
+    const int C = c1[0][0]->cin;
+    const int kts[3] = {c1[0][0]->kt, c1[1][0]->kt, c1[2][0]->kt};
+    if (!rbblock16_group3_supported(C, kts, c[0].batch, c[0].tmax)) return hipErrorInvalidValue;
+    for (int m = 0; m < 3; ++m) {
+        if (C == 64 && m == 2) {  // (rbb_params asks rbblock16_supported, which answers for the single launch)
+            KernelKnobs k2 = kernel_knobs();
+            k2.rbb_c64k11 = 1;
+            KernelKnobsScope scope(&k2);
+            if (hipError_t e = rbb_params(c1[m], c2[m], c[m], gp.m[m])) return e;
+        } else if (hipError_t e = rbb_params(c1[m], c2[m], c[m], gp.m[m])) return e;
+        if (c[m].batch != c[0].batch || c[m].tmax != c[0].tmax) return hipErrorInvalidValue;
+    }
+    // LDS of the k = 11 member (384 columns + the widest padding); grid.x of the member with the fewest outputs per tile (C = 32: k = 11, 264; C = 64: k = 7 on 256 columns, 184)
+    const int PITCH = (384 + 2 * 25 + 7) / 8 * 8, BOmin = C == 32 ? 264 : 184;
+    const size_t lds = (size_t)(C / 8) * PITCH * 16 + (size_t)6 * C * sizeof(float);
+    dim3 grid((c[0].tmax + BOmin - 1) / BOmin, 3 * c[0].batch);
+    const bool bf = arith == VITS_ARITH_BF16;
+    if (C == 32) {
+        if (bf) VITS_KLAUNCH((rbblock16_group3_kernel<32, true>), grid, dim3(256), lds, s, gp);
+        else VITS_KLAUNCH((rbblock16_group3_kernel<32, false>), grid, dim3(256), lds, s, gp);
+    } else {
+        if (bf) VITS_KLAUNCH((rbblock16_group3_kernel<64, true>), grid, dim3(512), lds, s, gp);
+        else VITS_KLAUNCH((rbblock16_group3_kernel<64, false>), grid, dim3(512), lds, s, gp);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rbblock16(const PackedConv* const* c1, const PackedConv* const* c2, const RbBlock16Call& c, int arith, hipStream_t s) {
+    const int C = c1[0]->cin, kt = c1[0]->kt;
+    RbBlockParams p;
+    if (hipError_t e = rbb_params(c1, c2, c, p)) return e;
     const bool bf = arith == VITS_ARITH_BF16;
     // tile shape (column strips x 32-column tiles per wave): C = 32: 4 x 3 = 384 columns, three blocks per CU. Measured alternatives (batch
     // 64 x 128 ids, f16): C = 32 with 4 x 4 = 512 columns (two blocks per CU instead of three) +5...12 %; C = 64 as 4 x 3 (eight waves, one
